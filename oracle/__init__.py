@@ -1,0 +1,28 @@
+"""CPU oracle for the assembly_gym / successor-DQN hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product tree
+(``bridges-with-reinforcement-learning_amd/``) imports this package; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may, and there only as the checker / timed CPU baseline.
+
+It is a plain float64 restatement (numpy + scalar Python; HiGHS via
+``scipy.optimize.linprog`` for the LP) of the reference's algorithm for the
+path SURVEY.md §8 names.  Every function cites the reference file:line it
+follows (paths relative to ``/root/reference``).
+
+Parity status
+-------------
+* Stability booleans: PINNED by the reference's own recorded outputs
+  (``notebooks/Stability Evaluation.ipynb`` cell 2: 96 rows, of which 94
+  reproduce and 2 are the documented IPOPT false negatives, see
+  ``tests/golden/README.md``), plus the ``AssemblyEnv.ipynb`` /
+  ``CRA_Assembly.ipynb`` known answers.
+* Geometry (placement, AABB, distances): PINNED by the float prints in
+  ``AssemblyEnv.ipynb`` cells 24-25 (``distance_to_targets``).
+* Rasters, action masks, linear rewards of a full rollout: the reference holds
+  no fixture for them and its third-party stack (compas, compas_cra, pyomo,
+  ipopt) is not installable here -> "parity unpinned"; pinned only against
+  this restatement.
+* Q-networks / replay / TD target: PINNED by fixtures generated from the
+  importable reference modules (``tests/golden/make_net_fixtures.py``).
+"""
