@@ -1,0 +1,166 @@
+"""ctypes mirror of include/bridges_hip.h and loader of libbridges_hip.so.
+
+The library is the product: if it is missing or no HIP device is present the
+entry points raise ``BridgesHipError`` -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbridges_hip.so")
+
+MAX_VERTS = 6
+MAX_BLOCKS = 16
+MAX_GROUPS = 24
+MAX_TARGETS = 8
+MAX_INTERFACES = 64
+IMG = 64
+
+FLAG_NAMES = ("valid_step", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",
+              "no_actions", "lp_error")
+STAT_NAMES = ("sum_cand", "sum_blocks", "env_steps", "reset_only", "lp_errors", "if_overflow", "locksteps",
+              "sum_valid")
+
+
+class BridgesHipError(RuntimeError):
+    pass
+
+
+class Shape(C.Structure):
+    _fields_ = [
+        ("nv", C.c_int32), ("pad_", C.c_int32),
+        ("vx", C.c_double * MAX_VERTS), ("vz", C.c_double * MAX_VERTS),
+        ("fa", C.c_int32 * MAX_VERTS), ("fb", C.c_int32 * MAX_VERTS),
+        ("fcx", C.c_double * MAX_VERTS), ("fcz", C.c_double * MAX_VERTS),
+        ("fnx", C.c_double * MAX_VERTS), ("fnz", C.c_double * MAX_VERTS),
+        ("depth", C.c_double), ("volume", C.c_double), ("gx", C.c_double), ("gz", C.c_double),
+    ]
+
+
+class Task(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("max_blocks", C.c_int32), ("max_steps", C.c_int32), ("a_max", C.c_int32),
+        ("n_shapes", C.c_int32), ("n_groups", C.c_int32),
+        ("group_shape", C.c_int32 * MAX_GROUPS), ("group_face", C.c_int32 * MAX_GROUPS),
+        ("n_ground", C.c_int32), ("n_offsets", C.c_int32), ("n_targets", C.c_int32), ("pad_", C.c_int32),
+        ("mu", C.c_double), ("density", C.c_double),
+        ("floor_half_width", C.c_double), ("floor_depth", C.c_double),
+        ("xlim", C.c_double * 2), ("ylim", C.c_double * 2),
+        ("targets", (C.c_double * 3) * MAX_TARGETS),
+        ("seed", C.c_uint64),
+        ("shapes", C.POINTER(Shape)),
+        ("x_ground", C.POINTER(C.c_double)), ("offsets", C.POINTER(C.c_double)),
+        ("grid_x", C.POINTER(C.c_double)), ("grid_y", C.POINTER(C.c_double)),
+    ]
+
+
+# (field name, torch dtype name, shape expression in E, K, C) -- order == bridges_env_buffers
+ENV_BUFFER_FIELDS = [
+    ("n_blocks", "int32", "E"),
+    ("blk_shape", "int32", "E,K"),
+    ("blk_pose", "float64", "E,K,4"),
+    ("blk_verts", "float64", "E,K,6,2"),
+    ("blk_occ", "uint8", "E,K"),
+    ("targets_left", "int32", "E"),          # uint32 on the device
+    ("state_bits", "int64", "E,64"),         # uint64 on the device
+    ("n_if", "int32", "E"),
+    ("if_body", "int32", "E,IF,2"),
+    ("if_geom", "float64", "E,IF,8"),
+    ("draw_counter", "int64", "E"),
+    ("needs_reset", "uint8", "E"),
+    ("sel_index", "int32", "E"),
+    ("step_flags", "uint8", "E,8"),
+    ("reward", "float32", "E"),
+    ("lin_reward", "float32", "E"),
+    ("n_reached", "int32", "E"),
+    ("n_cand", "int32", "E"),
+    ("n_valid", "int32", "E"),
+    ("cand_offset", "int32", "E1"),
+    ("cand_env", "int32", "C"),
+    ("cand_desc", "int32", "C,4"),
+    ("cand_ox", "float64", "C"),
+    ("cand_pose", "float64", "C,4"),
+    ("cand_verts", "float64", "C,6,2"),
+    ("cand_inb", "uint8", "C"),
+    ("cand_mask", "uint8", "C"),
+    ("cand_lin", "float32", "C"),
+    ("cand_bits", "int64", "C,64"),
+    ("cand_raster", "float32", "C,64,64"),
+    ("state_raster", "float32", "E,64,64"),
+    ("obstacle_bits", "int64", "64"),
+    ("reward_map", "float32", "64,64"),
+    ("lp_ws", "float64", "E,WS"),
+]
+
+
+class EnvBuffers(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS] + [
+        ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)]
+
+
+# put lp_ws_stride right after lp_ws as in the header (fields above are already in header order)
+assert [f[0] for f in EnvBuffers._fields_][-3:] == ["lp_ws", "lp_ws_stride", "stats"]
+
+_lib = None
+
+
+def lib():
+    """Load libbridges_hip.so (once).  Raises BridgesHipError if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BridgesHipError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
+    L.bridges_last_error.restype = C.c_char_p
+    L.bridges_device_count.restype = C.c_int
+    sigs = {
+        "bridges_env_create": [C.POINTER(Task), C.POINTER(EnvBuffers), C.POINTER(vp)],
+        "bridges_env_destroy": [vp],
+        "bridges_env_reset": [vp, vp],
+        "bridges_env_step": [vp, vp],
+        "bridges_env_select_random": [vp, vp],
+        "bridges_env_refresh": [vp, vp],
+        "bridges_shapes_upload": [C.POINTER(Shape), i32, C.POINTER(vp)],
+        "bridges_shapes_free": [vp],
+        "bridges_place": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_raster": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_bits_or": [i32, vp, vp, vp, vp],
+        "bridges_bits_to_f32": [i32, vp, vp, vp],
+        "bridges_stability": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp, vp, vp, i64, vp],
+        "bridges_soft_update": [vp, vp, i64, f32, vp],
+        "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
+    "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_refresh",
+    "bridges_place", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
+    "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",
+)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().bridges_last_error().decode(errors="replace")
+        raise BridgesHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run."""
+    import torch
+    L = lib()
+    if not torch.cuda.is_available() or L.bridges_device_count() <= 0:
+        raise BridgesHipError("no MI355X / HIP device visible: the assembly_gym hot path runs only on the "
+                              "HIP kernels of libbridges_hip.so (no CPU fallback)")
+    return L

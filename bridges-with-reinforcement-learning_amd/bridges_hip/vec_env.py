@@ -1,0 +1,251 @@
+"""VecAssemblyGym: E independent assembly_gym environments advanced in lock-step
+on one MI355X by the HIP kernels of libbridges_hip.so.
+
+Host-side mirror of ``AssemblyGym`` + the per-step feature pipeline of
+``rollout_episode`` (assembly_gym/assembly_gym/envs/gym_env.py:112-333,
+robotoddler/training/successor_dqn.py:365-475).  All state lives in device
+tensors allocated here (struct of arrays, see ``abi.ENV_BUFFER_FIELDS``); the
+library gets raw pointers.  Nothing in here computes the simulation on the
+host -- without the library or a GPU construction fails.
+
+Lock-step protocol: after ``reset()`` every env holds the candidate
+set of its (fresh) state.  ``step(sel)`` places candidate ``sel[e]`` of every
+env (or performs a reset-only step for envs whose state had no valid
+candidate), evaluates both stability variants, reward and termination,
+auto-resets finished envs and produces the candidate set of the new state.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import abi
+from .shapes import ShapeGeometry, load_urdf
+
+DEFAULT_BOUNDS = ((-3.0, -3.0, -1.0), (7.0, 7.0, 9.0))      # assembly_env.py:168
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gaussian_kernel_1d(kernel_size, sigma, device):
+    """robotoddler/utils/utils.py:93-100."""
+    coords = torch.arange(kernel_size, device=device) - kernel_size // 2
+    k = torch.exp(-(coords.float() ** 2) / (2 * sigma ** 2))
+    return k / k.sum()
+
+
+class ShapeTable:
+    """Device copy of a list of shapes for the stand-alone operators."""
+
+    def __init__(self, geoms):
+        L = abi.require_gpu()
+        self.geoms = list(geoms)
+        arr = (abi.Shape * len(self.geoms))(*[g.to_struct() for g in self.geoms])
+        self._dev = C.c_void_p()
+        abi.check(L.bridges_shapes_upload(arr, len(self.geoms), C.byref(self._dev)), "bridges_shapes_upload")
+
+    @property
+    def ptr(self):
+        return self._dev
+
+    def __del__(self):
+        try:
+            if self._dev:
+                abi.lib().bridges_shapes_free(self._dev)
+        except Exception:
+            pass
+
+
+def raster_posed(table, verts, shape_ids, grid_x, grid_y, want_bits=True, want_f32=False):
+    """bridges_raster on n posed outlines (verts [n,6,2] f64, shape_ids [n] i32, device tensors)."""
+    L = abi.require_gpu()
+    n = int(verts.shape[0])
+    dev = verts.device
+    bits = torch.empty((n, 64), dtype=torch.int64, device=dev) if want_bits else None
+    img = torch.empty((n, 64, 64), dtype=torch.float32, device=dev) if want_f32 else None
+    abi.check(L.bridges_raster(table.ptr, n, _ptr(verts), _ptr(shape_ids), _ptr(grid_x), _ptr(grid_y),
+                               _ptr(bits), _ptr(img), _stream()), "bridges_raster")
+    return bits, img
+
+
+class VecAssemblyGym:
+    def __init__(self, num_envs, shapes, obstacles, targets, max_steps=None, mu=0.8, density=1.0, bounds=None,
+                 xlim=(-3.0, 7.0), ylim=(0.0, 10.0), x_discr_ground=None, offset_values=(0.0,), seed=0,
+                 device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64)):
+        L = abi.require_gpu()
+        if tuple(img_size) != (64, 64):
+            raise NotImplementedError("the HIP rasteriser is built for 64x64 images (successor_dqn.py:585 default)")
+        self.L = L
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.E = int(num_envs)
+        self.shapes = [s if isinstance(s, ShapeGeometry) else s.geometry for s in shapes]
+        self.shape_target_faces = [list(getattr(s, "target_faces_2d", range(g.num_faces_2d)))
+                                   for s, g in zip(shapes, self.shapes)]
+        self.obstacles = [tuple(float(v) for v in o) for o in obstacles]
+        self.targets = [tuple(float(v) for v in t) for t in targets]
+        self.max_steps = int(max_steps) if max_steps else 0
+        self.K = self.max_steps if self.max_steps else abi.MAX_BLOCKS
+        if self.K > abi.MAX_BLOCKS:
+            raise ValueError(f"max_steps {self.K} > {abi.MAX_BLOCKS} (BRIDGES_MAX_BLOCKS)")
+        self.mu, self.density = float(mu), float(density)
+        bounds = DEFAULT_BOUNDS if bounds is None else bounds
+        self.bounds = tuple(tuple(float(v) for v in b) for b in bounds)
+        self.xlim, self.ylim = tuple(map(float, xlim)), tuple(map(float, ylim))
+        if x_discr_ground is None:
+            x_discr_ground = np.linspace(-2, 0, 10)               # successor_dqn.py:611
+        self.x_discr_ground = [float(v) for v in x_discr_ground]
+        self.offset_values = [float(v) for v in offset_values]
+        self.seed = int(seed)
+        # the task's shape table = the env's shapes + cube06 for obstacles/targets (gym_env.py:277)
+        self.cube06 = load_urdf("shapes/cube06.urdf")
+        self.table_geoms = self.shapes + [self.cube06]
+        self.groups = [(si, f) for si in range(len(self.shapes)) for f in self.shape_target_faces[si]]
+        if len(self.groups) > abi.MAX_GROUPS:
+            raise ValueError("too many (shape, target face) pairs")
+        max_faces = max(g.num_faces_2d for g in self.shapes)
+        bound = len(self.groups) * (len(self.x_discr_ground) + self.K * max_faces * len(self.offset_values))
+        self.a_max = int(a_max) if a_max else bound
+        self.f32_rasters = bool(f32_rasters)
+        self.grid_x = np.linspace(self.xlim[0], self.xlim[1], 64)          # rendering.py:108
+        self.grid_y = np.linspace(self.ylim[1], self.ylim[0], 64)
+        self._alloc()
+        self._task_features()
+        self._create()
+        self.reset()
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        E, K, Cc = self.E, self.K, self.E * self.a_max
+        self.ws_stride = 9 * abi.MAX_INTERFACES + (3 * K + 1) * (4 * abi.MAX_INTERFACES + 2)
+        dims = dict(E=E, K=K, C=Cc, E1=E + 1, IF=abi.MAX_INTERFACES, WS=self.ws_stride)
+        self.buf = {}
+        for name, dt, shape in abi.ENV_BUFFER_FIELDS:
+            if name in ("cand_raster", "state_raster") and not self.f32_rasters:
+                self.buf[name] = None
+                continue
+            shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))
+            self.buf[name] = torch.zeros(shp, dtype=getattr(torch, dt), device=self.device)
+        self.stats = torch.zeros(8, dtype=torch.int64, device=self.device)
+        for k, v in self.buf.items():
+            setattr(self, k, v)
+
+    def _task_features(self):
+        """get_task_features (successor_dqn.py:67-85): obstacle raster and the Gaussian-blurred target raster,
+        both rasterised by the HIP kernel from cube06 blocks (gym_env.py:277-284)."""
+        dev = self.device
+        self.table = ShapeTable(self.table_geoms)
+        cube_id = len(self.table_geoms) - 1
+        gx = torch.tensor(self.grid_x, dtype=torch.float64, device=dev)
+        gy = torch.tensor(self.grid_y, dtype=torch.float64, device=dev)
+        self.grid_x_dev, self.grid_y_dev = gx, gy
+
+        def raster_points(points):
+            if len(points) == 0:
+                return torch.zeros(64, dtype=torch.int64, device=dev)
+            verts = torch.zeros((len(points), 6, 2), dtype=torch.float64)
+            for i, p in enumerate(points):              # Block(shape=cube06, position=p): identity rotation
+                for k, (vx, vz) in enumerate(self.cube06.verts):
+                    verts[i, k, 0] = p[0] + vx
+                    verts[i, k, 1] = p[2] + vz
+            ids = torch.full((len(points),), cube_id, dtype=torch.int32, device=dev)
+            bits, _ = raster_posed(self.table, verts.to(dev), ids, gx, gy)
+            off = torch.tensor([0, len(points)], dtype=torch.int32, device=dev)
+            out = torch.empty(64, dtype=torch.int64, device=dev)
+            abi.check(self.L.bridges_bits_or(1, _ptr(off), _ptr(bits), _ptr(out), _stream()), "bridges_bits_or")
+            return out
+
+        self.buf["obstacle_bits"].copy_(raster_points(self.obstacles))
+        tbits = raster_points(self.targets)
+        timg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
+        abi.check(self.L.bridges_bits_to_f32(1, _ptr(tbits), _ptr(timg), _stream()), "bridges_bits_to_f32")
+        k1 = gaussian_kernel_1d(101, 16, dev)                              # successor_dqn.py:80-82
+        kernel = (k1.unsqueeze(0) * k1.unsqueeze(1))
+        rm = torch.nn.functional.conv2d(timg.unsqueeze(0), kernel.unsqueeze(0).unsqueeze(0), padding=50)
+        self.buf["reward_map"].copy_(rm[0, 0])
+        oimg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
+        abi.check(self.L.bridges_bits_to_f32(1, _ptr(self.buf["obstacle_bits"]), _ptr(oimg), _stream()),
+                  "bridges_bits_to_f32")
+        self.obstacle_raster = oimg                                       # [1,64,64] f32
+        self.reward_features = self.buf["reward_map"].unsqueeze(0)        # [1,64,64] f32
+
+    def _create(self):
+        t = abi.Task()
+        t.n_envs, t.max_blocks, t.max_steps, t.a_max = self.E, self.K, self.max_steps, self.a_max
+        t.n_shapes, t.n_groups = len(self.table_geoms), len(self.groups)
+        for i, (si, f) in enumerate(self.groups):
+            t.group_shape[i], t.group_face[i] = si, f
+        t.n_ground, t.n_offsets, t.n_targets = len(self.x_discr_ground), len(self.offset_values), len(self.targets)
+        t.mu, t.density = self.mu, self.density
+        t.floor_half_width = (self.bounds[1][0] - self.bounds[0][0]) / 2.0      # assembly_env.py:290-296
+        t.floor_depth = self.bounds[1][1] - self.bounds[0][1]
+        t.xlim[0], t.xlim[1], t.ylim[0], t.ylim[1] = *self.xlim, *self.ylim
+        if len(self.targets) > abi.MAX_TARGETS:
+            raise ValueError("too many targets")
+        for i, tg in enumerate(self.targets):
+            for k in range(3):
+                t.targets[i][k] = tg[k]
+        t.seed = self.seed
+        self._shape_arr = (abi.Shape * len(self.table_geoms))(*[g.to_struct() for g in self.table_geoms])
+        self._xg = (C.c_double * len(self.x_discr_ground))(*self.x_discr_ground)
+        self._off = (C.c_double * len(self.offset_values))(*self.offset_values)
+        self._gx = (C.c_double * 64)(*self.grid_x.tolist())
+        self._gy = (C.c_double * 64)(*self.grid_y.tolist())
+        t.shapes = C.cast(self._shape_arr, C.POINTER(abi.Shape))
+        dp = C.POINTER(C.c_double)
+        t.x_ground, t.offsets = C.cast(self._xg, dp), C.cast(self._off, dp)
+        t.grid_x, t.grid_y = C.cast(self._gx, dp), C.cast(self._gy, dp)
+        b = abi.EnvBuffers()
+        for name, _, _ in abi.ENV_BUFFER_FIELDS:
+            setattr(b, name, self.buf[name].data_ptr() if self.buf[name] is not None else None)
+        b.lp_ws_stride = self.ws_stride
+        b.stats = self.stats.data_ptr()
+        self._env = C.c_void_p()
+        abi.check(self.L.bridges_env_create(C.byref(t), C.byref(b), C.byref(self._env)), "bridges_env_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_env", None):
+                self.L.bridges_env_destroy(self._env)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ lock-step API
+    def reset(self):
+        abi.check(self.L.bridges_env_reset(self._env, _stream()), "bridges_env_reset")
+
+    def select_random(self):
+        """Synthetic uniform-random policy over each env's valid candidates -> sel_index."""
+        abi.check(self.L.bridges_env_select_random(self._env, _stream()), "bridges_env_select_random")
+
+    def step(self, sel_index=None):
+        if sel_index is not None:
+            self.buf["sel_index"].copy_(sel_index.to(device=self.device, dtype=torch.int32))
+        abi.check(self.L.bridges_env_step(self._env, _stream()), "bridges_env_step")
+
+    # ------------------------------------------------------------------ views
+    def flags(self):
+        f = self.buf["step_flags"]
+        return {n: f[:, i].bool() for i, n in enumerate(abi.FLAG_NAMES)}
+
+    def binary_features(self):
+        """get_state_features' binary vector [stable, collision x5] (successor_dqn.py:53-60).  The vector of the
+        current state: 'stable' of a freshly reset env is True (empty assembly, stability.py:53-56)."""
+        out = torch.zeros((self.E, 6), dtype=torch.float32, device=self.device)
+        f = self.buf["step_flags"]
+        fresh = self.buf["n_blocks"] == 0
+        out[:, 0] = torch.where(fresh, torch.ones_like(fresh), f[:, 1].bool()).float()
+        return out
+
+    def total_candidates(self):
+        return int(self.buf["cand_offset"][self.E].item())
+
+    def read_stats(self):
+        return dict(zip(abi.STAT_NAMES, self.stats.tolist()))

@@ -1,0 +1,254 @@
+// extern "C" entry points of libbridges_hip.so (see include/bridges_hip.h).  Unity build: the kernel
+// translation units are included here so one hipcc invocation produces the library.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "env_kernels.hip"
+#include "ops_kernels.hip"
+#include "dqn_kernels.hip"
+
+using namespace bridges;
+
+static thread_local char g_err[512] = "";
+
+static int fail_hip(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return BRIDGES_E_HIP;
+}
+static int fail_arg(const char* what) {
+    snprintf(g_err, sizeof(g_err), "bad argument: %s", what);
+    return BRIDGES_E_ARG;
+}
+#define HIP_TRY(x)                                        \
+    do {                                                  \
+        hipError_t e_ = (x);                              \
+        if (e_ != hipSuccess) return fail_hip(e_, #x);    \
+    } while (0)
+#define LAUNCH_CHECK(name)                                       \
+    do {                                                         \
+        hipError_t e_ = hipGetLastError();                       \
+        if (e_ != hipSuccess) return fail_hip(e_, name);         \
+    } while (0)
+
+struct bridges_env {
+    DevCtx ctx;
+    TaskTable* tt_dev;
+    int raster_blocks;
+};
+
+extern "C" {
+
+const char* bridges_last_error(void) { return g_err; }
+
+int bridges_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, bridges_env** out) {
+    if (!t || !buf || !out) return fail_arg("null");
+    if (t->n_envs <= 0) return fail_arg("n_envs");
+    if (t->max_blocks <= 0 || t->max_blocks > BRIDGES_MAX_BLOCKS) return fail_arg("max_blocks > BRIDGES_MAX_BLOCKS");
+    if (t->n_shapes <= 0 || t->n_shapes > 8) return fail_arg("n_shapes");
+    if (t->n_groups <= 0 || t->n_groups > BRIDGES_MAX_GROUPS) return fail_arg("n_groups");
+    if (t->n_ground < 0 || t->n_ground > 32 || t->n_offsets <= 0 || t->n_offsets > 8) return fail_arg("n_ground/n_offsets");
+    if (t->n_targets < 0 || t->n_targets > BRIDGES_MAX_TARGETS) return fail_arg("n_targets");
+    if (t->a_max <= 0) return fail_arg("a_max");
+    if (buf->lp_ws_stride < (int64_t)(3 * t->max_blocks + 1) * (4 * BRIDGES_MAX_INTERFACES + 2)) return fail_arg("lp_ws_stride");
+    for (int g = 0; g < t->n_groups; ++g) {
+        if (t->group_shape[g] < 0 || t->group_shape[g] >= t->n_shapes) return fail_arg("group_shape");
+        if (t->group_face[g] < 0 || t->group_face[g] >= t->shapes[t->group_shape[g]].nv) return fail_arg("group_face");
+    }
+    for (int s = 0; s < t->n_shapes; ++s)
+        if (t->shapes[s].nv < 3 || t->shapes[s].nv > BRIDGES_MAX_VERTS) return fail_arg("shape nv");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device");
+        return BRIDGES_E_NODEV;
+    }
+    bridges_env* env = new (std::nothrow) bridges_env();
+    if (!env) return fail_arg("oom");
+    TaskTable* host = new (std::nothrow) TaskTable();
+    if (!host) { delete env; return fail_arg("oom"); }
+    memset(host, 0, sizeof(TaskTable));
+    memcpy(host->shapes, t->shapes, sizeof(bridges_shape) * t->n_shapes);
+    memcpy(host->x_ground, t->x_ground, sizeof(double) * t->n_ground);
+    memcpy(host->offsets, t->offsets, sizeof(double) * t->n_offsets);
+    memcpy(host->grid_x, t->grid_x, sizeof(double) * IMG);
+    memcpy(host->grid_y, t->grid_y, sizeof(double) * IMG);
+    hipError_t e = hipMalloc((void**)&env->tt_dev, sizeof(TaskTable));
+    if (e == hipSuccess) e = hipMemcpy(env->tt_dev, host, sizeof(TaskTable), hipMemcpyHostToDevice);
+    delete host;
+    if (e != hipSuccess) { delete env; return fail_hip(e, "task table upload"); }
+    DevCtx& c = env->ctx;
+    memset(&c, 0, sizeof(c));
+    c.b = *buf;
+    c.tt = env->tt_dev;
+    c.E = t->n_envs; c.K = t->max_blocks; c.max_steps = t->max_steps; c.a_max = t->a_max;
+    c.n_groups = t->n_groups; c.n_ground = t->n_ground; c.n_offsets = t->n_offsets; c.n_targets = t->n_targets;
+    memcpy(c.group_shape, t->group_shape, sizeof(c.group_shape));
+    memcpy(c.group_face, t->group_face, sizeof(c.group_face));
+    c.mu = t->mu; c.density = t->density; c.floor_hw = t->floor_half_width; c.floor_depth = t->floor_depth;
+    c.xlim0 = t->xlim[0]; c.xlim1 = t->xlim[1]; c.ylim0 = t->ylim[0]; c.ylim1 = t->ylim[1];
+    memcpy(c.targets, t->targets, sizeof(c.targets));
+    c.seed = t->seed;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipGetDevice(&dev);
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    env->raster_blocks = cus * 8;            // 8 x 256-thread workgroups per CU, grid-stride over the work items
+    *out = env;
+    return BRIDGES_OK;
+}
+
+int bridges_env_destroy(bridges_env* env) {
+    if (!env) return BRIDGES_OK;
+    hipFree(env->tt_dev);
+    delete env;
+    return BRIDGES_OK;
+}
+
+static int refresh(bridges_env* env, hipStream_t s) {
+    const DevCtx& c = env->ctx;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, c);
+    LAUNCH_CHECK("k_scan");
+    hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
+    LAUNCH_CHECK("k_enumerate");
+    hipLaunchKernelGGL(k_raster, dim3(env->raster_blocks), dim3(256), 0, s, c);
+    LAUNCH_CHECK("k_raster");
+    hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
+    LAUNCH_CHECK("k_select");
+    return BRIDGES_OK;
+}
+
+int bridges_env_reset(bridges_env* env, void* stream) {
+    if (!env) return fail_arg("null env");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_reset, dim3(env->ctx.E), dim3(WAVE), 0, s, env->ctx);
+    LAUNCH_CHECK("k_reset");
+    return refresh(env, s);
+}
+
+int bridges_env_step(bridges_env* env, void* stream) {
+    if (!env) return fail_arg("null env");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_step, dim3(env->ctx.E), dim3(WAVE), 0, s, env->ctx);
+    LAUNCH_CHECK("k_step");
+    return refresh(env, s);
+}
+
+int bridges_env_refresh(bridges_env* env, void* stream) {
+    if (!env) return fail_arg("null env");
+    return refresh(env, (hipStream_t)stream);
+}
+
+int bridges_env_select_random(bridges_env* env, void* stream) {
+    if (!env) return fail_arg("null env");
+    hipLaunchKernelGGL(k_select, dim3(env->ctx.E), dim3(WAVE), 0, (hipStream_t)stream, env->ctx, 1);
+    LAUNCH_CHECK("k_select");
+    return BRIDGES_OK;
+}
+
+int bridges_shapes_upload(const bridges_shape* host, int32_t n, bridges_shape** out_dev) {
+    if (!host || n <= 0 || !out_dev) return fail_arg("shapes_upload");
+    HIP_TRY(hipMalloc((void**)out_dev, sizeof(bridges_shape) * n));
+    HIP_TRY(hipMemcpy(*out_dev, host, sizeof(bridges_shape) * n, hipMemcpyHostToDevice));
+    return BRIDGES_OK;
+}
+
+int bridges_shapes_free(bridges_shape* dev) {
+    if (dev) HIP_TRY(hipFree(dev));
+    return BRIDGES_OK;
+}
+
+int bridges_place(const bridges_shape* shapes_dev, int32_t n, const double* frame1, const int32_t* shape_id,
+                  const int32_t* face, const double* ox, const double* oy, double* pose, double* verts, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_place");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_place, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shapes_dev, n, frame1,
+                       shape_id, face, ox, oy, pose, verts);
+    LAUNCH_CHECK("k_place");
+    return BRIDGES_OK;
+}
+
+static int grid_for_waves(int64_t n_items) {
+    int64_t blocks = (n_items + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                   const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_raster");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_raster_generic, dim3(grid_for_waves(n)), dim3(256), 0, (hipStream_t)stream, shapes_dev, n,
+                       verts, shape_id, grid_x, grid_y, bits, img);
+    LAUNCH_CHECK("k_raster_generic");
+    return BRIDGES_OK;
+}
+
+int bridges_bits_or(int32_t n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out, void* stream) {
+    if (n_groups < 0) return fail_arg("bridges_bits_or");
+    if (n_groups == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_bits_or, dim3(n_groups), dim3(WAVE), 0, (hipStream_t)stream, n_groups, group_offset, bits, out);
+    LAUNCH_CHECK("k_bits_or");
+    return BRIDGES_OK;
+}
+
+int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream) {
+    if (n < 0) return fail_arg("bridges_bits_to_f32");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_bits_to_f32, dim3(grid_for_waves(n)), dim3(256), 0, (hipStream_t)stream, n, bits, img);
+    LAUNCH_CHECK("k_bits_to_f32");
+    return BRIDGES_OK;
+}
+
+int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose, const double* verts,
+                      const int32_t* shape_id, const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
+                      double density, double floor_half_width, double floor_depth, uint8_t* stable, double* info,
+                      double* lp_ws, int64_t lp_ws_stride, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_stability");
+    if (K <= 0 || K > BRIDGES_MAX_BLOCKS) return fail_arg("K > BRIDGES_MAX_BLOCKS");
+    if (lp_ws_stride < 9 * BRIDGES_MAX_INTERFACES + (int64_t)(3 * K + 1) * (4 * BRIDGES_MAX_INTERFACES + 2))
+        return fail_arg("lp_ws_stride");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_stability, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, shapes_dev, n, K, pose, verts, shape_id,
+                       n_blocks, fixed_mask, mu, density, floor_half_width, floor_depth, stable, info, lp_ws, lp_ws_stride);
+    LAUNCH_CHECK("k_stability");
+    return BRIDGES_OK;
+}
+
+int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, void* stream) {
+    if (n < 0) return fail_arg("bridges_soft_update");
+    if (n == 0) return BRIDGES_OK;
+    if ((((uintptr_t)target) | ((uintptr_t)policy)) & 15) return fail_arg("soft_update pointers must be 16-byte aligned");
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_soft_update, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, target, policy, n, tau);
+    LAUNCH_CHECK("k_soft_update");
+    return BRIDGES_OK;
+}
+
+int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* next_q, const float* next_sf,
+                      int64_t next_sf_row_stride, const float* action_raster, const float* lin_reward,
+                      const uint8_t* done, float gamma, int32_t sf_dim, float* q_target, float* sf_target,
+                      int32_t* argmax_row, void* stream) {
+    if (n_trans < 0 || sf_dim < 0) return fail_arg("bridges_td_target");
+    if (n_trans == 0) return BRIDGES_OK;
+    if (sf_dim > 0 && ((next_sf_row_stride & 3) || (sf_dim & 3) ||
+                       ((((uintptr_t)next_sf) | ((uintptr_t)action_raster) | ((uintptr_t)sf_target)) & 15)))
+        return fail_arg("td_target: sf rows must be 16-byte aligned");
+    hipLaunchKernelGGL(k_td_target, dim3(n_trans), dim3(256), 0, (hipStream_t)stream, n_trans, seg_offset, next_q,
+                       next_sf, next_sf_row_stride, action_raster, lin_reward, done, gamma, sf_dim, q_target, sf_target,
+                       argmax_row);
+    LAUNCH_CHECK("k_td_target");
+    return BRIDGES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// Device-side helpers shared by the gfx950 kernels.
+//
+// ARITHMETIC CONTRACT: every geometric quantity is computed with
+// separately rounded IEEE-754 binary64 operations in exactly the order written
+// here; the translation units are compiled with -ffp-contract=off so hipcc
+// cannot fuse a*b+c.  The CPU oracle (oracle/geometry.py, oracle/shapes.py,
+// oracle/raster.py, oracle/rbe.py) states the same order, which is what makes
+// poses, masks and rasters comparable bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bridges_hip.h"
+
+#define WAVE 64
+#define MAXV BRIDGES_MAX_VERTS
+#define MAXK BRIDGES_MAX_BLOCKS
+#define MAXIF BRIDGES_MAX_INTERFACES
+#define IMG BRIDGES_IMG
+
+namespace bridges {
+
+struct Frame2 {            // face frame: centre, tangent (x-axis), outward normal
+    double cx, cz, tx, tz, nx, nz;
+};
+
+// assembly_env.py:118-124 on a directed edge va->vb (oracle/shapes.py edge_frame)
+__device__ __forceinline__ Frame2 edge_frame(double ax, double az, double bx, double bz) {
+    Frame2 f;
+    f.cx = (ax + bx) * 0.5;
+    f.cz = (az + bz) * 0.5;
+    double dx = bx - ax;
+    double dz = bz - az;
+    double L = sqrt(dx * dx + dz * dz);
+    f.tx = dx / L;
+    f.tz = dz / L;
+    f.nx = -f.tz;
+    f.nz = f.tx;
+    return f;
+}
+
+__device__ __forceinline__ void rot2(double vx, double vz, double c, double s, double& ox, double& oz) {
+    ox = vx * c + vz * s;
+    oz = vz * c - vx * s;
+}
+
+// geometry.py:39-50 align_frames_2d + gym_env.py:204-216 create_block (oracle/geometry.py align)
+__device__ __forceinline__ void align_place(const Frame2& f1, double c2x, double c2z, double n2x, double n2z,
+                                            double ox, double oy, double& px, double& pz, double& c, double& s) {
+    double dot = f1.nx * n2x + f1.nz * n2z;
+    c = -dot;
+    if (c > 1.0) c = 1.0;
+    if (c < -1.0) c = -1.0;
+    double cy = f1.nz * n2x - f1.nx * n2z;
+    s = (cy + 1e-6 >= 0) ? fabs(cy) : -fabs(cy);
+    double r2x, r2z;
+    rot2(c2x, c2z, c, s, r2x, r2z);
+    px = ((f1.cx + ox * f1.tx) + oy * f1.nx) - r2x;
+    pz = ((f1.cz + ox * f1.tz) + oy * f1.nz) - r2z;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, WAVE); }
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, WAVE);
+    hi = __shfl(hi, src, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// Small constant tables of a task, resident in device memory.
+struct TaskTable {
+    bridges_shape shapes[8];
+    double x_ground[32];
+    double offsets[8];
+    double grid_x[IMG];
+    double grid_y[IMG];
+};
+
+// Everything a kernel needs, passed by value (kernarg segment, scalar loads).
+struct DevCtx {
+    bridges_env_buffers b;
+    const TaskTable* tt;
+    int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
+    int32_t group_shape[BRIDGES_MAX_GROUPS];
+    int32_t group_face[BRIDGES_MAX_GROUPS];
+    double mu, density, floor_hw, floor_depth;
+    double xlim0, xlim1, ylim0, ylim1;
+    double targets[BRIDGES_MAX_TARGETS][3];
+    uint64_t seed;
+};
+
+enum { F_VALID = 0, F_STABLE_FROZEN, F_STABLE_UNFROZEN, F_TERMINATED, F_TRUNCATED, F_DONE, F_NO_ACTIONS, F_LP_ERROR };
+enum { ST_SUM_CAND = 0, ST_SUM_BLOCKS, ST_ENV_STEPS, ST_RESET_ONLY, ST_LP_ERRORS, ST_IF_OVERFLOW, ST_LOCKSTEPS, ST_SUM_VALID };
+
+}  // namespace bridges

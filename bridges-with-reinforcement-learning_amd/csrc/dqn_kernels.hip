@@ -1,0 +1,80 @@
+// K7: fused DQN target / soft-update ops (robotoddler/training/successor_dqn.py).
+#include "bridges_device.h"
+
+namespace bridges {
+
+// update_target_net (successor_dqn.py:280-288): target = policy * tau + target * (1 - tau), f32, 16 B per lane.
+// The two products are rounded separately, as torch does (no FMA: -ffp-contract=off).
+__global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ target, const float* __restrict__ policy,
+                                                     int64_t n, float tau) {
+    const float omt = 1.f - tau;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4* t4 = reinterpret_cast<float4*>(target);
+    const float4* p4 = reinterpret_cast<const float4*>(policy);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 t = t4[i], p = p4[i];
+        t.x = p.x * tau + t.x * omt;
+        t.y = p.y * tau + t.y * omt;
+        t.z = p.z * tau + t.z * omt;
+        t.w = p.w * tau + t.w * omt;
+        t4[i] = t;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        target[i] = policy[i] * tau + target[i] * omt;
+}
+
+// train_policy_net target construction (successor_dqn.py:197-213, 222, 230).  One workgroup per transition:
+// segmented first-argmax over its next-action rows, then the q target and (optionally) the successor-feature
+// target row, 16 B per lane.
+__global__ __launch_bounds__(256) void k_td_target(int n_trans, const int32_t* __restrict__ seg_offset,
+                                                   const float* __restrict__ next_q, const float* __restrict__ next_sf,
+                                                   int64_t sf_row_stride, const float* __restrict__ action_raster,
+                                                   const float* __restrict__ lin_reward, const uint8_t* __restrict__ done,
+                                                   float gamma, int sf_dim, float* __restrict__ q_target,
+                                                   float* __restrict__ sf_target, int32_t* __restrict__ argmax_row) {
+    __shared__ float s_val[256];
+    __shared__ int s_idx[256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const int lo = seg_offset[i], hi = seg_offset[i + 1];
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int j = lo + t; j < hi; j += 256) {
+        float v = next_q[j];
+        if (v > best || (v == best && j < bidx) || bidx == 0x7fffffff) { best = v; bidx = j; }   // NaN-free inputs
+    }
+    s_val[t] = best; s_idx[t] = bidx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            float v = s_val[t + o]; int k = s_idx[t + o];
+            if (k != 0x7fffffff && (s_idx[t] == 0x7fffffff || v > s_val[t] || (v == s_val[t] && k < s_idx[t]))) {
+                s_val[t] = v; s_idx[t] = k;
+            }
+        }
+        __syncthreads();
+    }
+    const int row = s_idx[0];
+    const bool dn = done[i] != 0;
+    if (t == 0) {
+        float nq = dn ? 0.f : s_val[0];
+        q_target[i] = lin_reward[i] + gamma * nq;
+        argmax_row[i] = row;
+    }
+    if (sf_dim > 0) {
+        const float* src = next_sf + (int64_t)row * sf_row_stride;
+        const float* ar = action_raster + (int64_t)i * sf_dim;
+        float* dst = sf_target + (int64_t)i * sf_dim;
+        const int n4 = sf_dim >> 2;
+        for (int k = t; k < n4; k += 256) {
+            float4 a = reinterpret_cast<const float4*>(ar)[k];
+            float4 s = dn ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(src)[k];
+            float4 o;
+            o.x = a.x + gamma * s.x; o.y = a.y + gamma * s.y; o.z = a.z + gamma * s.z; o.w = a.w + gamma * s.w;
+            reinterpret_cast<float4*>(dst)[k] = o;
+        }
+        for (int k = (n4 << 2) + t; k < sf_dim; k += 256) dst[k] = ar[k] + gamma * (dn ? 0.f : src[k]);
+    }
+}
+
+}  // namespace bridges

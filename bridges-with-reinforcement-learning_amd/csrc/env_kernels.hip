@@ -1,0 +1,442 @@
+// Vectorised assembly_gym lock-step on gfx950: one 64-lane wavefront per environment for the
+// task logic (k_step, k_enumerate, k_select) and a persistent wave-per-image rasteriser (k_raster).
+//
+// Reference semantics (paths relative to the reference root):
+//   k_step      AssemblyGym.step + stabilities_freezing + sparse_reward + terminated
+//               (assembly_gym/assembly_gym/envs/gym_env.py:11-22, 141-145, 218-253, 325-333),
+//               lin_reward rule of rollout_episode (robotoddler/training/successor_dqn.py:397-401)
+//   k_enumerate generate_actions (robotoddler/utils/actions.py:7-52) + create_block
+//               (gym_env.py:204-216) + the bounds half of collision_on_action (gym_env.py:304-323)
+//   k_raster    render_blocks_2d / Shape.contains_2d (assembly_gym/assembly_gym/utils/rendering.py:105-113,
+//               assembly_env.py:126-137), the overlap half of filter_actions (actions.py:71-82) and
+//               sum(action_features * reward_features) (successor_dqn.py:399-401)
+#include "bridges_device.h"
+#include "rbe_device.h"
+
+namespace bridges {
+
+// ---------------------------------------------------------------------------------------------
+__device__ inline void reset_env(const DevCtx& c, int e, int lane) {
+    c.b.state_bits[(size_t)e * IMG + lane] = 0ull;
+    if (lane < c.K) c.b.blk_occ[(size_t)e * c.K + lane] = 0;
+    if (lane == 0) {
+        c.b.n_blocks[e] = 0;
+        c.b.n_if[e] = 0;
+        c.b.targets_left[e] = (c.n_targets >= 32) ? 0xffffffffu : ((1u << c.n_targets) - 1u);
+        c.b.needs_reset[e] = 0;
+    }
+}
+
+// number of raw candidates of a state: n_groups * (n_ground + n_free_faces * n_offsets)
+__device__ inline int count_candidates(const DevCtx& c, int e, int nb, int lane) {
+    int nfree = 0;
+    for (int i0 = 0; i0 < nb * MAXV; i0 += WAVE) {
+        int i = i0 + lane;
+        bool fr = false;
+        if (i < nb * MAXV) {
+            int b = i / MAXV, f = i % MAXV;
+            int nv = c.tt->shapes[c.b.blk_shape[(size_t)e * c.K + b]].nv;
+            fr = f < nv && !((c.b.blk_occ[(size_t)e * c.K + b] >> f) & 1);
+        }
+        nfree += __popcll(__ballot(fr));
+    }
+    int n = c.n_groups * (c.n_ground + nfree * c.n_offsets);
+    return n > c.a_max ? c.a_max : n;
+}
+
+__global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
+    int e = blockIdx.x, lane = threadIdx.x;
+    reset_env(c, e, lane);
+    if (lane < 8) c.b.step_flags[(size_t)e * 8 + lane] = 0;
+    int nc = count_candidates(c, e, 0, lane);
+    if (lane == 0) {
+        c.b.reward[e] = 0.f;
+        c.b.lin_reward[e] = 0.f;
+        c.b.n_reached[e] = 0;
+        c.b.draw_counter[e] = 0;
+        c.b.n_cand[e] = nc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
+    __shared__ FaceLds F;
+    __shared__ double tab[LP_TAB_LDS];
+    __shared__ int basis[WAVE];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int K = c.K;
+    const bridges_shape* shapes = c.tt->shapes;
+    uint8_t* flags = c.b.step_flags + (size_t)e * 8;
+
+    if (c.b.needs_reset[e]) {                       // reset-only lock-step (previous state had no valid action)
+        reset_env(c, e, lane);
+        if (lane < 8) flags[lane] = 0;
+        if (lane == 0) {
+            c.b.reward[e] = 0.f;
+            c.b.lin_reward[e] = 0.f;
+            c.b.n_reached[e] = 0;
+            atomicAdd((unsigned long long*)&c.b.stats[ST_RESET_ONLY], 1ull);
+        }
+        int nc = count_candidates(c, e, 0, lane);
+        if (lane == 0) c.b.n_cand[e] = nc;
+        return;
+    }
+
+    const int a = c.b.sel_index[e];
+    const size_t ci = (size_t)c.b.cand_offset[e] + a;
+    const int nb = c.b.n_blocks[e];                 // index of the new block
+    int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
+    double* pose = c.b.blk_pose + (size_t)e * K * 4;
+    double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+    const int tb = c.b.cand_desc[ci * 4 + 0], tf = c.b.cand_desc[ci * 4 + 1];
+    const int sh = c.b.cand_desc[ci * 4 + 2], fc = c.b.cand_desc[ci * 4 + 3];
+
+    // ---- append the block (gym_env.py:220-232) ----
+    if (lane < 4) pose[nb * 4 + lane] = c.b.cand_pose[ci * 4 + lane];
+    if (lane < MAXV * 2) verts[nb * MAXV * 2 + lane] = c.b.cand_verts[ci * MAXV * 2 + lane];
+    c.b.state_bits[(size_t)e * IMG + lane] |= c.b.cand_bits[ci * IMG + lane];
+    if (lane == 0) {
+        shape_id[nb] = sh;
+        uint8_t* occ = c.b.blk_occ + (size_t)e * K;
+        occ[nb] = (uint8_t)(1u << fc);
+        if (tb >= 0) occ[tb] |= (uint8_t)(1u << tf);
+        c.b.n_blocks[e] = nb + 1;
+    }
+    __syncthreads();
+
+    // ---- targets (gym_env.py:163-169, compas Box.contains_point tol 1e-6) ----
+    double vx = 0.0, vz = 0.0;
+    const int nvn = shapes[sh].nv;
+    bool hasv = lane < nvn;
+    if (hasv) { vx = verts[nb * MAXV * 2 + 2 * lane]; vz = verts[nb * MAXV * 2 + 2 * lane + 1]; }
+    double x0 = wave_min_d(hasv ? vx : 1e300), x1 = wave_max_d(hasv ? vx : -1e300);
+    double z0 = wave_min_d(hasv ? vz : 1e300), z1 = wave_max_d(hasv ? vz : -1e300);
+    uint32_t left = c.b.targets_left[e];
+    {
+        double cx = (x0 + x1) * 0.5, cz = (z0 + z1) * 0.5, hx = (x1 - x0) * 0.5, hz = (z1 - z0) * 0.5;
+        double hy = shapes[sh].depth * 0.5;
+        for (int t = 0; t < c.n_targets; ++t) {
+            if (!((left >> t) & 1u)) continue;
+            bool in = fabs(c.targets[t][0] - cx) < hx + 1e-6 && fabs(c.targets[t][1]) < hy + 1e-6 &&
+                      fabs(c.targets[t][2] - cz) < hz + 1e-6;
+            if (in) left &= ~(1u << t);
+        }
+    }
+    const int n_reached = c.n_targets - __popc(left);
+
+    // ---- contact interfaces of the new block (assembly_env.py:281-304) ----
+    int32_t* if_body = c.b.if_body + (size_t)e * MAXIF * 2;
+    double* if_geom = c.b.if_geom + (size_t)e * MAXIF * 8;
+    stage_faces(F, 0, 1 + (nb + 1) * MAXV, verts, shape_id, shapes, c.floor_hw, lane);
+    __syncthreads();
+    bool overflow = false;
+    int n_if = append_interfaces(F, nb, shape_id, shapes, c.floor_depth, c.b.n_if[e], if_body, if_geom, lane, &overflow);
+    __syncthreads();
+
+    // ---- stability with the last block frozen / nothing frozen (gym_env.py:238-245, 325-333) ----
+    double* ws = c.b.lp_ws + (size_t)e * c.b.lp_ws_stride;
+    bool err = false;
+    double w;
+    int piv;
+    const bool st_frozen = rbe_stable(tab, ws, c.b.lp_ws_stride, basis, n_if, if_body, if_geom, nb + 1, nb, pose,
+                                      shape_id, shapes, c.mu, c.density, lane, &w, &piv, &err);
+    __syncthreads();
+    const bool st_free = rbe_stable(tab, ws, c.b.lp_ws_stride, basis, n_if, if_body, if_geom, nb + 1, nb + 1, pose,
+                                    shape_id, shapes, c.mu, c.density, lane, &w, &piv, &err);
+
+    // ---- reward / termination (gym_env.py:11-22, 141-145) ----
+    const bool all_reached = left == 0;
+    const bool terminated = !st_frozen || all_reached;
+    const bool truncated = c.max_steps > 0 && (nb + 1) >= c.max_steps;
+    const bool done = terminated || truncated;
+    float reward = !st_frozen ? -1.f : (all_reached ? (float)n_reached : (float)(-1 + n_reached));
+    const float base = c.b.cand_lin[ci];
+    float lin = st_free ? base : (st_frozen ? base / 100.f : 0.f);          // successor_dqn.py:397-401
+
+    if (lane == 0) {
+        flags[F_VALID] = 1; flags[F_STABLE_FROZEN] = st_frozen; flags[F_STABLE_UNFROZEN] = st_free;
+        flags[F_TERMINATED] = terminated; flags[F_TRUNCATED] = truncated; flags[F_DONE] = done;
+        flags[F_NO_ACTIONS] = 0; flags[F_LP_ERROR] = err || overflow;
+        c.b.reward[e] = reward;
+        c.b.lin_reward[e] = lin;
+        c.b.n_reached[e] = n_reached;
+        c.b.n_if[e] = n_if;
+        c.b.targets_left[e] = left;
+        atomicAdd((unsigned long long*)&c.b.stats[ST_ENV_STEPS], 1ull);
+        if (err) atomicAdd((unsigned long long*)&c.b.stats[ST_LP_ERRORS], 1ull);
+        if (overflow) atomicAdd((unsigned long long*)&c.b.stats[ST_IF_OVERFLOW], 1ull);
+    }
+    __syncthreads();
+    int nb_after = nb + 1;
+    if (done) {                                     // auto-reset
+        reset_env(c, e, lane);
+        nb_after = 0;
+        __syncthreads();
+    }
+    int nc = count_candidates(c, e, nb_after, lane);
+    if (lane == 0) c.b.n_cand[e] = nc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive prefix sum of n_cand -> cand_offset[E+1]; single workgroup.
+__global__ __launch_bounds__(1024) void k_scan(DevCtx c) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    long long sum_blocks = 0;
+    for (int base = 0; base < c.E; base += 1024) {
+        int i = base + t;
+        int v = i < c.E ? c.b.n_cand[i] : 0;
+        if (i < c.E) sum_blocks += c.b.n_blocks[i];
+        part[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int add = t >= o ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (i < c.E) c.b.cand_offset[i] = carry + part[t] - v;
+        __syncthreads();
+        if (t == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    // block-reduce sum_blocks
+    __shared__ long long red[1024];
+    red[t] = sum_blocks;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        c.b.cand_offset[c.E] = carry;
+        c.b.stats[ST_SUM_CAND] += (uint64_t)carry;
+        c.b.stats[ST_SUM_BLOCKS] += (uint64_t)red[0];
+        c.b.stats[ST_LOCKSTEPS] += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
+    __shared__ uint8_t free_b[MAXK * MAXV], free_f[MAXK * MAXV];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int K = c.K;
+    const bridges_shape* shapes = c.tt->shapes;
+    const int nb = c.b.n_blocks[e];
+    const int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
+    const double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+    // free (block, face) list in (block, face) order (actions.py:28-45)
+    int nfree = 0;
+    for (int i0 = 0; i0 < nb * MAXV; i0 += WAVE) {
+        int i = i0 + lane;
+        bool fr = false;
+        int b = i / MAXV, f = i % MAXV;
+        if (i < nb * MAXV) {
+            int nv = shapes[shape_id[b]].nv;
+            fr = f < nv && !((c.b.blk_occ[(size_t)e * K + b] >> f) & 1);
+        }
+        uint64_t bal = __ballot(fr);
+        if (fr) {
+            int idx = nfree + __popcll(bal & ((1ull << lane) - 1ull));
+            free_b[idx] = (uint8_t)b;
+            free_f[idx] = (uint8_t)f;
+        }
+        nfree += __popcll(bal);
+    }
+    __syncthreads();
+    const int gsize = c.n_ground + nfree * c.n_offsets;
+    const int ncand = c.b.n_cand[e];
+    const size_t off = (size_t)c.b.cand_offset[e];
+    for (int a = lane; a < ncand; a += WAVE) {
+        int grp = a / gsize, slot = a % gsize;
+        int sh = c.group_shape[grp], fc = c.group_face[grp];
+        int tb = -1, tf = 0;
+        double ox;
+        Frame2 f1;
+        if (slot < c.n_ground) {
+            ox = c.tt->x_ground[slot];
+            f1.cx = 0.0; f1.cz = 0.0; f1.tx = 1.0; f1.tz = 0.0; f1.nx = 0.0; f1.nz = 1.0;   // assembly_env.py:339-340
+        } else {
+            int k = (slot - c.n_ground) / c.n_offsets;
+            ox = c.tt->offsets[(slot - c.n_ground) % c.n_offsets];
+            tb = free_b[k]; tf = free_f[k];
+            const bridges_shape& st = shapes[shape_id[tb]];
+            const double* v = verts + (size_t)tb * MAXV * 2;
+            f1 = edge_frame(v[2 * st.fa[tf]], v[2 * st.fa[tf] + 1], v[2 * st.fb[tf]], v[2 * st.fb[tf] + 1]);
+        }
+        const bridges_shape& sn = shapes[sh];
+        double px, pz, cs, sn_;
+        align_place(f1, sn.fcx[fc], sn.fcz[fc], sn.fnx[fc], sn.fnz[fc], ox, 0.0, px, pz, cs, sn_);
+        const size_t ci = off + a;
+        bool inb = true;
+        const double eps = 1e-6;
+        for (int i = 0; i < MAXV; ++i) {
+            double wx = 0.0, wz = 0.0;
+            if (i < sn.nv) {
+                double rx, rz;
+                rot2(sn.vx[i], sn.vz[i], cs, sn_, rx, rz);
+                wx = px + rx; wz = pz + rz;
+                if (wx < c.xlim0 - eps || wx > c.xlim1 + eps || wz < c.ylim0 - eps || wz > c.ylim1 + eps) inb = false;
+                if (wz < -eps) inb = false;
+            }
+            c.b.cand_verts[ci * MAXV * 2 + 2 * i] = wx;
+            c.b.cand_verts[ci * MAXV * 2 + 2 * i + 1] = wz;
+        }
+        c.b.cand_pose[ci * 4 + 0] = px; c.b.cand_pose[ci * 4 + 1] = pz;
+        c.b.cand_pose[ci * 4 + 2] = cs; c.b.cand_pose[ci * 4 + 3] = sn_;
+        c.b.cand_desc[ci * 4 + 0] = tb; c.b.cand_desc[ci * 4 + 1] = tf;
+        c.b.cand_desc[ci * 4 + 2] = sh; c.b.cand_desc[ci * 4 + 3] = fc;
+        c.b.cand_ox[ci] = ox;
+        c.b.cand_inb[ci] = inb;
+        c.b.cand_env[ci] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 expansion of a 64x64 bit raster held one row per lane: 16 wave-wide float4 stores of 1 KiB.
+__device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, int lane) {
+    const int sub = lane >> 4, col4 = (lane & 15) * 4;
+#pragma unroll
+    for (int r0 = 0; r0 < IMG; r0 += 4) {
+        uint64_t m = shfl_u64(rowbits, r0 + sub);
+        uint32_t nib = (uint32_t)(m >> col4) & 0xFu;
+        float4 v;
+        v.x = (nib & 1u) ? 1.f : 0.f;
+        v.y = (nib & 2u) ? 1.f : 0.f;
+        v.z = (nib & 4u) ? 1.f : 0.f;
+        v.w = (nib & 8u) ? 1.f : 0.f;
+        *reinterpret_cast<float4*>(img + (size_t)(r0 + sub) * IMG + col4) = v;
+    }
+}
+
+// Rasterise one convex outline.  Lane = pixel column; returns the row masks with row r in lane r.
+// If reward_map != nullptr also accumulates sum(inside * reward_map) into *lin (per lane partial).
+__device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, int nv, const int32_t* fa,
+                                                   const int32_t* fb, const double* gx, const double* gy,
+                                                   const float* reward_map, double* lin, int lane) {
+    // face frames: lane f computes face f, then broadcast (oracle/raster.py contains_2d)
+    double cx = 0.0, cz = 0.0, nx = 0.0, nz = 0.0, myz = 0.0;
+    if (lane < nv) {
+        Frame2 fr = edge_frame(v[2 * fa[lane]], v[2 * fa[lane] + 1], v[2 * fb[lane]], v[2 * fb[lane] + 1]);
+        cx = fr.cx; cz = fr.cz; nx = fr.nx; nz = fr.nz;
+        myz = v[2 * lane + 1];
+    }
+    const double zmin = wave_min_d(lane < nv ? myz : 1e300);
+    const double zmax = wave_max_d(lane < nv ? myz : -1e300);
+    const double X = gx[lane];
+    const double ytop = gy[0], dy = (gy[0] - gy[IMG - 1]) / (double)(IMG - 1);
+    // conservative row window (one extra pixel row either side; outside it every pixel fails some half-plane by >> 1 ulp)
+    int r_lo = (int)floor((ytop - zmax) / dy) - 1;
+    int r_hi = (int)ceil((ytop - zmin) / dy) + 1;
+    r_lo = r_lo < 0 ? 0 : r_lo;
+    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
+    double txf[MAXV], czf[MAXV], nzf[MAXV];
+#pragma unroll
+    for (int f = 0; f < MAXV; ++f) {
+        double cxf = shfl_d(cx, f), nxf = shfl_d(nx, f);
+        czf[f] = shfl_d(cz, f);
+        nzf[f] = shfl_d(nz, f);
+        txf[f] = (X - cxf) * nxf;
+    }
+    uint64_t mybits = 0ull;
+    double acc = 0.0;
+    for (int r = r_lo; r <= r_hi; ++r) {
+        const double Y = gy[r];
+        bool in = true;
+#pragma unroll
+        for (int f = 0; f < MAXV; ++f) {
+            if (f < nv) {
+                double d = txf[f] + (Y - czf[f]) * nzf[f];
+                in = in && (d <= 0.0);
+            }
+        }
+        uint64_t m = __ballot(in);
+        if (lane == r) mybits = m;
+        if (reward_map != nullptr && in) acc += (double)reward_map[r * IMG + lane];
+    }
+    if (lin) *lin = acc;
+    return mybits;
+}
+
+// Persistent rasteriser: work item i < total -> candidate i (compact index), else state raster of env i-total.
+__global__ __launch_bounds__(256) void k_raster(DevCtx c) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    const int total = c.b.cand_offset[c.E];
+    const int items = total + c.E;
+    const bridges_shape* shapes = c.tt->shapes;
+    for (int it = wave; it < items; it += nwaves) {
+        if (it < total) {
+            const size_t ci = (size_t)it;
+            const int e = c.b.cand_env[ci];
+            const bridges_shape& sh = shapes[c.b.cand_desc[ci * 4 + 2]];
+            double linp;
+            uint64_t bits = raster_outline(c.b.cand_verts + ci * MAXV * 2, sh.nv, sh.fa, sh.fb, c.tt->grid_x,
+                                           c.tt->grid_y, c.b.reward_map, &linp, lane);
+            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | c.b.obstacle_bits[lane];
+            const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
+            const double lin = wave_sum_d(linp);
+            c.b.cand_bits[ci * IMG + lane] = bits;
+            if (lane == 0) {
+                c.b.cand_lin[ci] = (float)lin;
+                c.b.cand_mask[ci] = (uint8_t)(c.b.cand_inb[ci] && !overlap);
+            }
+            if (c.b.cand_raster) write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane);
+        } else if (c.b.state_raster) {
+            const int e = it - total;
+            write_f32_image(c.b.state_raster + (size_t)e * IMG * IMG, c.b.state_bits[(size_t)e * IMG + lane], lane);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// draw == 0: n_valid + no-action detection (successor_dqn.py:409-411), part of every lock-step;
+// draw == 1: the synthetic uniform-random policy over the valid candidates -> sel_index.
+__global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int nc = c.b.n_cand[e];
+    const size_t off = (size_t)c.b.cand_offset[e];
+    int nvalid = 0;
+    for (int a0 = 0; a0 < nc; a0 += WAVE) {
+        int a = a0 + lane;
+        nvalid += __popcll(__ballot(a < nc && c.b.cand_mask[off + a]));
+    }
+    int sel = 0;
+    if (nvalid > 0 && draw) {
+        uint64_t ctr = c.b.draw_counter[e];
+        uint64_t r = splitmix64(splitmix64(((c.seed & 0xFFFFFFFFull) << 32) | (uint32_t)e) ^ ctr);
+        int rank = (int)(r % (uint64_t)nvalid);
+        int seen = 0;
+        for (int a0 = 0; a0 < nc; a0 += WAVE) {
+            int a = a0 + lane;
+            uint64_t bal = __ballot(a < nc && c.b.cand_mask[off + a]);
+            int cnt = __popcll(bal);
+            if (rank < seen + cnt) {
+                int want = rank - seen;            // want-th set bit of bal
+                for (int k = 0; k < want; ++k) bal &= bal - 1;
+                sel = a0 + (__ffsll((long long)bal) - 1);
+                break;
+            }
+            seen += cnt;
+        }
+    }
+    if (lane == 0) {
+        if (draw) {
+            c.b.sel_index[e] = sel;
+            if (nvalid > 0) c.b.draw_counter[e] += 1;
+        } else {
+            c.b.n_valid[e] = nvalid;
+            if (nvalid == 0) {
+                c.b.needs_reset[e] = 1;
+                c.b.step_flags[(size_t)e * 8 + F_NO_ACTIONS] = 1;
+            }
+            atomicAdd((unsigned long long*)&c.b.stats[ST_SUM_VALID], (unsigned long long)nvalid);
+        }
+    }
+}
+
+}  // namespace bridges

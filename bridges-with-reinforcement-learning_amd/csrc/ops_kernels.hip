@@ -1,0 +1,112 @@
+// Stand-alone operators: the same device code as the lock-step kernels, on caller-shaped batches.
+// Used by the single-environment assembly_gym API, by replay re-rasterisation and by the parity tests.
+#include "bridges_device.h"
+#include "rbe_device.h"
+
+namespace bridges {
+
+// K1: create_block / align_frames_2d (gym_env.py:204-216, geometry.py:39-50); one thread per placement.
+__global__ void k_place(const bridges_shape* shapes, int n, const double* frame1, const int32_t* shape_id,
+                        const int32_t* face, const double* ox, const double* oy, double* pose, double* verts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Frame2 f1;
+    f1.cx = frame1[6 * i + 0]; f1.cz = frame1[6 * i + 1];
+    f1.tx = frame1[6 * i + 2]; f1.tz = frame1[6 * i + 3];
+    f1.nx = frame1[6 * i + 4]; f1.nz = frame1[6 * i + 5];
+    const bridges_shape& s = shapes[shape_id[i]];
+    int f = face[i];
+    double px, pz, c, sn;
+    align_place(f1, s.fcx[f], s.fcz[f], s.fnx[f], s.fnz[f], ox[i], oy[i], px, pz, c, sn);
+    pose[4 * i + 0] = px; pose[4 * i + 1] = pz; pose[4 * i + 2] = c; pose[4 * i + 3] = sn;
+    for (int k = 0; k < MAXV; ++k) {
+        double wx = 0.0, wz = 0.0;
+        if (k < s.nv) {
+            double rx, rz;
+            rot2(s.vx[k], s.vz[k], c, sn, rx, rz);
+            wx = px + rx; wz = pz + rz;
+        }
+        verts[(size_t)i * MAXV * 2 + 2 * k] = wx;
+        verts[(size_t)i * MAXV * 2 + 2 * k + 1] = wz;
+    }
+}
+
+// K4: one wave per posed outline (world vertices in shape-vertex order).
+__global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* shapes, int n, const double* verts,
+                                                        const int32_t* shape_id, const double* gx, const double* gy,
+                                                        uint64_t* bits, float* img) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int it = wave; it < n; it += nwaves) {
+        const bridges_shape& sh = shapes[shape_id[it]];
+        uint64_t b = raster_outline(verts + (size_t)it * MAXV * 2, sh.nv, sh.fa, sh.fb, gx, gy, nullptr, nullptr, lane);
+        if (bits) bits[(size_t)it * IMG + lane] = b;
+        if (img) write_f32_image(img + (size_t)it * IMG * IMG, b, lane);
+    }
+}
+
+__global__ void k_bits_or(int n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out) {
+    int g = blockIdx.x, lane = threadIdx.x;
+    uint64_t acc = 0ull;
+    for (int i = group_offset[g]; i < group_offset[g + 1]; ++i) acc |= bits[(size_t)i * IMG + lane];
+    out[(size_t)g * IMG + lane] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_bits_to_f32(int n, const uint64_t* bits, float* img) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int it = wave; it < n; it += nwaves)
+        write_f32_image(img + (size_t)it * IMG * IMG, bits[(size_t)it * IMG + lane], lane);
+}
+
+// K2+K3: is_stable_rbe on independent assemblies; fixed blocks must be a suffix of the block list
+// (the reference only ever freezes the last block, gym_env.py:235-240); other masks are rejected (info[3]=2).
+__global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes, int n, int K, const double* pose_all,
+                                                    const double* verts_all, const int32_t* shape_all,
+                                                    const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
+                                                    double density, double floor_hw, double floor_depth,
+                                                    uint8_t* stable, double* info, double* lp_ws, int64_t ws_stride) {
+    __shared__ FaceLds F;
+    __shared__ double tab[LP_TAB_LDS];
+    __shared__ int basis[WAVE];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int nb = n_blocks[e];
+    const double* pose = pose_all + (size_t)e * K * 4;
+    const double* verts = verts_all + (size_t)e * K * MAXV * 2;
+    const int32_t* shape_id = shape_all + (size_t)e * K;
+    // workspace layout per assembly: [0,8*MAXIF) interface geometry, [8*MAXIF,9*MAXIF) interface bodies (int32
+    // pairs), then the tableau overflow area
+    double* ws = lp_ws + (size_t)e * ws_stride;
+    double* if_geom = ws;
+    int32_t* if_body = reinterpret_cast<int32_t*>(ws + 8 * MAXIF);
+    double* tab_ws = ws + 9 * MAXIF;
+    const int64_t tab_cap = ws_stride - 9 * MAXIF;
+    const uint32_t fm = fixed_mask[e];
+    int n_free = nb;
+    while (n_free > 0 && ((fm >> (n_free - 1)) & 1u)) --n_free;
+    bool bad_mask = (fm & ((n_free >= 32) ? 0xffffffffu : ((1u << n_free) - 1u))) != 0u;
+    stage_faces(F, 0, 1 + nb * MAXV, verts, shape_id, shapes, floor_hw, lane);
+    __syncthreads();
+    int n_if = 0;
+    bool overflow = false;
+    for (int b = 0; b < nb; ++b) {
+        n_if = append_interfaces(F, b, shape_id, shapes, floor_depth, n_if, if_body, if_geom, lane, &overflow);
+        __syncthreads();
+    }
+    bool err = false;
+    double w = 0.0;
+    int piv = 0;
+    bool st = rbe_stable(tab, tab_ws, tab_cap, basis, n_if, if_body, if_geom, nb, n_free,
+                         pose, shape_id, shapes, mu, density, lane, &w, &piv, &err);
+    if (lane == 0) {
+        stable[e] = (uint8_t)(st && !bad_mask);
+        info[4 * e + 0] = w;
+        info[4 * e + 1] = (double)n_if;
+        info[4 * e + 2] = (double)piv;
+        info[4 * e + 3] = bad_mask ? 2.0 : ((err || overflow) ? 1.0 : 0.0);
+    }
+}
+
+}  // namespace bridges

@@ -1,0 +1,305 @@
+// Wave-level contact detection and rigid-block-equilibrium feasibility.
+//
+// Replaces AssemblyEnv._reset_cra_assembly -> assembly_interfaces_numpy(amin=0.001)
+// (assembly_gym/assembly_gym/envs/assembly_env.py:281-304) and is_stable_rbe ->
+// rbe_solve(mu, density, penalty=False) (assembly_gym/assembly_gym/utils/stability.py:49-71).
+// One 64-lane wavefront (= one workgroup) owns one assembly: face frames are staged in LDS,
+// face-pair hits are compacted with wave ballots, the phase-1 simplex tableau lives in LDS
+// (global overflow for the rare large assemblies) and every pivot decision is a wave
+// reduction, so the result is deterministic and identical on every GPU.
+#pragma once
+#include "bridges_device.h"
+
+namespace bridges {
+
+#define RBE_TOL_PARALLEL 1e-6
+#define RBE_TOL_COPLANAR 1e-6
+#define RBE_AMIN 0.001
+#define RBE_FEAS_TOL 1e-5     // oracle: HiGHS optimum <= 1e-7; observed gap between the classes: 0 vs >= 3e-2
+#define LP_EPS_COST 1e-9
+#define LP_TAU 1e-7           // smallest admissible pivot element
+#define LP_TIE 1e-9           // ratios within this (relative) band are ties
+#define LP_STALL 40           // degenerate pivots before Bland's rule takes over
+#define LP_MAX_PIVOTS 5000
+#define LP_TAB_LDS 1536                       // doubles of LDS tableau per wave (12 KiB)
+#define MAXFACES (1 + MAXK * MAXV)            // floor + K blocks
+#define LP_MAX_COLS (4 * MAXIF)
+#define LP_MAX_CHUNKS ((LP_MAX_COLS + 1 + WAVE - 1) / WAVE)
+
+struct FaceLds {            // staged face frames of one assembly
+    double ax[MAXFACES], az[MAXFACES], bx[MAXFACES], bz[MAXFACES];
+    double cx[MAXFACES], cz[MAXFACES], tx[MAXFACES], tz[MAXFACES], nx[MAXFACES], nz[MAXFACES];
+};
+
+// Stage frames of faces [q_begin, q_end) (q = 0 floor, q = 1 + b*MAXV + f otherwise).
+__device__ inline void stage_faces(FaceLds& F, int q_begin, int q_end, const double* verts /*[K,6,2]*/,
+                                   const int32_t* shape_id, const bridges_shape* shapes, double floor_hw, int lane) {
+    for (int q = q_begin + lane; q < q_end; q += WAVE) {
+        if (q == 0) {
+            F.ax[0] = -floor_hw; F.az[0] = 0.0; F.bx[0] = floor_hw; F.bz[0] = 0.0;
+            F.cx[0] = 0.0; F.cz[0] = 0.0; F.tx[0] = 1.0; F.tz[0] = 0.0; F.nx[0] = 0.0; F.nz[0] = 1.0;
+        } else {
+            int b = (q - 1) / MAXV, f = (q - 1) % MAXV;
+            const bridges_shape& sh = shapes[shape_id[b]];
+            if (f < sh.nv) {
+                const double* v = verts + (size_t)b * MAXV * 2;
+                double ax = v[2 * sh.fa[f]], az = v[2 * sh.fa[f] + 1];
+                double bx = v[2 * sh.fb[f]], bz = v[2 * sh.fb[f] + 1];
+                Frame2 fr = edge_frame(ax, az, bx, bz);
+                F.ax[q] = ax; F.az[q] = az; F.bx[q] = bx; F.bz[q] = bz;
+                F.cx[q] = fr.cx; F.cz[q] = fr.cz; F.tx[q] = fr.tx; F.tz[q] = fr.tz; F.nx[q] = fr.nx; F.nz[q] = fr.nz;
+            }
+        }
+    }
+}
+
+// oracle/rbe.py face_pair_contact, same operation order.
+__device__ __forceinline__ bool face_pair_contact(const FaceLds& F, int qa, int qb, double depth, double* out8) {
+    double dotn = F.nx[qa] * F.nx[qb] + F.nz[qa] * F.nz[qb];
+    if (dotn > -1.0 + RBE_TOL_PARALLEL) return false;
+    double cAx = F.cx[qa], cAz = F.cz[qa], tAx = F.tx[qa], tAz = F.tz[qa], nAx = F.nx[qa], nAz = F.nz[qa];
+    double gap = (F.cx[qb] - cAx) * nAx + (F.cz[qb] - cAz) * nAz;
+    if (fabs(gap) > RBE_TOL_COPLANAR) return false;
+    double a0 = (F.ax[qa] - cAx) * tAx + (F.az[qa] - cAz) * tAz;
+    double a1 = (F.bx[qa] - cAx) * tAx + (F.bz[qa] - cAz) * tAz;
+    double b0 = (F.ax[qb] - cAx) * tAx + (F.az[qb] - cAz) * tAz;
+    double b1 = (F.bx[qb] - cAx) * tAx + (F.bz[qb] - cAz) * tAz;
+    double lo = fmax(fmin(a0, a1), fmin(b0, b1));
+    double hi = fmin(fmax(a0, a1), fmax(b0, b1));
+    if ((hi - lo) * depth < RBE_AMIN) return false;
+    out8[0] = cAx + lo * tAx; out8[1] = cAz + lo * tAz;
+    out8[2] = cAx + hi * tAx; out8[3] = cAz + hi * tAz;
+    out8[4] = nAx; out8[5] = nAz; out8[6] = tAx; out8[7] = tAz;
+    return true;
+}
+
+// Append the interfaces between block `nb_new` and every earlier body (floor, blocks < nb_new).
+// Faces must be staged for q in [0, 1 + (nb_new+1)*MAXV).  Returns the new interface count
+// (uniform); sets *overflow if MAXIF was exceeded (extra contacts are dropped).
+__device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int32_t* shape_id,
+                                        const bridges_shape* shapes, double floor_depth, int n_if,
+                                        int32_t* if_body, double* if_geom, int lane, bool* overflow) {
+    const bridges_shape& shn = shapes[shape_id[nb_new]];
+    int n_old_q = 1 + nb_new * MAXV;
+    int total = n_old_q * MAXV;
+    for (int p0 = 0; p0 < total; p0 += WAVE) {
+        int p = p0 + lane;
+        bool hit = false;
+        double g[8];
+        int bodyA = -1;
+        if (p < total) {
+            int qa = p / MAXV, fn = p % MAXV;
+            bool valid = fn < shn.nv;
+            double depthA = floor_depth;
+            if (qa > 0) {
+                bodyA = (qa - 1) / MAXV;
+                const bridges_shape& sa = shapes[shape_id[bodyA]];
+                valid = valid && ((qa - 1) % MAXV) < sa.nv;
+                depthA = sa.depth;
+            }
+            if (valid) {
+                int qb = 1 + nb_new * MAXV + fn;
+                hit = face_pair_contact(F, qa, qb, fmin(depthA, shn.depth), g);
+            }
+        }
+        uint64_t bal = __ballot(hit);
+        int idx = n_if + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit) {
+            if (idx < MAXIF) {
+                if_body[2 * idx] = bodyA;
+                if_body[2 * idx + 1] = nb_new;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if_geom[8 * idx + k] = g[k];
+            }
+        }
+        n_if += __popcll(bal);
+    }
+    if (n_if > MAXIF) { *overflow = true; n_if = MAXIF; }
+    return n_if;
+}
+
+// Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = cost.
+// Blocks >= n_free are fixed (only the last block is ever frozen, gym_env.py:235-240).
+__device__ inline void lp_build(double* T, int stride, int m, int n, int n_if, const int32_t* if_body,
+                                const double* if_geom, int n_free, const double* pose /*[K,4]*/,
+                                const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
+                                int lane) {
+    int cells = (m + 1) * stride;
+    for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
+    __syncthreads();
+    for (int j = lane; j < n; j += WAVE) {
+        int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
+        const double* g = if_geom + 8 * k;
+        double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+        double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
+        double gx = ig ? nx - mu * tx : nx + mu * tx;
+        double gz = ig ? nz - mu * tz : nz + mu * tz;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            int body = if_body[2 * k + (side == 0 ? 1 : 0)];   // side 0: body B (+), side 1: body A (-)
+            if (body >= 0 && body < n_free) {
+                double sgx = side == 0 ? gx : -gx;
+                double sgz = side == 0 ? gz : -gz;
+                const bridges_shape& sh = shapes[shape_id[body]];
+                const double* P = pose + 4 * body;
+                double rgx, rgz;
+                rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
+                double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+                int r = 3 * body;
+                T[(r + 0) * stride + j] = sgx;
+                T[(r + 1) * stride + j] = sgz;
+                T[(r + 2) * stride + j] = rx * sgz - rz * sgx;
+            }
+        }
+    }
+    for (int b = lane; b < n_free; b += WAVE) T[(3 * b + 1) * stride + n] = density * shapes[shape_id[b]].volume;
+    __syncthreads();
+    for (int q = lane; q <= n; q += WAVE) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += T[i * stride + q];
+        T[m * stride + q] = -s;
+    }
+    __syncthreads();
+}
+
+// Phase-1 simplex on the dense tableau (artificial columns implicit: an artificial that leaves never returns).
+// Pricing: most negative reduced cost (ties -> lowest column).  Ratio test: rows with a pivot candidate > LP_TAU,
+// minimum ratio; among ratios tied within LP_TIE the LARGEST pivot element wins (ties -> lowest row) -- the
+// float32 block meshes make faces parallel only to ~1e-7, which creates legitimate 1e-8 tableau entries that must
+// never be pivoted on.  After LP_STALL pivots without progress the rules switch to Bland's (lowest entering column,
+// lowest leaving variable) until the objective moves again.  Every decision is a wave reduction with a total
+// order, so the pivot sequence -- and the boolean -- is identical on every GPU.
+// Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
+__device__ __forceinline__ double artificial_sum(const double* T, int stride, int m, int n, const int* basis, int lane) {
+    double v = 0.0;
+    if (lane < m && basis[lane] >= n) {
+        double rhs = T[lane * stride + n];
+        v = rhs > 0.0 ? rhs : 0.0;
+    }
+    return wave_sum_d(v);
+}
+
+__device__ inline double lp_phase1(double* T, int stride, int m, int n, int* basis /*LDS [>=m]*/, int lane,
+                                   int* pivots_out, bool* error) {
+    for (int i = lane; i < m; i += WAVE) basis[i] = n + i;       // artificial i
+    __syncthreads();
+    int pivots = 0, stall = 0;
+    bool bland = false;
+    const int nchunk = (n + 1 + WAVE - 1) / WAVE;
+    double w = artificial_sum(T, stride, m, n, basis, lane);
+    while (w > RBE_FEAS_TOL) {
+        // ---- entering column ----
+        int jin = -1;
+        if (bland) {
+            for (int c = 0; c < nchunk && jin < 0; ++c) {
+                int j = c * WAVE + lane;
+                bool neg = (j < n) && (T[m * stride + j] < -LP_EPS_COST);
+                uint64_t bal = __ballot(neg);
+                if (bal) jin = c * WAVE + (__ffsll((long long)bal) - 1);
+            }
+        } else {
+            double dbest = 0.0;
+            int jbest = 0x7fffffff;
+            for (int j = lane; j < n; j += WAVE) {
+                double d = T[m * stride + j];
+                if (d < dbest) { dbest = d; jbest = j; }           // strict: keeps the lowest column of a tie
+            }
+            double dmin = wave_min_d(dbest);
+            if (dmin < -LP_EPS_COST) {
+                int jc = (dbest == dmin) ? jbest : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) jc = min(jc, __shfl_xor(jc, o, WAVE));
+                jin = jc;
+            }
+        }
+        if (jin < 0) break;                                        // optimal with w > tol: infeasible
+        // ---- ratio test, lanes over rows (m <= 48 < 64) ----
+        double col = (lane <= m) ? T[lane * stride + jin] : 0.0;   // lane m holds the cost entry
+        double ratio = 1e300;
+        if (lane < m && col > LP_TAU) {
+            double rhs = T[lane * stride + n];
+            ratio = (rhs > 0.0 ? rhs : 0.0) / col;
+        }
+        const double rmin = wave_min_d(ratio);
+        if (rmin >= 1e300) {                                       // no usable pivot in this column: retire it
+            if (lane == 0) T[m * stride + jin] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        const bool tie = ratio <= rmin + LP_TIE * (1.0 + rmin);
+        int r;
+        if (bland) {
+            int var = tie ? basis[lane] : 0x7fffffff;
+            int vmin = var;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmin = min(vmin, __shfl_xor(vmin, o, WAVE));
+            r = __ffsll((long long)__ballot(tie && var == vmin)) - 1;
+        } else {
+            double cmax = wave_max_d(tie ? col : -1e300);
+            r = __ffsll((long long)__ballot(tie && col == cmax)) - 1;
+        }
+        const double piv = shfl_d(col, r);
+        __syncthreads();
+        // ---- pivot: normalise row r (kept in registers), eliminate the column everywhere else ----
+        double rowr[LP_MAX_CHUNKS];
+#pragma unroll
+        for (int c = 0; c < LP_MAX_CHUNKS; ++c) {
+            int q = c * WAVE + lane;
+            rowr[c] = 0.0;
+            if (c < nchunk && q <= n) {
+                double v = (q == jin) ? 1.0 : T[r * stride + q] / piv;
+                rowr[c] = v;
+                T[r * stride + q] = v;
+            }
+        }
+        for (int i = 0; i <= m; ++i) {
+            if (i == r) continue;
+            double f = shfl_d(col, i);
+            if (f == 0.0) continue;
+#pragma unroll
+            for (int c = 0; c < LP_MAX_CHUNKS; ++c) {
+                int q = c * WAVE + lane;
+                if (c < nchunk && q <= n) {
+                    double v = (q == jin) ? 0.0 : T[i * stride + q] - f * rowr[c];
+                    T[i * stride + q] = v;
+                }
+            }
+        }
+        if (lane == 0) basis[r] = jin;
+        __syncthreads();
+        const double wn = artificial_sum(T, stride, m, n, basis, lane);
+        if (wn < w - 1e-12) { stall = 0; bland = false; }
+        else if (++stall > LP_STALL) bland = true;
+        w = wn;
+        if (++pivots >= LP_MAX_PIVOTS) { *error = true; break; }
+    }
+    *pivots_out = pivots;
+    return w;
+}
+
+// Stability of one assembly variant.  n_free = number of leading free blocks.
+__device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_cap, int* basis, int n_if,
+                                  const int32_t* if_body, const double* if_geom, int n_blocks, int n_free,
+                                  const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
+                                  double mu, double density, int lane, double* w_out, int* pivots_out,
+                                  bool* error) {
+    *w_out = 0.0;
+    *pivots_out = 0;
+    if (n_if == 0) return n_free == 0;                 // stability.py:53-56
+    if (n_free == 0) return true;
+    int m = 3 * n_free, n = 4 * n_if;
+    int stride = n + 1;
+    if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
+    int64_t cells = (int64_t)(m + 1) * stride;
+    double* T = tab_lds;
+    if (cells > LP_TAB_LDS) {
+        if (cells > ws_cap) { *error = true; return false; }
+        T = tab_ws;
+    }
+    lp_build(T, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
+    double w = lp_phase1(T, stride, m, n, basis, lane, pivots_out, error);
+    *w_out = w;
+    return w <= RBE_FEAS_TOL;
+}
+
+}  // namespace bridges

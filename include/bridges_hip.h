@@ -1,0 +1,196 @@
+/*
+ * bridges_hip.h -- C ABI of libbridges_hip.so (MI355X / gfx950).
+ *
+ * The reference (syghmon/bridges-with-reinforcement-learning) is pure Python and has
+ * no FFI layer; this header is the boundary SURVEY.md §8(b) defines for its hot path.
+ * Every entry point names the reference code it replaces (paths relative to the
+ * reference root).  Conventions:
+ *   - all buffers are DEVICE pointers owned by the caller (PyTorch tensors in the
+ *     shipped host code); the library allocates only small constant tables inside
+ *     *_create and nothing afterwards;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is
+ *     enqueued asynchronously, nothing synchronises;
+ *   - return value 0 = ok, negative = BRIDGES_E_*; no exceptions cross the ABI.
+ *
+ * Reference-side binding: INTEGRATION.md shows the ctypes stub a maintainer adds.
+ */
+#ifndef BRIDGES_HIP_H
+#define BRIDGES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRIDGES_OK 0
+#define BRIDGES_E_ARG (-1)      /* bad argument / size over a compiled limit */
+#define BRIDGES_E_HIP (-2)      /* a HIP runtime call failed (bridges_last_error()) */
+#define BRIDGES_E_NODEV (-3)    /* no HIP device */
+
+#define BRIDGES_MAX_VERTS 6     /* hexagon */
+#define BRIDGES_MAX_BLOCKS 16   /* --max_steps <= 16 */
+#define BRIDGES_MAX_GROUPS 24   /* (shape, target face) pairs of one task */
+#define BRIDGES_MAX_TARGETS 8
+#define BRIDGES_MAX_INTERFACES 64
+#define BRIDGES_IMG 64          /* rasters are 64x64 (successor_dqn.py:585 default) */
+
+/* One block shape: a convex (x,z) outline extruded along y.
+ * Replaces Shape.from_urdf / from_mesh / get_face_frame_2d
+ * (assembly_gym/assembly_gym/envs/assembly_env.py:45-68, 118-124).  The host
+ * fills the derived fields with the arithmetic contract of DESIGN.md. */
+typedef struct {
+    int32_t nv;                              /* vertices == 2-D faces */
+    int32_t pad_;
+    double vx[BRIDGES_MAX_VERTS], vz[BRIDGES_MAX_VERTS];
+    int32_t fa[BRIDGES_MAX_VERTS], fb[BRIDGES_MAX_VERTS];   /* face f = directed edge fa->fb */
+    double fcx[BRIDGES_MAX_VERTS], fcz[BRIDGES_MAX_VERTS];  /* local face centre */
+    double fnx[BRIDGES_MAX_VERTS], fnz[BRIDGES_MAX_VERTS];  /* local outward normal */
+    double depth;                            /* extent along y */
+    double volume;                           /* area * depth */
+    double gx, gz;                           /* local centroid */
+} bridges_shape;
+
+/* Static description of one vectorised task (all environments share it).
+ * Replaces the arguments of AssemblyGym.__init__/reset, AssemblyEnv.__init__
+ * (gym_env.py:116-139, 255-289; assembly_env.py:164-199) and the constants of
+ * successor_dqn.py:611-616. */
+typedef struct {
+    int32_t n_envs;
+    int32_t max_blocks;        /* state capacity K (>= max_steps) */
+    int32_t max_steps;         /* 0 = None (gym_env.py:143) */
+    int32_t a_max;             /* candidate capacity per env */
+    int32_t n_shapes;          /* entries of `shapes` */
+    int32_t n_groups;          /* (shape, target_face) pairs in generate_actions order (actions.py:16-19) */
+    int32_t group_shape[BRIDGES_MAX_GROUPS];
+    int32_t group_face[BRIDGES_MAX_GROUPS];
+    int32_t n_ground;          /* len(x_discr_ground) */
+    int32_t n_offsets;         /* len(offset_values) */
+    int32_t n_targets;
+    int32_t pad_;
+    double mu, density;        /* assembly_env.py:164 */
+    double floor_half_width;   /* assembly_env.py:290-296 */
+    double floor_depth;
+    double xlim[2], ylim[2];   /* successor_dqn.py:615-616 */
+    double targets[BRIDGES_MAX_TARGETS][3];
+    uint64_t seed;             /* synthetic random policy */
+    const bridges_shape* shapes;   /* HOST pointer, n_shapes entries (copied) */
+    const double* x_ground;        /* HOST, n_ground */
+    const double* offsets;         /* HOST, n_offsets */
+    const double* grid_x;          /* HOST, 64: np.linspace(xlim0, xlim1, 64) */
+    const double* grid_y;          /* HOST, 64: np.linspace(ylim1, ylim0, 64) */
+} bridges_task;
+
+/* Caller-owned device buffers of a vectorised environment.  E = n_envs,
+ * K = max_blocks, C = E * a_max (capacity of the compact candidate arrays:
+ * candidate a of env e lives at index cand_offset[e] + a). */
+typedef struct {
+    /* --- state (struct of arrays) --- */
+    int32_t* n_blocks;         /* [E] */
+    int32_t* blk_shape;        /* [E,K] */
+    double* blk_pose;          /* [E,K,4]  x, z, cos, sin */
+    double* blk_verts;         /* [E,K,6,2] world (x,z) */
+    uint8_t* blk_occ;          /* [E,K] bit f = face f occupied (gym_env.py:228-232 block_graph) */
+    uint32_t* targets_left;    /* [E] bit t = target t not reached yet */
+    uint64_t* state_bits;      /* [E,64] row r = 64-pixel mask of the state raster */
+    int32_t* n_if;             /* [E] contact interfaces */
+    int32_t* if_body;          /* [E,MAX_IF,2] body A, body B (-1 = floor) */
+    double* if_geom;           /* [E,MAX_IF,8] p_lo.xz, p_hi.xz, n.xz, t.xz */
+    uint64_t* draw_counter;    /* [E] policy draws so far */
+    uint8_t* needs_reset;      /* [E] */
+    /* --- per-step results --- */
+    int32_t* sel_index;        /* [E] in: candidate to place */
+    uint8_t* step_flags;       /* [E,8] valid_step, stable_frozen, stable_unfrozen, terminated, truncated, done, no_actions, lp_error */
+    float* reward;             /* [E] sparse_reward (gym_env.py:11-22) */
+    float* lin_reward;         /* [E] successor_dqn.py:397-401 */
+    int32_t* n_reached;        /* [E] */
+    /* --- candidates of the current state --- */
+    int32_t* n_cand;           /* [E] */
+    int32_t* n_valid;          /* [E] */
+    int32_t* cand_offset;      /* [E+1] exclusive prefix sum of n_cand */
+    int32_t* cand_env;         /* [C] owning env */
+    int32_t* cand_desc;        /* [C,4] target_block, target_face, shape, face */
+    double* cand_ox;           /* [C] offset_x */
+    double* cand_pose;         /* [C,4] */
+    double* cand_verts;        /* [C,6,2] */
+    uint8_t* cand_inb;         /* [C] inside xlim/ylim (gym_env.py:304-323) */
+    uint8_t* cand_mask;        /* [C] filter_actions result (actions.py:71-82) */
+    float* cand_lin;           /* [C] sum(action_raster * reward_map) */
+    uint64_t* cand_bits;       /* [C,64] bit-packed action rasters */
+    float* cand_raster;        /* [C,64,64] f32 action rasters (may be NULL: skip) */
+    float* state_raster;       /* [E,64,64] f32 (may be NULL) */
+    /* --- task features --- */
+    const uint64_t* obstacle_bits; /* [64] */
+    const float* reward_map;       /* [64,64] */
+    /* --- scratch --- */
+    double* lp_ws;             /* [E, lp_ws_stride] simplex tableau overflow */
+    int64_t lp_ws_stride;      /* >= (3K+1)*(4*MAX_IF+1) */
+    uint64_t* stats;           /* [8] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps */
+} bridges_env_buffers;
+
+typedef struct bridges_env bridges_env;
+
+const char* bridges_last_error(void);
+int bridges_device_count(void);
+
+/* --- vectorised environment ------------------------------------------------ */
+int bridges_env_create(const bridges_task* task, const bridges_env_buffers* buf, bridges_env** out);
+int bridges_env_destroy(bridges_env* env);
+/* AssemblyGym.reset for every env + first candidate set. */
+int bridges_env_reset(bridges_env* env, void* stream);
+/* One lock-step: AssemblyGym.step + stabilities_freezing (gym_env.py:218-253, 325-333),
+ * sparse_reward, auto-reset, then generate_actions / get_action_features /
+ * filter_actions / linear reward for the new state (successor_dqn.py:392-411).
+ * Places sel_index[e] for every env. */
+int bridges_env_step(bridges_env* env, void* stream);
+/* Synthetic uniform-random policy over the valid candidates -> sel_index. */
+int bridges_env_select_random(bridges_env* env, void* stream);
+/* Candidate refresh only (used after the host edited the state). */
+int bridges_env_refresh(bridges_env* env, void* stream);
+
+/* --- stand-alone operators (same kernels, caller-shaped batches) ------------ */
+/* K1: create_block / align_frames_2d (gym_env.py:204-216, geometry.py:39-50).
+ * frame1: [n,6] target frame (c.xz, t.xz, n.xz); shape_id,face: [n]; ox,oy: [n]
+ * -> pose [n,4], verts [n,6,2]. */
+int bridges_place(const bridges_shape* shapes_dev, int32_t n, const double* frame1, const int32_t* shape_id,
+                  const int32_t* face, const double* ox, const double* oy, double* pose, double* verts,
+                  void* stream);
+/* K4: render_blocks_2d (rendering.py:105-113) of n posed outlines, one image each.
+ * verts [n,6,2] world vertices in shape-vertex order, shape_id [n], grid_x/grid_y [64] DEVICE
+ * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */
+int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                   const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream);
+/* OR-reduce groups of bit rasters: out[g] = OR bits[group_offset[g] .. group_offset[g+1]). */
+int bridges_bits_or(int32_t n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out, void* stream);
+/* bit raster -> f32 image. */
+int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream);
+/* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
+ * padded block lists.  verts [n,K,6,2], shape_id [n,K], n_blocks [n], fixed_mask [n] (bit b = block b
+ * is_static; must be a suffix of the block list, as the reference only freezes the last block)
+ * -> stable [n] u8, info [n,4] f64 (phase-1 objective, n_interfaces, pivots, error).
+ * lp_ws: [n, lp_ws_stride] doubles, lp_ws_stride >= 9*MAX_INTERFACES + (3K+1)*(4*MAX_INTERFACES+2). */
+int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose,
+                      const double* verts, const int32_t* shape_id, const int32_t* n_blocks,
+                      const uint32_t* fixed_mask, double mu, double density, double floor_half_width,
+                      double floor_depth, uint8_t* stable, double* info, double* lp_ws, int64_t lp_ws_stride,
+                      void* stream);
+/* upload a shape table; returns a device pointer the stand-alone operators take. */
+int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, bridges_shape** out_dev);
+int bridges_shapes_free(bridges_shape* dev);
+
+/* --- K7: DQN ops (robotoddler/training/successor_dqn.py) --------------------- */
+/* update_target_net (successor_dqn.py:280-288): target = policy*tau + target*(1-tau). */
+int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, void* stream);
+/* train_policy_net target construction (successor_dqn.py:197-213, 222, 230):
+ * per transition i with rows [seg_offset[i], seg_offset[i+1]) of the target net's output:
+ *   j* = argmax next_q (first maximum), q_target[i] = lin_reward[i] + gamma * (done ? 0 : next_q[j*]),
+ *   sf_target[i,:] = action_raster[i,:] + gamma * (done ? 0 : next_sf[j*,:])   (sf_dim may be 0). */
+int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* next_q, const float* next_sf,
+                      int64_t next_sf_row_stride, const float* action_raster, const float* lin_reward,
+                      const uint8_t* done, float gamma, int32_t sf_dim, float* q_target, float* sf_target,
+                      int32_t* argmax_row, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRIDGES_HIP_H */

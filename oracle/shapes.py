@@ -51,8 +51,8 @@ SHAPES = {
     ),
     # faces: 0 bottom, 1 lower-left, 2 lower-right, 3 upper-left, 4 top, 5 upper-right
     "hexagon": dict(
-        verts=[(-0.5, -HEX_H), (0.5, -HEX_H), (1.0, HEX_Z0), (0.5, HEX_H), (-0.5, HEX_H), (-1.0, HEX_Z0)],
-        faces=[(1, 0), (0, 5), (2, 1), (5, 4), (4, 3), (3, 2)],
+        verts=[(0.5, -HEX_H), (-0.5, -HEX_H), (-1.0, HEX_Z0), (-0.5, HEX_H), (0.5, HEX_H), (1.0, HEX_Z0)],
+        faces=[(0, 1), (1, 2), (5, 0), (2, 3), (3, 4), (4, 5)],
         depth=1.0,
     ),
     "cube": _box(1.0, 1.0, 1.0),      # shapes/cube.urdf  <box size="1.0 1.0 1.0"/>

@@ -1,0 +1,133 @@
+"""GPU parity: the HIP lock-step environment against the CPU oracle, env by env, step by step.
+Bit-exact: candidate lists, poses/vertices (float64), in-bounds + overlap masks, bit rasters, f32 rasters,
+stability booleans (both variants), rewards, termination, selected actions.  1e-5: linear rewards."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.env import OracleGym, OracleLockstep, bridge_setup, horizontal_bridge_setup, policy_draw
+
+pytestmark = pytest.mark.gpu
+
+
+def bits_to_bool(bits_row):
+    """[64] int64 (row masks, bit q = column q) -> bool[64,64]."""
+    u = np.asarray(bits_row).astype(np.uint64)
+    return ((u[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+
+
+def make_pair(setup_kwargs, setup_fn, E, max_steps, seed, shapes_names, **kw):
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    setup = setup_fn(**setup_kwargs)
+    geoms = [load_urdf(f"shapes/{n}.urdf") for n in shapes_names]
+    vec = VecAssemblyGym(E, geoms, setup["obstacles"], setup["targets"], max_steps=max_steps, seed=seed, **kw)
+    oracles = [OracleLockstep(OracleGym(**setup, max_steps=max_steps, **kw)) for _ in range(E)]
+    return vec, oracles
+
+
+def compare_candidates(vec, oracles, check_f32=True):
+    off = vec.cand_offset.cpu().numpy()
+    n_cand = vec.n_cand.cpu().numpy()
+    desc = vec.cand_desc.cpu().numpy()
+    ox = vec.cand_ox.cpu().numpy()
+    pose = vec.cand_pose.cpu().numpy()
+    verts = vec.cand_verts.cpu().numpy()
+    mask = vec.cand_mask.cpu().numpy()
+    lin = vec.cand_lin.cpu().numpy()
+    bits = vec.cand_bits.cpu().numpy()
+    sbits = vec.state_bits.cpu().numpy()
+    nvalid = vec.n_valid.cpu().numpy()
+    for e, o in enumerate(oracles):
+        c = o.cand
+        A = len(c["actions"])
+        assert n_cand[e] == A, (e, n_cand[e], A)
+        sl = slice(off[e], off[e] + A)
+        acts = np.array([a[:4] for a in c["actions"]], dtype=np.int32).reshape(A, 4)
+        assert np.array_equal(desc[sl], acts)
+        assert np.array_equal(ox[sl], np.array([a[4] for a in c["actions"]]))
+        for i, b in enumerate(c["blocks"]):
+            assert tuple(pose[off[e] + i]) == (b.pos[0], b.pos[1], b.cs[0], b.cs[1]), (e, i)
+            nv = len(b.verts)
+            assert np.array_equal(verts[off[e] + i, :nv], np.array(b.verts)), (e, i)
+            assert np.array_equal(bits_to_bool(bits[off[e] + i]), c["rasters"][i]), (e, i)
+        assert np.array_equal(mask[sl].astype(bool), c["mask"]), e
+        assert nvalid[e] == int(c["mask"].sum())
+        np.testing.assert_allclose(lin[sl], c["lin_reward"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(bits_to_bool(sbits[e]), c["state"]), e
+    if check_f32 and vec.cand_raster is not None:
+        total = int(off[-1])
+        img = vec.cand_raster[:total].cpu().numpy()
+        ref = np.stack([bits_to_bool(b) for b in bits[:total]]).astype(np.float32) if total else img
+        assert np.array_equal(img, ref)
+        simg = vec.state_raster.cpu().numpy()
+        assert np.array_equal(simg, np.stack([bits_to_bool(b) for b in sbits]).astype(np.float32))
+
+
+def run_lockstep_parity(vec, oracles, seed, n_lock, counters=None):
+    E = len(oracles)
+    counters = [0] * E if counters is None else counters
+    compare_candidates(vec, oracles)
+    n_real = 0
+    for it in range(n_lock):
+        vec.select_random()
+        sel = vec.sel_index.cpu().numpy()
+        outs = []
+        for e, o in enumerate(oracles):
+            picked = {}
+
+            def pick(nv, e=e):
+                r = policy_draw(seed, e, counters[e]) % nv
+                counters[e] += 1
+                picked["rank"] = r
+                return r
+            outs.append(o.lockstep(pick))
+        vec.step()
+        flags = {k: v.cpu().numpy() for k, v in vec.flags().items()}
+        reward = vec.reward.cpu().numpy()
+        lin = vec.lin_reward.cpu().numpy()
+        nre = vec.n_reached.cpu().numpy()
+        for e, out in enumerate(outs):
+            assert bool(flags["valid_step"][e]) == out["valid_step"], (it, e)
+            assert bool(flags["no_actions"][e]) == out["no_actions"], (it, e)
+            assert not flags["lp_error"][e]
+            if not out["valid_step"]:
+                continue
+            n_real += 1
+            assert sel[e] == out["action_index"], (it, e, sel[e], out["action_index"])
+            assert bool(flags["stable_frozen"][e]) == out["stable_frozen"], (it, e)
+            assert bool(flags["stable_unfrozen"][e]) == out["stable_unfrozen"], (it, e)
+            assert bool(flags["terminated"][e]) == out["terminated"], (it, e)
+            assert bool(flags["truncated"][e]) == out["truncated"], (it, e)
+            assert bool(flags["done"][e]) == out["done"], (it, e)
+            assert reward[e] == out["reward"], (it, e)
+            assert nre[e] == out["targets_reached"]
+            np.testing.assert_allclose(lin[e], out["lin_reward"], rtol=1e-5, atol=1e-7)
+        compare_candidates(vec, oracles, check_f32=(it % 8 == 0))
+    return n_real
+
+
+@pytest.mark.parametrize("tower_height,max_steps", [(2, 10), (4, 15)])
+def test_tower_lockstep_parity(tower_height, max_steps):
+    E, seed = 48, 3
+    vec, oracles = make_pair(dict(num_stories=tower_height), bridge_setup, E, max_steps, seed, ["trapezoid"])
+    n = run_lockstep_parity(vec, oracles, seed, n_lock=24)
+    assert n > E * 12
+    st = vec.read_stats()
+    assert st["lp_errors"] == 0 and st["if_overflow"] == 0
+    assert st["env_steps"] == n
+
+
+def test_hexagon_bridge_lockstep_parity():
+    E, seed = 32, 11
+    from oracle.shapes import get_shape
+    vec, oracles = make_pair(dict(num_obstacles=3, trapezoid=False, hexagon=True), horizontal_bridge_setup, E, 15, seed,
+                             ["hexagon"], mu=0.8)
+    run_lockstep_parity(vec, oracles, seed, n_lock=16)
+
+
+def test_task_features_match_oracle():
+    vec, oracles = make_pair(dict(num_stories=4), bridge_setup, 4, 15, 0, ["trapezoid"])
+    g = oracles[0].gym
+    assert np.array_equal(bits_to_bool(vec.obstacle_bits.cpu().numpy()), g.obstacle_raster)
+    np.testing.assert_allclose(vec.reward_map.cpu().numpy(), g.reward_map, rtol=1e-5, atol=1e-7)

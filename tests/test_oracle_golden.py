@@ -101,4 +101,5 @@ def test_shape_tables_match_reference_meshes(name):
     edges_ref = [(verts[a], verts[b]) for a, b in faces]
     edges_tab = [(s.verts[a], s.verts[b]) for a, b in s.faces]
     assert edges_ref == edges_tab
+    assert [tuple(v) for v in verts] == s.verts and [tuple(f) for f in faces] == s.faces
     assert depth == s.depth
