@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the vectorised assembly_gym hot path (BASELINE.json metric).
+
+One "step" of this bench = one lock-step of the hot path over one batch of E synthetic
+environments: uniform-random policy draw -> place the block -> contact interfaces -> stability
+{last frozen, none frozen} -> reward/termination/auto-reset -> enumerate + place the A raw
+candidates -> (A+1) 64x64 f32 rasters -> bounds/overlap mask -> linear reward  (SURVEY.md §8d).
+`value` counts real environment steps (reset-only lock-steps of an env are not counted).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Envs are independent: each rank owns E envs (weak scaling), there is no data-path collective;
+the only communication is the barrier / max-reduce of the timing contract.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4):
+    """bytes one lock-step must move for `n_envsteps_units` environments holding
+    sum_blocks blocks and sum_cand raw candidates in total (f32 rasters as the reference surfaces them)."""
+    A, k, E = float(sum_cand), float(sum_blocks), float(n_envsteps_units)
+    return (4 * 64 * 64 * (A + E)          # action + state rasters written
+            + 2 * 4 * 64 * 64 * E          # state + obstacle rasters read for the overlap test
+            + 8 * 2 * V * (k + A)          # vertex reads, f64
+            + 24 * (k + A)                 # poses
+            + 16 * A + A + 4 * A           # candidate descriptors, mask, lin_reward
+            + 100 * E)                     # stability I/O
+
+
+# ------------------------------------------------------------------------- CPU baseline (oracle)
+def _cpu_worker(args):
+    seed, env_id, seconds, tower_height, max_steps = args
+    from oracle.env import OracleGym, OracleLockstep, bridge_setup, policy_draw
+    g = OracleGym(**bridge_setup(num_stories=tower_height), max_steps=max_steps)
+    L = OracleLockstep(g)
+    ctr = [0]
+
+    def pick(nv):
+        r = policy_draw(seed, env_id, ctr[0]) % nv
+        ctr[0] += 1
+        return r
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        n += int(L.lockstep(pick)["valid_step"])
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(tower_height, max_steps, seconds=12.0):
+    """The oracle (numpy + HiGHS restatement of the reference path) on the host cores, one env per process."""
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(0, i, seconds, tower_height, max_steps) for i in range(cores)])
+    steps = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return dict(value=steps / wall, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} oracle processes x {seconds:.0f} s of tower_height={tower_height} "
+                       f"random-policy lock-steps ({steps} env-steps; numpy float64 + scipy HiGHS)")
+
+
+# ------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--tower_height", type=int, default=4)
+    ap.add_argument("--max_steps", type=int, default=15)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.tower_height, args.max_steps)      # before the GPU is initialised (fork pool)
+
+    import torch
+    import torch.distributed as dist
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    H = 0.8                                                     # gym_env.py:46 bridge_setup(H=.8, num_stories=N)
+    targets = [(0.5, 0.0, args.tower_height * H + H / 2)]
+    obstacles = [(0.5, 0.0, i * H + H / 2) for i in range(args.tower_height)]
+    env = VecAssemblyGym(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
+                         max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev,
+                         f32_rasters=not args.no_f32_rasters)
+
+    def lockstep():
+        env.select_random()
+        env.step()
+
+    for _ in range(args.warmup):
+        lockstep()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    s0 = env.read_stats()
+    env.timing_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lockstep()
+    sync()
+    dt = time.perf_counter() - t0
+    raster_ms, n_launch = env.timing_end()
+    s1 = env.read_stats()
+    d = {k: s1[k] - s0[k] for k in s1}
+
+    env_steps = float(d["env_steps"])
+    if world > 1:
+        t = torch.tensor([dt, env_steps], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_all, steps_all = float(tmax[0]), float(tsum[1])
+    else:
+        dt_all, steps_all = dt, env_steps
+
+    if rank == 0:
+        units = args.envs * args.steps                      # env slots processed by the timed rasteriser launches
+        alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units)
+        per_launch = alg / max(n_launch, 1)
+        avg_ms = raster_ms / max(n_launch, 1)
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (vectorised assembly_gym, tower_height=%d)" % args.tower_height,
+            "value": steps_all / dt_all,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_all / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d envs/GPU lock-step, bridge_setup(num_stories=%d), trapezoid, max_steps=%d, "
+                            "uniform-random policy, %s" % (args.envs, args.tower_height, args.max_steps,
+                                                           "bit-packed rasters only" if args.no_f32_rasters
+                                                           else "f32 64x64 rasters for every raw candidate"),
+                "envs_per_gpu": args.envs, "tower_height": args.tower_height, "max_steps": args.max_steps,
+                "mean_raw_candidates": d["sum_cand"] / max(units, 1),
+                "mean_valid_candidates": d["sum_valid"] / max(units, 1),
+                "mean_blocks": d["sum_blocks"] / max(units, 1),
+                "env_step_fraction": env_steps / max(units, 1),
+                "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
+                "bytes_per_env_step": alg / max(units, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_raster",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_launch,
+                "whole_step_GBps": alg / dt / 1e9,
+            },
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,8 @@ def lib():
         "bridges_env_step": [vp, vp],
         "bridges_env_select_random": [vp, vp],
         "bridges_env_refresh": [vp, vp],
+        "bridges_env_timing_begin": [vp, i32],
+        "bridges_env_timing_end": [vp, C.POINTER(C.c_double), C.POINTER(i32)],
         "bridges_shapes_upload": [C.POINTER(Shape), i32, C.POINTER(vp)],
         "bridges_shapes_free": [vp],
         "bridges_place": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -145,6 +147,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_refresh",
+    "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",
 )

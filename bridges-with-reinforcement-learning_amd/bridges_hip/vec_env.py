@@ -230,6 +230,15 @@ class VecAssemblyGym:
             self.buf["sel_index"].copy_(sel_index.to(device=self.device, dtype=torch.int32))
         abi.check(self.L.bridges_env_step(self._env, _stream()), "bridges_env_step")
 
+    def timing_begin(self, max_launches):
+        abi.check(self.L.bridges_env_timing_begin(self._env, int(max_launches)), "bridges_env_timing_begin")
+
+    def timing_end(self):
+        """-> (total ms of the rasteriser launches, number of launches), measured with HIP events on the stream."""
+        ms, n = C.c_double(0.0), C.c_int32(0)
+        abi.check(self.L.bridges_env_timing_end(self._env, C.byref(ms), C.byref(n)), "bridges_env_timing_end")
+        return ms.value, n.value
+
     # ------------------------------------------------------------------ views
     def flags(self):
         f = self.buf["step_flags"]

@@ -36,6 +36,10 @@ struct bridges_env {
     DevCtx ctx;
     TaskTable* tt_dev;
     int raster_blocks;
+    // optional per-launch timing of the dominant kernel (k_raster) with HIP events on the launch stream
+    hipEvent_t* ev_start;
+    hipEvent_t* ev_stop;
+    int ev_cap, ev_used;
 };
 
 extern "C" {
@@ -97,7 +101,9 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     c.seed = t->seed;
     hipDeviceProp_t prop;
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
+    env->ev_start = env->ev_stop = nullptr;
+    env->ev_cap = env->ev_used = 0;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     env->raster_blocks = cus * 8;            // 8 x 256-thread workgroups per CU, grid-stride over the work items
@@ -105,10 +111,52 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     return BRIDGES_OK;
 }
 
+static void free_events(bridges_env* env) {
+    for (int i = 0; i < env->ev_cap; ++i) {
+        (void)hipEventDestroy(env->ev_start[i]);
+        (void)hipEventDestroy(env->ev_stop[i]);
+    }
+    delete[] env->ev_start;
+    delete[] env->ev_stop;
+    env->ev_start = env->ev_stop = nullptr;
+    env->ev_cap = env->ev_used = 0;
+}
+
 int bridges_env_destroy(bridges_env* env) {
     if (!env) return BRIDGES_OK;
-    hipFree(env->tt_dev);
+    free_events(env);
+    (void)hipFree(env->tt_dev);
     delete env;
+    return BRIDGES_OK;
+}
+
+int bridges_env_timing_begin(bridges_env* env, int32_t max_launches) {
+    if (!env || max_launches <= 0 || max_launches > (1 << 16)) return fail_arg("timing_begin");
+    free_events(env);
+    env->ev_start = new (std::nothrow) hipEvent_t[max_launches];
+    env->ev_stop = new (std::nothrow) hipEvent_t[max_launches];
+    if (!env->ev_start || !env->ev_stop) return fail_arg("oom");
+    for (int i = 0; i < max_launches; ++i) {
+        HIP_TRY(hipEventCreate(&env->ev_start[i]));
+        HIP_TRY(hipEventCreate(&env->ev_stop[i]));
+        env->ev_cap = i + 1;
+    }
+    env->ev_used = 0;
+    return BRIDGES_OK;
+}
+
+int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n_launches) {
+    if (!env || !raster_ms_total || !n_launches) return fail_arg("timing_end");
+    double total = 0.0;
+    for (int i = 0; i < env->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(env->ev_stop[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, env->ev_start[i], env->ev_stop[i]));
+        total += ms;
+    }
+    *raster_ms_total = total;
+    *n_launches = env->ev_used;
+    free_events(env);
     return BRIDGES_OK;
 }
 
@@ -118,8 +166,11 @@ static int refresh(bridges_env* env, hipStream_t s) {
     LAUNCH_CHECK("k_scan");
     hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_enumerate");
+    const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
+    if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
     hipLaunchKernelGGL(k_raster, dim3(env->raster_blocks), dim3(256), 0, s, c);
     LAUNCH_CHECK("k_raster");
+    if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
     hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
     LAUNCH_CHECK("k_select");
     return BRIDGES_OK;

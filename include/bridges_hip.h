@@ -145,6 +145,10 @@ int bridges_env_reset(bridges_env* env, void* stream);
 int bridges_env_step(bridges_env* env, void* stream);
 /* Synthetic uniform-random policy over the valid candidates -> sel_index. */
 int bridges_env_select_random(bridges_env* env, void* stream);
+/* Time the dominant kernel (the rasteriser) of the next <= max_launches lock-steps with HIP events recorded on
+ * the launch stream; timing_end synchronises on them and returns the summed duration. */
+int bridges_env_timing_begin(bridges_env* env, int32_t max_launches);
+int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n_launches);
 /* Candidate refresh only (used after the host edited the state). */
 int bridges_env_refresh(bridges_env* env, void* stream);
 
