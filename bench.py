@@ -84,7 +84,9 @@ def main():
     ap.add_argument("--tower_height", type=int, default=4)
     ap.add_argument("--max_steps", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
     args = ap.parse_args()
 
@@ -102,7 +104,7 @@ def main():
     import torch
     import torch.distributed as dist
     from bridges_hip.shapes import load_urdf
-    from bridges_hip.vec_env import VecAssemblyGym
+    from bridges_hip.vec_env import VecAssemblyGymGroups
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -113,18 +115,16 @@ def main():
     H = 0.8                                                     # gym_env.py:46 bridge_setup(H=.8, num_stories=N)
     targets = [(0.5, 0.0, args.tower_height * H + H / 2)]
     obstacles = [(0.5, 0.0, i * H + H / 2) for i in range(args.tower_height)]
-    env = VecAssemblyGym(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
-                         max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev,
-                         f32_rasters=not args.no_f32_rasters)
-
-    def lockstep():
-        env.select_random()
-        env.step()
+    env = VecAssemblyGymGroups(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
+                               groups=args.groups, max_steps=args.max_steps, seed=args.seed * 1000003 + rank,
+                               device=dev, f32_rasters=not args.no_f32_rasters, debug=args.debug)
+    lockstep = env.lockstep_random
 
     for _ in range(args.warmup):
         lockstep()
 
     def sync():
+        env.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -155,6 +155,7 @@ def main():
 
     if rank == 0:
         units = args.envs * args.steps                      # env slots processed by the timed rasteriser launches
+        n_launch = max(n_launch, 1)
         alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units)
         per_launch = alg / max(n_launch, 1)
         avg_ms = raster_ms / max(n_launch, 1)
@@ -177,7 +178,7 @@ def main():
                             "uniform-random policy, %s" % (args.envs, args.tower_height, args.max_steps,
                                                            "bit-packed rasters only" if args.no_f32_rasters
                                                            else "f32 64x64 rasters for every raw candidate"),
-                "envs_per_gpu": args.envs, "tower_height": args.tower_height, "max_steps": args.max_steps,
+                "envs_per_gpu": args.envs, "groups": args.groups, "tower_height": args.tower_height, "max_steps": args.max_steps,
                 "mean_raw_candidates": d["sum_cand"] / max(units, 1),
                 "mean_valid_candidates": d["sum_valid"] / max(units, 1),
                 "mean_blocks": d["sum_blocks"] / max(units, 1),

@@ -42,7 +42,8 @@ class Task(C.Structure):
         ("n_envs", C.c_int32), ("max_blocks", C.c_int32), ("max_steps", C.c_int32), ("a_max", C.c_int32),
         ("n_shapes", C.c_int32), ("n_groups", C.c_int32),
         ("group_shape", C.c_int32 * MAX_GROUPS), ("group_face", C.c_int32 * MAX_GROUPS),
-        ("n_ground", C.c_int32), ("n_offsets", C.c_int32), ("n_targets", C.c_int32), ("pad_", C.c_int32),
+        ("n_ground", C.c_int32), ("n_offsets", C.c_int32), ("n_targets", C.c_int32), ("debug", C.c_int32),
+        ("env_id_base", C.c_int32), ("pad_", C.c_int32),
         ("mu", C.c_double), ("density", C.c_double),
         ("floor_half_width", C.c_double), ("floor_depth", C.c_double),
         ("xlim", C.c_double * 2), ("ylim", C.c_double * 2),
@@ -81,6 +82,8 @@ ENV_BUFFER_FIELDS = [
     ("cand_ox", "float64", "C"),
     ("cand_pose", "float64", "C,4"),
     ("cand_verts", "float64", "C,6,2"),
+    ("cand_frames", "float64", "C,6,4"),
+    ("cand_rows", "int32", "C,2"),
     ("cand_inb", "uint8", "C"),
     ("cand_mask", "uint8", "C"),
     ("cand_lin", "float32", "C"),
@@ -123,6 +126,7 @@ def lib():
         "bridges_env_reset": [vp, vp],
         "bridges_env_step": [vp, vp],
         "bridges_env_select_random": [vp, vp],
+        "bridges_env_lockstep_random": [vp, vp],
         "bridges_env_refresh": [vp, vp],
         "bridges_env_timing_begin": [vp, i32],
         "bridges_env_timing_end": [vp, C.POINTER(C.c_double), C.POINTER(i32)],
@@ -146,7 +150,7 @@ def lib():
 
 EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
-    "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_refresh",
+    "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",

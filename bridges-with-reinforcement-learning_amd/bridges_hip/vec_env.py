@@ -78,7 +78,7 @@ def raster_posed(table, verts, shape_ids, grid_x, grid_y, want_bits=True, want_f
 class VecAssemblyGym:
     def __init__(self, num_envs, shapes, obstacles, targets, max_steps=None, mu=0.8, density=1.0, bounds=None,
                  xlim=(-3.0, 7.0), ylim=(0.0, 10.0), x_discr_ground=None, offset_values=(0.0,), seed=0,
-                 device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64)):
+                 device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64), debug=0, env_id_base=0):
         L = abi.require_gpu()
         if tuple(img_size) != (64, 64):
             raise NotImplementedError("the HIP rasteriser is built for 64x64 images (successor_dqn.py:585 default)")
@@ -104,6 +104,8 @@ class VecAssemblyGym:
         self.x_discr_ground = [float(v) for v in x_discr_ground]
         self.offset_values = [float(v) for v in offset_values]
         self.seed = int(seed)
+        self.debug = int(debug)
+        self.env_id_base = int(env_id_base)
         # the task's shape table = the env's shapes + cube06 for obstacles/targets (gym_env.py:277)
         self.cube06 = load_urdf("shapes/cube06.urdf")
         self.table_geoms = self.shapes + [self.cube06]
@@ -193,6 +195,8 @@ class VecAssemblyGym:
             for k in range(3):
                 t.targets[i][k] = tg[k]
         t.seed = self.seed
+        t.debug = self.debug
+        t.env_id_base = self.env_id_base
         self._shape_arr = (abi.Shape * len(self.table_geoms))(*[g.to_struct() for g in self.table_geoms])
         self._xg = (C.c_double * len(self.x_discr_ground))(*self.x_discr_ground)
         self._off = (C.c_double * len(self.offset_values))(*self.offset_values)
@@ -258,3 +262,65 @@ class VecAssemblyGym:
 
     def read_stats(self):
         return dict(zip(abi.STAT_NAMES, self.stats.tolist()))
+
+
+class VecAssemblyGymGroups:
+    """E environments split into G independent groups, each a VecAssemblyGym on its own HIP stream.
+
+    The lock-step of one group is a dependent chain (latency-bound wave-per-env task kernel, then the
+    bandwidth-bound rasteriser); with two or more groups in flight the task kernel of one group overlaps the
+    rasteriser of another.  Environments are independent, so results are identical to a single group with the same
+    global env ids (policy RNG streams are keyed by seed and global env id)."""
+
+    def __init__(self, num_envs, *args, groups=2, device="cuda:0", **kw):
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.G = int(groups)
+        base = num_envs // self.G
+        sizes = [base + (1 if g < num_envs % self.G else 0) for g in range(self.G)]
+        self.E = int(num_envs)
+        self.envs, self.streams, start = [], [], 0
+        for n in sizes:
+            st = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(st):
+                self.envs.append(VecAssemblyGym(n, *args, device=device, env_id_base=start, **kw))
+            self.streams.append(st)
+            start += n
+        self._stream_ptrs = [C.c_void_p(st.cuda_stream) for st in self.streams]
+        self.sync()
+
+    def sync(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def reset(self):
+        for env, st in zip(self.envs, self.streams):
+            with torch.cuda.stream(st):
+                env.reset()
+
+    def lockstep_random(self):
+        """select_random + step for every group, each on its own stream (one C call per group)."""
+        fn = self.envs[0].L.bridges_env_lockstep_random
+        for env, sp in zip(self.envs, self._stream_ptrs):
+            rc = fn(env._env, sp)
+            if rc != 0:
+                abi.check(rc, "bridges_env_lockstep_random")
+
+    def timing_begin(self, max_launches):
+        for env in self.envs:
+            env.timing_begin(max_launches)
+
+    def timing_end(self):
+        ms = n = 0
+        for env in self.envs:
+            a, b = env.timing_end()
+            ms += a
+            n += b
+        return ms, n
+
+    def read_stats(self):
+        out = {}
+        for env in self.envs:
+            for k, v in env.read_stats().items():
+                out[k] = out.get(k, 0) + v
+        return out

@@ -99,6 +99,8 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     c.xlim0 = t->xlim[0]; c.xlim1 = t->xlim[1]; c.ylim0 = t->ylim[0]; c.ylim1 = t->ylim[1];
     memcpy(c.targets, t->targets, sizeof(c.targets));
     c.seed = t->seed;
+    c.debug = t->debug;
+    c.env_id_base = t->env_id_base;
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -106,7 +108,14 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     env->ev_cap = env->ev_used = 0;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    env->raster_blocks = cus * 8;            // 8 x 256-thread workgroups per CU, grid-stride over the work items
+    // persistent rasteriser grid: <= 8 x 256-thread workgroups per CU, sized so a wave sees >= ~8 work items
+    {
+        long long est_items = (long long)t->n_envs * 64;
+        long long blocks = est_items / (4 * 8);
+        if (blocks > (long long)cus * 8) blocks = (long long)cus * 8;
+        if (blocks < cus) blocks = cus;
+        env->raster_blocks = (int)blocks;
+    }
     *out = env;
     return BRIDGES_OK;
 }
@@ -160,9 +169,9 @@ int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n
     return BRIDGES_OK;
 }
 
-static int refresh(bridges_env* env, hipStream_t s) {
+static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     const DevCtx& c = env->ctx;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, c);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, c, after_step);
     LAUNCH_CHECK("k_scan");
     hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_enumerate");
@@ -181,7 +190,7 @@ int bridges_env_reset(bridges_env* env, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_reset, dim3(env->ctx.E), dim3(WAVE), 0, s, env->ctx);
     LAUNCH_CHECK("k_reset");
-    return refresh(env, s);
+    return refresh(env, s, 0);
 }
 
 int bridges_env_step(bridges_env* env, void* stream) {
@@ -189,12 +198,12 @@ int bridges_env_step(bridges_env* env, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_step, dim3(env->ctx.E), dim3(WAVE), 0, s, env->ctx);
     LAUNCH_CHECK("k_step");
-    return refresh(env, s);
+    return refresh(env, s, 1);
 }
 
 int bridges_env_refresh(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");
-    return refresh(env, (hipStream_t)stream);
+    return refresh(env, (hipStream_t)stream, 0);
 }
 
 int bridges_env_select_random(bridges_env* env, void* stream) {
@@ -202,6 +211,12 @@ int bridges_env_select_random(bridges_env* env, void* stream) {
     hipLaunchKernelGGL(k_select, dim3(env->ctx.E), dim3(WAVE), 0, (hipStream_t)stream, env->ctx, 1);
     LAUNCH_CHECK("k_select");
     return BRIDGES_OK;
+}
+
+int bridges_env_lockstep_random(bridges_env* env, void* stream) {
+    int rc = bridges_env_select_random(env, stream);
+    if (rc != BRIDGES_OK) return rc;
+    return bridges_env_step(env, stream);
 }
 
 int bridges_shapes_upload(const bridges_shape* host, int32_t n, bridges_shape** out_dev) {

@@ -58,6 +58,17 @@ __device__ __forceinline__ void align_place(const Frame2& f1, double c2x, double
     pz = ((f1.cz + ox * f1.tz) + oy * f1.nz) - r2z;
 }
 
+// Conservative image-row window of a block spanning z in [zmin, zmax]: one extra pixel row either side; outside it
+// every pixel fails some half-plane test by a margin of ~0.08 world units >> 1 ulp, so skipping the rows cannot
+// change a bit of the raster.  grid_y = np.linspace(ylim1, ylim0, 64) (row 0 = top).
+__device__ __forceinline__ void row_window(const double* gy, double zmin, double zmax, int& r_lo, int& r_hi) {
+    const double ytop = gy[0], dy = (gy[0] - gy[IMG - 1]) / (double)(IMG - 1);
+    r_lo = (int)floor((ytop - zmax) / dy) - 1;
+    r_hi = (int)ceil((ytop - zmin) / dy) + 1;
+    r_lo = r_lo < 0 ? 0 : r_lo;
+    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     uint64_t z = x;
@@ -75,20 +86,51 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+// ---- wave-wide reductions on the DPP cross-lane path (VALU speed; __shfl_xor lowers to ds_bpermute, which costs
+// ~100+ cycles per step and made every simplex pivot ~10k cycles).  gfx9 DPP controls:
+#define DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142   // lane 15 of each row -> next row   (row_mask 0xA)
+#define DPP_ROW_BCAST31 0x143   // lane 31 -> rows 2,3               (row_mask 0xC)
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int x) {
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
-    return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double old, double x) {
+    int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(old), __double2loint(x));
+    int hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(old), __double2hiint(x));
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
+__device__ __forceinline__ double readlane_d(double v, int lane_uniform) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_uniform);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_uniform);
+    return __hiloint2double(hi, lo);
+}
+#define WAVE_REDUCE_D(OP, IDENT_OLD)                                                   \
+    v = OP(v, dpp_d<DPP_QUAD_XOR1, 0xF>(v, v));                                        \
+    v = OP(v, dpp_d<DPP_QUAD_XOR2, 0xF>(v, v));                                        \
+    v = OP(v, dpp_d<DPP_ROW_HALF_MIRROR, 0xF>(v, v));                                  \
+    v = OP(v, dpp_d<DPP_ROW_MIRROR, 0xF>(v, v));                                       \
+    v = OP(v, dpp_d<DPP_ROW_BCAST15, 0xA>(IDENT_OLD, v));                              \
+    v = OP(v, dpp_d<DPP_ROW_BCAST31, 0xC>(IDENT_OLD, v));                              \
+    return readlane_d(v, 63);
+
+__device__ __forceinline__ double add_d_(double a, double b) { return a + b; }
+__device__ __forceinline__ double wave_sum_d(double v) { WAVE_REDUCE_D(add_d_, 0.0) }
+__device__ __forceinline__ double wave_min_d(double v) { WAVE_REDUCE_D(fmin, v) }
+__device__ __forceinline__ double wave_max_d(double v) { WAVE_REDUCE_D(fmax, v) }
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<DPP_QUAD_XOR1, 0xF>(v, v));
+    v = min(v, dpp_i<DPP_QUAD_XOR2, 0xF>(v, v));
+    v = min(v, dpp_i<DPP_ROW_HALF_MIRROR, 0xF>(v, v));
+    v = min(v, dpp_i<DPP_ROW_MIRROR, 0xF>(v, v));
+    v = min(v, dpp_i<DPP_ROW_BCAST15, 0xA>(v, v));
+    v = min(v, dpp_i<DPP_ROW_BCAST31, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Small constant tables of a task, resident in device memory.
@@ -105,6 +147,7 @@ struct DevCtx {
     bridges_env_buffers b;
     const TaskTable* tt;
     int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
+    int32_t debug, env_id_base;     // debug bit0: skip the LPs (timing experiments only)
     int32_t group_shape[BRIDGES_MAX_GROUPS];
     int32_t group_face[BRIDGES_MAX_GROUPS];
     double mu, density, floor_hw, floor_depth;

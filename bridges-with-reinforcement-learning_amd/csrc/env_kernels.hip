@@ -60,9 +60,11 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
-    __shared__ FaceLds F;
-    __shared__ double tab[LP_TAB_LDS];
-    __shared__ int basis[WAVE];
+    // LDS: the staged face frames are dead once the interfaces are found, so they share storage with the tableau
+    __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
+    __shared__ LpScratch S;
+    FaceLds& F = *reinterpret_cast<FaceLds*>(lds_tab);
+    double* tab = lds_tab;
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
     const bridges_shape* shapes = c.tt->shapes;
@@ -75,7 +77,6 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
             c.b.reward[e] = 0.f;
             c.b.lin_reward[e] = 0.f;
             c.b.n_reached[e] = 0;
-            atomicAdd((unsigned long long*)&c.b.stats[ST_RESET_ONLY], 1ull);
         }
         int nc = count_candidates(c, e, 0, lane);
         if (lane == 0) c.b.n_cand[e] = nc;
@@ -136,13 +137,10 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     // ---- stability with the last block frozen / nothing frozen (gym_env.py:238-245, 325-333) ----
     double* ws = c.b.lp_ws + (size_t)e * c.b.lp_ws_stride;
     bool err = false;
-    double w;
-    int piv;
-    const bool st_frozen = rbe_stable(tab, ws, c.b.lp_ws_stride, basis, n_if, if_body, if_geom, nb + 1, nb, pose,
-                                      shape_id, shapes, c.mu, c.density, lane, &w, &piv, &err);
-    __syncthreads();
-    const bool st_free = rbe_stable(tab, ws, c.b.lp_ws_stride, basis, n_if, if_body, if_geom, nb + 1, nb + 1, pose,
-                                    shape_id, shapes, c.mu, c.density, lane, &w, &piv, &err);
+    bool st_frozen = true, st_free = true;
+    if (!(c.debug & 1))
+        rbe_both(tab, ws, c.b.lp_ws_stride, S, n_if, if_body, if_geom, nb + 1, pose, shape_id, shapes, c.mu, c.density,
+                 lane, &st_frozen, &st_free, &err);
 
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
     const bool all_reached = left == 0;
@@ -156,15 +154,12 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     if (lane == 0) {
         flags[F_VALID] = 1; flags[F_STABLE_FROZEN] = st_frozen; flags[F_STABLE_UNFROZEN] = st_free;
         flags[F_TERMINATED] = terminated; flags[F_TRUNCATED] = truncated; flags[F_DONE] = done;
-        flags[F_NO_ACTIONS] = 0; flags[F_LP_ERROR] = err || overflow;
+        flags[F_NO_ACTIONS] = 0; flags[F_LP_ERROR] = (uint8_t)((err ? 1 : 0) | (overflow ? 2 : 0));
         c.b.reward[e] = reward;
         c.b.lin_reward[e] = lin;
         c.b.n_reached[e] = n_reached;
         c.b.n_if[e] = n_if;
         c.b.targets_left[e] = left;
-        atomicAdd((unsigned long long*)&c.b.stats[ST_ENV_STEPS], 1ull);
-        if (err) atomicAdd((unsigned long long*)&c.b.stats[ST_LP_ERRORS], 1ull);
-        if (overflow) atomicAdd((unsigned long long*)&c.b.stats[ST_IF_OVERFLOW], 1ull);
     }
     __syncthreads();
     int nb_after = nb + 1;
@@ -178,43 +173,66 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive prefix sum of n_cand -> cand_offset[E+1]; single workgroup.
-__global__ __launch_bounds__(1024) void k_scan(DevCtx c) {
-    __shared__ int part[1024];
-    __shared__ int carry;
-    const int t = threadIdx.x;
-    if (t == 0) carry = 0;
+// exclusive prefix sum of n_cand -> cand_offset[E+1], plus the per-lock-step statistics (no atomics anywhere:
+// 4096 adds on one word cost ~50 us per kernel on this chip); single workgroup of 16 waves.
+__global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    __shared__ unsigned long long red[16][6];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    long long sum_blocks = 0;
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};   // blocks, env-steps, reset-only, lp errors, if overflow, valid
     for (int base = 0; base < c.E; base += 1024) {
-        int i = base + t;
-        int v = i < c.E ? c.b.n_cand[i] : 0;
-        if (i < c.E) sum_blocks += c.b.n_blocks[i];
-        part[t] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int add = t >= o ? part[t - o] : 0;
-            __syncthreads();
-            part[t] += add;
-            __syncthreads();
+        const int i = base + t;
+        const int v = i < c.E ? c.b.n_cand[i] : 0;
+        if (i < c.E) {
+            acc[0] += (unsigned long long)c.b.n_blocks[i];
+            if (after_step) {
+                const uint8_t* fl = c.b.step_flags + (size_t)i * 8;
+                acc[1] += fl[F_VALID] ? 1 : 0;
+                acc[2] += fl[F_VALID] ? 0 : 1;
+                acc[3] += (fl[F_LP_ERROR] & 1) ? 1 : 0;
+                acc[4] += (fl[F_LP_ERROR] & 2) ? 1 : 0;
+                acc[5] += (unsigned long long)c.b.n_valid[i];      // valid candidates of the state just left
+            }
         }
-        if (i < c.E) c.b.cand_offset[i] = carry + part[t] - v;
+        int incl = v;                                    // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            int up = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == WAVE - 1) wave_tot[wv] = incl;
         __syncthreads();
-        if (t == 1023) carry += part[1023];
+        int wbase = 0;
+        for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+        const int carry = carry_s;
+        if (i < c.E) c.b.cand_offset[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (t == 1023) carry_s = carry + wbase + incl;
         __syncthreads();
     }
-    // block-reduce sum_blocks
-    __shared__ long long red[1024];
-    red[t] = sum_blocks;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long x = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+        if (lane == 0) red[wv][k] = x;
+    }
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (t < o) red[t] += red[t + o];
-        __syncthreads();
-    }
     if (t == 0) {
-        c.b.cand_offset[c.E] = carry;
-        c.b.stats[ST_SUM_CAND] += (uint64_t)carry;
-        c.b.stats[ST_SUM_BLOCKS] += (uint64_t)red[0];
+        unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w)
+            for (int k = 0; k < 6; ++k) tot[k] += red[w][k];
+        c.b.cand_offset[c.E] = carry_s;
+        c.b.stats[ST_SUM_CAND] += (uint64_t)carry_s;
+        c.b.stats[ST_SUM_BLOCKS] += tot[0];
+        c.b.stats[ST_ENV_STEPS] += tot[1];
+        c.b.stats[ST_RESET_ONLY] += tot[2];
+        c.b.stats[ST_LP_ERRORS] += tot[3];
+        c.b.stats[ST_IF_OVERFLOW] += tot[4];
+        c.b.stats[ST_SUM_VALID] += tot[5];
         c.b.stats[ST_LOCKSTEPS] += 1;
     }
 }
@@ -273,17 +291,43 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
         const size_t ci = off + a;
         bool inb = true;
         const double eps = 1e-6;
+        double wx[MAXV], wz[MAXV];
+        double zmin = 1e300, zmax = -1e300;
+#pragma unroll
         for (int i = 0; i < MAXV; ++i) {
-            double wx = 0.0, wz = 0.0;
+            wx[i] = 0.0; wz[i] = 0.0;
             if (i < sn.nv) {
                 double rx, rz;
                 rot2(sn.vx[i], sn.vz[i], cs, sn_, rx, rz);
-                wx = px + rx; wz = pz + rz;
-                if (wx < c.xlim0 - eps || wx > c.xlim1 + eps || wz < c.ylim0 - eps || wz > c.ylim1 + eps) inb = false;
-                if (wz < -eps) inb = false;
+                wx[i] = px + rx; wz[i] = pz + rz;
+                if (wx[i] < c.xlim0 - eps || wx[i] > c.xlim1 + eps || wz[i] < c.ylim0 - eps || wz[i] > c.ylim1 + eps) inb = false;
+                if (wz[i] < -eps) inb = false;
+                zmin = fmin(zmin, wz[i]); zmax = fmax(zmax, wz[i]);
             }
-            c.b.cand_verts[ci * MAXV * 2 + 2 * i] = wx;
-            c.b.cand_verts[ci * MAXV * 2 + 2 * i + 1] = wz;
+            c.b.cand_verts[ci * MAXV * 2 + 2 * i] = wx[i];
+            c.b.cand_verts[ci * MAXV * 2 + 2 * i + 1] = wz[i];
+        }
+        // world face frames (oracle: Block.frames) and the conservative row window of the rasteriser
+        {
+#define PICK6(v, k) ((k) == 5 ? v[5] : (k) == 4 ? v[4] : (k) == 3 ? v[3] : (k) == 2 ? v[2] : (k) == 1 ? v[1] : v[0])
+#pragma unroll
+            for (int f = 0; f < MAXV; ++f) {
+                double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+                if (f < sn.nv) {
+                    const int ia = sn.fa[f], ib = sn.fb[f];
+                    const double ax = PICK6(wx, ia), az = PICK6(wz, ia), bx = PICK6(wx, ib), bz = PICK6(wz, ib);
+                    Frame2 fr = edge_frame(ax, az, bx, bz);
+                    o0 = fr.cx; o1 = fr.cz; o2 = fr.nx; o3 = fr.nz;
+                }
+                double2* dst = reinterpret_cast<double2*>(c.b.cand_frames + (ci * MAXV + f) * 4);
+                dst[0] = make_double2(o0, o1);
+                dst[1] = make_double2(o2, o3);
+            }
+#undef PICK6
+            int r_lo, r_hi;
+            row_window(c.tt->grid_y, zmin, zmax, r_lo, r_hi);
+            c.b.cand_rows[ci * 2 + 0] = r_lo | (r_hi << 8) | (sn.nv << 16) | ((inb ? 1 : 0) << 24);   // packed for the rasteriser
+            c.b.cand_rows[ci * 2 + 1] = e;
         }
         c.b.cand_pose[ci * 4 + 0] = px; c.b.cand_pose[ci * 4 + 1] = pz;
         c.b.cand_pose[ci * 4 + 2] = cs; c.b.cand_pose[ci * 4 + 3] = sn_;
@@ -299,10 +343,14 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
 // f32 expansion of a 64x64 bit raster held one row per lane: 16 wave-wide float4 stores of 1 KiB.
 __device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, int lane) {
     const int sub = lane >> 4, col4 = (lane & 15) * 4;
+    const uint64_t nonzero_rows = __ballot(rowbits != 0ull);       // most of a raster is empty rows
 #pragma unroll
     for (int r0 = 0; r0 < IMG; r0 += 4) {
-        uint64_t m = shfl_u64(rowbits, r0 + sub);
-        uint32_t nib = (uint32_t)(m >> col4) & 0xFu;
+        uint32_t nib = 0u;
+        if ((nonzero_rows >> r0) & 0xFull) {
+            uint64_t m = shfl_u64(rowbits, r0 + sub);
+            nib = (uint32_t)(m >> col4) & 0xFu;
+        }
         float4 v;
         v.x = (nib & 1u) ? 1.f : 0.f;
         v.y = (nib & 2u) ? 1.f : 0.f;
@@ -312,12 +360,48 @@ __device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, in
     }
 }
 
-// Rasterise one convex outline.  Lane = pixel column; returns the row masks with row r in lane r.
-// If reward_map != nullptr also accumulates sum(inside * reward_map) into *lin (per lane partial).
+// Rasterise one convex outline from its world face frames.  Lane = pixel column; returns the row masks with row r
+// in lane r.  `frames` = [nv][4] (centre.xz, normal.xz), gyv = this lane's grid_y value (lane r holds Y[r]).
+// If s_w != nullptr (LDS copy of the reward map) also accumulates sum(inside * reward_map) into *lin (per lane).
+__device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, int r_lo, int r_hi, double X, double gyv,
+                                                  const float* s_w, double* lin, int lane) {
+    double fr0 = 0.0, fr1 = 0.0, fr2 = 0.0, fr3 = 0.0;
+    if (lane < nv) {
+        const double2* p = reinterpret_cast<const double2*>(frames + (size_t)lane * 4);
+        double2 a = p[0], b = p[1];
+        fr0 = a.x; fr1 = a.y; fr2 = b.x; fr3 = b.y;
+    }
+    double txf[MAXV], czf[MAXV], nzf[MAXV];
+#pragma unroll
+    for (int f = 0; f < MAXV; ++f) {
+        const double cxf = readlane_d(fr0, f), nxf = readlane_d(fr2, f);
+        czf[f] = readlane_d(fr1, f);
+        nzf[f] = readlane_d(fr3, f);
+        txf[f] = (X - cxf) * nxf;
+    }
+    uint64_t mybits = 0ull;
+    double acc = 0.0;
+    for (int r = r_lo; r <= r_hi; ++r) {
+        const double Y = readlane_d(gyv, r);
+        bool in = true;
+#pragma unroll
+        for (int f = 0; f < MAXV; ++f) {
+            if (f < nv) {
+                double d = txf[f] + (Y - czf[f]) * nzf[f];
+                in = in && (d <= 0.0);
+            }
+        }
+        const uint64_t m = __ballot(in);
+        if (lane == r) mybits = m;
+        if (s_w != nullptr && in) acc += (double)s_w[r * IMG + lane];
+    }
+    if (lin) *lin = acc;
+    return mybits;
+}
+
+// Same from world vertices (stand-alone operator): frames are derived first (oracle/raster.py contains_2d).
 __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, int nv, const int32_t* fa,
-                                                   const int32_t* fb, const double* gx, const double* gy,
-                                                   const float* reward_map, double* lin, int lane) {
-    // face frames: lane f computes face f, then broadcast (oracle/raster.py contains_2d)
+                                                   const int32_t* fb, const double* gx, const double* gy, int lane) {
     double cx = 0.0, cz = 0.0, nx = 0.0, nz = 0.0, myz = 0.0;
     if (lane < nv) {
         Frame2 fr = edge_frame(v[2 * fa[lane]], v[2 * fa[lane] + 1], v[2 * fb[lane]], v[2 * fb[lane] + 1]);
@@ -326,23 +410,18 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
     }
     const double zmin = wave_min_d(lane < nv ? myz : 1e300);
     const double zmax = wave_max_d(lane < nv ? myz : -1e300);
+    int r_lo, r_hi;
+    row_window(gy, zmin, zmax, r_lo, r_hi);
     const double X = gx[lane];
-    const double ytop = gy[0], dy = (gy[0] - gy[IMG - 1]) / (double)(IMG - 1);
-    // conservative row window (one extra pixel row either side; outside it every pixel fails some half-plane by >> 1 ulp)
-    int r_lo = (int)floor((ytop - zmax) / dy) - 1;
-    int r_hi = (int)ceil((ytop - zmin) / dy) + 1;
-    r_lo = r_lo < 0 ? 0 : r_lo;
-    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
     double txf[MAXV], czf[MAXV], nzf[MAXV];
 #pragma unroll
     for (int f = 0; f < MAXV; ++f) {
-        double cxf = shfl_d(cx, f), nxf = shfl_d(nx, f);
-        czf[f] = shfl_d(cz, f);
-        nzf[f] = shfl_d(nz, f);
+        double cxf = readlane_d(cx, f), nxf = readlane_d(nx, f);
+        czf[f] = readlane_d(cz, f);
+        nzf[f] = readlane_d(nz, f);
         txf[f] = (X - cxf) * nxf;
     }
     uint64_t mybits = 0ull;
-    double acc = 0.0;
     for (int r = r_lo; r <= r_hi; ++r) {
         const double Y = gy[r];
         bool in = true;
@@ -355,35 +434,43 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
         }
         uint64_t m = __ballot(in);
         if (lane == r) mybits = m;
-        if (reward_map != nullptr && in) acc += (double)reward_map[r * IMG + lane];
     }
-    if (lin) *lin = acc;
     return mybits;
 }
 
 // Persistent rasteriser: work item i < total -> candidate i (compact index), else state raster of env i-total.
+// One wave per image; the 16 KiB reward map is staged once per workgroup in LDS.
 __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
+    __shared__ float s_w[IMG * IMG];
+    for (int i = threadIdx.x; i < IMG * IMG / 4; i += blockDim.x)
+        reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(c.b.reward_map)[i];
+    __syncthreads();
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     const int total = c.b.cand_offset[c.E];
     const int items = total + c.E;
     const bridges_shape* shapes = c.tt->shapes;
-    for (int it = wave; it < items; it += nwaves) {
+    const double X = c.tt->grid_x[lane];
+    const double gyv = c.tt->grid_y[lane];
+    const uint64_t obst = c.b.obstacle_bits[lane];
+    for (int itv = wave; itv < items; itv += nwaves) {
+        const int it = __builtin_amdgcn_readfirstlane(itv);       // wave-uniform: metadata comes through scalar loads
         if (it < total) {
             const size_t ci = (size_t)it;
-            const int e = c.b.cand_env[ci];
-            const bridges_shape& sh = shapes[c.b.cand_desc[ci * 4 + 2]];
+            const int meta = c.b.cand_rows[ci * 2];
+            const int e = c.b.cand_rows[ci * 2 + 1];
+            const int r_lo = meta & 0xff, r_hi = (meta >> 8) & 0xff, nv = (meta >> 16) & 0xff;
+            const bool inb = (meta >> 24) & 1;
             double linp;
-            uint64_t bits = raster_outline(c.b.cand_verts + ci * MAXV * 2, sh.nv, sh.fa, sh.fb, c.tt->grid_x,
-                                           c.tt->grid_y, c.b.reward_map, &linp, lane);
-            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | c.b.obstacle_bits[lane];
+            const uint64_t bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, X, gyv, s_w, &linp, lane);
+            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | obst;
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
             const double lin = wave_sum_d(linp);
             c.b.cand_bits[ci * IMG + lane] = bits;
             if (lane == 0) {
                 c.b.cand_lin[ci] = (float)lin;
-                c.b.cand_mask[ci] = (uint8_t)(c.b.cand_inb[ci] && !overlap);
+                c.b.cand_mask[ci] = (uint8_t)(inb && !overlap);
             }
             if (c.b.cand_raster) write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane);
         } else if (c.b.state_raster) {
@@ -408,7 +495,7 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
     int sel = 0;
     if (nvalid > 0 && draw) {
         uint64_t ctr = c.b.draw_counter[e];
-        uint64_t r = splitmix64(splitmix64(((c.seed & 0xFFFFFFFFull) << 32) | (uint32_t)e) ^ ctr);
+        uint64_t r = splitmix64(splitmix64(((c.seed & 0xFFFFFFFFull) << 32) | (uint32_t)(c.env_id_base + e)) ^ ctr);
         int rank = (int)(r % (uint64_t)nvalid);
         int seen = 0;
         for (int a0 = 0; a0 < nc; a0 += WAVE) {
@@ -434,7 +521,6 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
                 c.b.needs_reset[e] = 1;
                 c.b.step_flags[(size_t)e * 8 + F_NO_ACTIONS] = 1;
             }
-            atomicAdd((unsigned long long*)&c.b.stats[ST_SUM_VALID], (unsigned long long)nvalid);
         }
     }
 }

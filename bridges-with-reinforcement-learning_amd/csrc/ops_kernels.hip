@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* sha
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     for (int it = wave; it < n; it += nwaves) {
         const bridges_shape& sh = shapes[shape_id[it]];
-        uint64_t b = raster_outline(verts + (size_t)it * MAXV * 2, sh.nv, sh.fa, sh.fb, gx, gy, nullptr, nullptr, lane);
+        uint64_t b = raster_outline(verts + (size_t)it * MAXV * 2, sh.nv, sh.fa, sh.fb, gx, gy, lane);
         if (bits) bits[(size_t)it * IMG + lane] = b;
         if (img) write_f32_image(img + (size_t)it * IMG * IMG, b, lane);
     }
@@ -68,9 +68,10 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
                                                     const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
                                                     double density, double floor_hw, double floor_depth,
                                                     uint8_t* stable, double* info, double* lp_ws, int64_t ws_stride) {
-    __shared__ FaceLds F;
-    __shared__ double tab[LP_TAB_LDS];
-    __shared__ int basis[WAVE];
+    __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
+    __shared__ LpScratch S;
+    FaceLds& F = *reinterpret_cast<FaceLds*>(lds_tab);
+    double* tab = lds_tab;
     const int e = blockIdx.x, lane = threadIdx.x;
     const int nb = n_blocks[e];
     const double* pose = pose_all + (size_t)e * K * 4;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     int n_free = nb;
     while (n_free > 0 && ((fm >> (n_free - 1)) & 1u)) --n_free;
     bool bad_mask = (fm & ((n_free >= 32) ? 0xffffffffu : ((1u << n_free) - 1u))) != 0u;
+    const long long t0 = clock64();
     stage_faces(F, 0, 1 + nb * MAXV, verts, shape_id, shapes, floor_hw, lane);
     __syncthreads();
     int n_if = 0;
@@ -98,14 +100,20 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     bool err = false;
     double w = 0.0;
     int piv = 0;
-    bool st = rbe_stable(tab, tab_ws, tab_cap, basis, n_if, if_body, if_geom, nb, n_free,
+    const long long t1 = clock64();
+    bool st = rbe_stable(tab, tab_ws, tab_cap, S, n_if, if_body, if_geom, n_free,
                          pose, shape_id, shapes, mu, density, lane, &w, &piv, &err);
     if (lane == 0) {
         stable[e] = (uint8_t)(st && !bad_mask);
-        info[4 * e + 0] = w;
-        info[4 * e + 1] = (double)n_if;
-        info[4 * e + 2] = (double)piv;
-        info[4 * e + 3] = bad_mask ? 2.0 : ((err || overflow) ? 1.0 : 0.0);
+        const long long t2 = clock64();
+        info[8 * e + 0] = w;
+        info[8 * e + 1] = (double)n_if;
+        info[8 * e + 2] = (double)piv;
+        info[8 * e + 3] = bad_mask ? 2.0 : ((err || overflow) ? 1.0 : 0.0);
+        info[8 * e + 4] = (double)(t1 - t0);     // shader cycles: face staging + interface detection
+        info[8 * e + 5] = (double)(t2 - t1);     // shader cycles: tableau build + simplex
+        info[8 * e + 6] = 0.0;
+        info[8 * e + 7] = 0.0;
     }
 }
 

@@ -21,7 +21,8 @@ namespace bridges {
 #define LP_TIE 1e-9           // ratios within this (relative) band are ties
 #define LP_STALL 40           // degenerate pivots before Bland's rule takes over
 #define LP_MAX_PIVOTS 5000
-#define LP_TAB_LDS 1536                       // doubles of LDS tableau per wave (12 KiB)
+#define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
+#define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (8 KiB); larger tableaux live in lp_ws
 #define MAXFACES (1 + MAXK * MAXV)            // floor + K blocks
 #define LP_MAX_COLS (4 * MAXIF)
 #define LP_MAX_CHUNKS ((LP_MAX_COLS + 1 + WAVE - 1) / WAVE)
@@ -120,7 +121,11 @@ __device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int3
 
 // Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = cost.
 // Blocks >= n_free are fixed (only the last block is ever frozen, gym_env.py:235-240).
-__device__ inline void lp_build(double* T, int stride, int m, int n, int n_if, const int32_t* if_body,
+// The right-hand side carries a tiny deterministic perturbation (<= 2e-7 per row, far below RBE_FEAS_TOL): these
+// equilibrium systems are massively degenerate (most rhs entries are exactly 0) and the perturbation is what keeps
+// the simplex from stalling.
+template <typename TP>
+__device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const int32_t* if_body,
                                 const double* if_geom, int n_free, const double* pose /*[K,4]*/,
                                 const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
                                 int lane) {
@@ -152,7 +157,10 @@ __device__ inline void lp_build(double* T, int stride, int m, int n, int n_if, c
             }
         }
     }
-    for (int b = lane; b < n_free; b += WAVE) T[(3 * b + 1) * stride + n] = density * shapes[shape_id[b]].volume;
+    for (int i = lane; i < m; i += WAVE) {
+        double rhs = (i % 3 == 1) ? density * shapes[shape_id[i / 3]].volume : 0.0;
+        T[i * stride + n] = rhs + LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    }
     __syncthreads();
     for (int q = lane; q <= n; q += WAVE) {
         double s = 0.0;
@@ -162,15 +170,28 @@ __device__ inline void lp_build(double* T, int stride, int m, int n, int n_if, c
     __syncthreads();
 }
 
-// Phase-1 simplex on the dense tableau (artificial columns implicit: an artificial that leaves never returns).
-// Pricing: most negative reduced cost (ties -> lowest column).  Ratio test: rows with a pivot candidate > LP_TAU,
-// minimum ratio; among ratios tied within LP_TIE the LARGEST pivot element wins (ties -> lowest row) -- the
-// float32 block meshes make faces parallel only to ~1e-7, which creates legitimate 1e-8 tableau entries that must
-// never be pivoted on.  After LP_STALL pivots without progress the rules switch to Bland's (lowest entering column,
-// lowest leaving variable) until the objective moves again.  Every decision is a wave reduction with a total
-// order, so the pivot sequence -- and the boolean -- is identical on every GPU.
-// Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
-__device__ __forceinline__ double artificial_sum(const double* T, int stride, int m, int n, const int* basis, int lane) {
+struct LpScratch {                 // LDS scratch of one wave's simplex
+    double col[WAVE];              // entering column (row i in slot i, cost entry in slot m)
+    double rowr[LP_MAX_COLS + 2];  // normalised pivot row
+    int basis[WAVE];
+};
+
+// Ordering point between the lanes of the ONE wave that owns a tableau.  LDS operations of a wave execute in
+// program order, so for an LDS tableau a compiler fence is enough; the global overflow path needs the real
+// barrier (s_waitcnt vmcnt(0)) before other lanes re-read what was stored.
+template <bool IN_LDS>
+__device__ __forceinline__ void wave_sync() {
+    if constexpr (IN_LDS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <typename TP>
+__device__ __forceinline__ double artificial_sum(TP T, int stride, int m, int n, const int* basis, int lane) {
     double v = 0.0;
     if (lane < m && basis[lane] >= n) {
         double rhs = T[lane * stride + n];
@@ -179,15 +200,41 @@ __device__ __forceinline__ double artificial_sum(const double* T, int stride, in
     return wave_sum_d(v);
 }
 
-__device__ inline double lp_phase1(double* T, int stride, int m, int n, int* basis /*LDS [>=m]*/, int lane,
-                                   int* pivots_out, bool* error) {
+// 1/x to ~1e-16 relative: hardware v_rcp_f64 seed + one Newton step (the LP needs no correctly rounded quotient;
+// a full IEEE f64 division is ~40 dependent instructions and sat on the critical path of every pivot).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return r + r * (1.0 - x * r);
+}
+
+// Phase-1 simplex on the dense tableau (artificial columns implicit: an artificial that leaves never returns).
+// Pricing: most negative reduced cost (ties -> lowest lane).  Ratio test: rows with a pivot candidate > LP_TAU,
+// minimum ratio; among ratios tied within LP_TIE the LARGEST pivot element wins (ties -> lowest row) -- the
+// float32 block meshes make faces parallel only to ~1e-7, which creates legitimate 1e-8 tableau entries that must
+// never be pivoted on.  After LP_STALL pivots without progress the rules switch to Bland's (lowest entering column,
+// lowest leaving variable) until the objective moves again.  Every decision is a wave reduction with a total
+// order, so the pivot sequence -- and the boolean -- is identical on every GPU.
+// A pivot is one dependent chain (price -> ratio -> stage -> sweep), so its latency is what bounds the kernel:
+// reductions run on DPP, the cells of the elimination sweep are batched 4 per lane, and the running objective is
+// read from the cost row (the exact artificial sum is recomputed only to confirm a "feasible" exit).
+// Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
+template <bool IN_LDS, typename TP>
+__device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S, int lane, int* pivots_out,
+                                   bool* error) {
+    int* basis = S.basis;
     for (int i = lane; i < m; i += WAVE) basis[i] = n + i;       // artificial i
-    __syncthreads();
+    wave_sync<IN_LDS>();
     int pivots = 0, stall = 0;
     bool bland = false;
-    const int nchunk = (n + 1 + WAVE - 1) / WAVE;
-    double w = artificial_sum(T, stride, m, n, basis, lane);
-    while (w > RBE_FEAS_TOL) {
+    const int nchunk = (n + WAVE - 1) / WAVE;
+    const int ncols = n + 1;
+    const int cells = (m + 1) * ncols;
+    double w = -T[m * stride + n];
+    for (;;) {
+        if (w <= RBE_FEAS_TOL) {                                   // confirm with the exact artificial sum
+            w = artificial_sum(T, stride, m, n, basis, lane);
+            if (w <= RBE_FEAS_TOL) break;
+        }
         // ---- entering column ----
         int jin = -1;
         if (bland) {
@@ -199,87 +246,94 @@ __device__ inline double lp_phase1(double* T, int stride, int m, int n, int* bas
             }
         } else {
             double dbest = 0.0;
-            int jbest = 0x7fffffff;
+            int jbest = 0;
             for (int j = lane; j < n; j += WAVE) {
                 double d = T[m * stride + j];
-                if (d < dbest) { dbest = d; jbest = j; }           // strict: keeps the lowest column of a tie
+                if (d < dbest) { dbest = d; jbest = j; }           // strict: keeps the lane's lowest column of a tie
             }
             double dmin = wave_min_d(dbest);
             if (dmin < -LP_EPS_COST) {
-                int jc = (dbest == dmin) ? jbest : 0x7fffffff;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) jc = min(jc, __shfl_xor(jc, o, WAVE));
-                jin = jc;
+                int src = __ffsll((long long)__ballot(dbest == dmin)) - 1;
+                jin = __builtin_amdgcn_readlane(jbest, src);
             }
         }
-        if (jin < 0) break;                                        // optimal with w > tol: infeasible
+        if (jin < 0) {                                             // optimal: w is the true minimum
+            w = artificial_sum(T, stride, m, n, basis, lane);
+            break;
+        }
         // ---- ratio test, lanes over rows (m <= 48 < 64) ----
         double col = (lane <= m) ? T[lane * stride + jin] : 0.0;   // lane m holds the cost entry
         double ratio = 1e300;
         if (lane < m && col > LP_TAU) {
             double rhs = T[lane * stride + n];
-            ratio = (rhs > 0.0 ? rhs : 0.0) / col;
+            ratio = (rhs > 0.0 ? rhs : 0.0) * fast_rcp(col);
         }
         const double rmin = wave_min_d(ratio);
         if (rmin >= 1e300) {                                       // no usable pivot in this column: retire it
             if (lane == 0) T[m * stride + jin] = 0.0;
-            __syncthreads();
+            wave_sync<IN_LDS>();
             continue;
         }
         const bool tie = ratio <= rmin + LP_TIE * (1.0 + rmin);
         int r;
         if (bland) {
             int var = tie ? basis[lane] : 0x7fffffff;
-            int vmin = var;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) vmin = min(vmin, __shfl_xor(vmin, o, WAVE));
+            int vmin = wave_min_i(var);
             r = __ffsll((long long)__ballot(tie && var == vmin)) - 1;
         } else {
             double cmax = wave_max_d(tie ? col : -1e300);
             r = __ffsll((long long)__ballot(tie && col == cmax)) - 1;
         }
-        const double piv = shfl_d(col, r);
-        __syncthreads();
-        // ---- pivot: normalise row r (kept in registers), eliminate the column everywhere else ----
-        double rowr[LP_MAX_CHUNKS];
+        const double ipiv = fast_rcp(readlane_d(col, r));
+        // ---- stage the entering column and the normalised pivot row ----
+        S.col[lane] = col;
+        for (int q = lane; q < ncols; q += WAVE) S.rowr[q] = (q == jin) ? 1.0 : T[r * stride + q] * ipiv;
+        wave_sync<IN_LDS>();
+        // ---- flat elimination sweep, 4 independent cells per lane per trip (loads first, then stores: the
+        //      cells are distinct, which the compiler cannot prove, so the batching is explicit) ----
+        {
+            const int di = WAVE / ncols, dq = WAVE - di * ncols;
+            int i = lane / ncols, q = lane - i * ncols;
+            for (int idx = lane; idx < cells; idx += 4 * WAVE) {
+                int ii[4], qq[4];
+                double tv[4], cv[4], rv[4];
 #pragma unroll
-        for (int c = 0; c < LP_MAX_CHUNKS; ++c) {
-            int q = c * WAVE + lane;
-            rowr[c] = 0.0;
-            if (c < nchunk && q <= n) {
-                double v = (q == jin) ? 1.0 : T[r * stride + q] / piv;
-                rowr[c] = v;
-                T[r * stride + q] = v;
-            }
-        }
-        for (int i = 0; i <= m; ++i) {
-            if (i == r) continue;
-            double f = shfl_d(col, i);
-            if (f == 0.0) continue;
+                for (int u = 0; u < 4; ++u) {
+                    ii[u] = i; qq[u] = q;
+                    const bool ok = idx + u * WAVE < cells;
+                    tv[u] = ok ? T[i * stride + q] : 0.0;
+                    cv[u] = ok ? S.col[i] : 0.0;
+                    rv[u] = ok ? S.rowr[q] : 0.0;
+                    i += di; q += dq;
+                    if (q >= ncols) { q -= ncols; ++i; }
+                }
 #pragma unroll
-            for (int c = 0; c < LP_MAX_CHUNKS; ++c) {
-                int q = c * WAVE + lane;
-                if (c < nchunk && q <= n) {
-                    double v = (q == jin) ? 0.0 : T[i * stride + q] - f * rowr[c];
-                    T[i * stride + q] = v;
+                for (int u = 0; u < 4; ++u) {
+                    if (idx + u * WAVE < cells) {
+                        double v;
+                        if (ii[u] == r) v = rv[u];
+                        else if (qq[u] == jin) v = 0.0;
+                        else v = tv[u] - cv[u] * rv[u];
+                        T[ii[u] * stride + qq[u]] = v;
+                    }
                 }
             }
         }
         if (lane == 0) basis[r] = jin;
-        __syncthreads();
-        const double wn = artificial_sum(T, stride, m, n, basis, lane);
+        wave_sync<IN_LDS>();
+        const double wn = -T[m * stride + n];
         if (wn < w - 1e-12) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
-        if (++pivots >= LP_MAX_PIVOTS) { *error = true; break; }
+        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m, n, basis, lane); break; }
     }
     *pivots_out = pivots;
     return w;
 }
 
 // Stability of one assembly variant.  n_free = number of leading free blocks.
-__device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_cap, int* basis, int n_if,
-                                  const int32_t* if_body, const double* if_geom, int n_blocks, int n_free,
+__device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
+                                  const int32_t* if_body, const double* if_geom, int n_free,
                                   const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
                                   double mu, double density, int lane, double* w_out, int* pivots_out,
                                   bool* error) {
@@ -287,19 +341,38 @@ __device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_ca
     *pivots_out = 0;
     if (n_if == 0) return n_free == 0;                 // stability.py:53-56
     if (n_free == 0) return true;
-    int m = 3 * n_free, n = 4 * n_if;
+    const int m = 3 * n_free, n = 4 * n_if;
     int stride = n + 1;
     if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
-    int64_t cells = (int64_t)(m + 1) * stride;
-    double* T = tab_lds;
-    if (cells > LP_TAB_LDS) {
+    const int64_t cells = (int64_t)(m + 1) * stride;
+    double w;
+    if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
+        lp_build(tab_lds, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
+        w = lp_phase1<true>(tab_lds, stride, m, n, S, lane, pivots_out, error);
+    } else {
         if (cells > ws_cap) { *error = true; return false; }
-        T = tab_ws;
+        lp_build(tab_ws, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
+        w = lp_phase1<false>(tab_ws, stride, m, n, S, lane, pivots_out, error);
     }
-    lp_build(T, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
-    double w = lp_phase1(T, stride, m, n, basis, lane, pivots_out, error);
     *w_out = w;
     return w <= RBE_FEAS_TOL;
+}
+
+// Both variants of gym_env.py:325-333 with one or two LPs: the unfrozen system is the frozen one plus three more
+// equilibrium rows, so "stable with nothing frozen" implies "stable with the last block frozen".
+__device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
+                                const int32_t* if_body, const double* if_geom, int n_blocks, const double* pose,
+                                const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
+                                int lane, bool* st_frozen, bool* st_free, bool* error) {
+    double w;
+    int piv;
+    *st_free = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu,
+                          density, lane, &w, &piv, error);
+    __syncthreads();
+    if (*st_free) { *st_frozen = true; return; }
+    *st_frozen = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks - 1, pose, shape_id, shapes,
+                            mu, density, lane, &w, &piv, error);
+    __syncthreads();
 }
 
 }  // namespace bridges

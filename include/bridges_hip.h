@@ -67,6 +67,8 @@ typedef struct {
     int32_t n_ground;          /* len(x_discr_ground) */
     int32_t n_offsets;         /* len(offset_values) */
     int32_t n_targets;
+    int32_t debug;             /* 0; bit0 = skip the LPs (kernel timing experiments only) */
+    int32_t env_id_base;       /* global id of env 0 (policy RNG stream = seed, env_id_base + e) */
     int32_t pad_;
     double mu, density;        /* assembly_env.py:164 */
     double floor_half_width;   /* assembly_env.py:290-296 */
@@ -113,6 +115,8 @@ typedef struct {
     double* cand_ox;           /* [C] offset_x */
     double* cand_pose;         /* [C,4] */
     double* cand_verts;        /* [C,6,2] */
+    double* cand_frames;       /* [C,6,4] world face frames (centre.xz, normal.xz) of the candidate block */
+    int32_t* cand_rows;        /* [C,2] rasteriser work descriptor: row_lo | row_hi<<8 | nv<<16 | in_bounds<<24, owning env */
     uint8_t* cand_inb;         /* [C] inside xlim/ylim (gym_env.py:304-323) */
     uint8_t* cand_mask;        /* [C] filter_actions result (actions.py:71-82) */
     float* cand_lin;           /* [C] sum(action_raster * reward_map) */
@@ -145,6 +149,8 @@ int bridges_env_reset(bridges_env* env, void* stream);
 int bridges_env_step(bridges_env* env, void* stream);
 /* Synthetic uniform-random policy over the valid candidates -> sel_index. */
 int bridges_env_select_random(bridges_env* env, void* stream);
+/* select_random + step in one call (the synthetic-rollout inner loop). */
+int bridges_env_lockstep_random(bridges_env* env, void* stream);
 /* Time the dominant kernel (the rasteriser) of the next <= max_launches lock-steps with HIP events recorded on
  * the launch stream; timing_end synchronises on them and returns the summed duration. */
 int bridges_env_timing_begin(bridges_env* env, int32_t max_launches);
@@ -171,7 +177,8 @@ int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* strea
 /* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
  * padded block lists.  verts [n,K,6,2], shape_id [n,K], n_blocks [n], fixed_mask [n] (bit b = block b
  * is_static; must be a suffix of the block list, as the reference only freezes the last block)
- * -> stable [n] u8, info [n,4] f64 (phase-1 objective, n_interfaces, pivots, error).
+ * -> stable [n] u8, info [n,8] f64 (phase-1 objective, n_interfaces, pivots, error, shader cycles spent in
+ *    interface detection, shader cycles spent in the LP, 0, 0).
  * lp_ws: [n, lp_ws_stride] doubles, lp_ws_stride >= 9*MAX_INTERFACES + (3K+1)*(4*MAX_INTERFACES+2). */
 int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose,
                       const double* verts, const int32_t* shape_id, const int32_t* n_blocks,
