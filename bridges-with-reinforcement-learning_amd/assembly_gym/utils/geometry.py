@@ -1,0 +1,28 @@
+"""Geometry helpers of the path (assembly_gym/assembly_gym/utils/geometry.py:39-50, 89-105 of the reference)."""
+import math
+
+from bridges_hip import ops
+
+
+def align_frames_2d(frame1, frame2_shape_face, frame1_coordinates=None):
+    """(position, (cos, sin)) aligning a shape face onto frame1.  ``frame2_shape_face`` = (shape, face): the kernel
+    needs the shape's local face frame, which is part of the uploaded shape table."""
+    shape, face = frame2_shape_face
+    if frame1_coordinates is None:
+        frame1_coordinates = [0, 0, 0]
+    f1 = (frame1.point[0], frame1.point[2], frame1.xaxis[0], frame1.xaxis[2], frame1.normal[0], frame1.normal[2])
+    pose, _verts = ops.place(f1, shape.geometry, face, frame1_coordinates[0], frame1_coordinates[2])
+    return [pose[0], 0.0, pose[1]], (pose[2], pose[3])
+
+
+def project_point_on_box(box, point):
+    return (min(max(point[0], box.xmin), box.xmax),
+            min(max(point[1], box.ymin), box.ymax),
+            min(max(point[2], box.zmin), box.zmax))
+
+
+def distance_box_point(box, point):
+    if box.contains_point(point):
+        return 0.
+    q = project_point_on_box(box, point)
+    return math.sqrt(sum((a - b) ** 2 for a, b in zip(point, q)))

@@ -133,6 +133,9 @@ def lib():
         "bridges_shapes_upload": [C.POINTER(Shape), i32, C.POINTER(vp)],
         "bridges_shapes_free": [vp],
         "bridges_place": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_create_block": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_pose_block": [vp, i32, vp, vp, vp, vp],
+        "bridges_face_frames": [vp, i32, vp, vp, vp, vp],
         "bridges_raster": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
         "bridges_bits_or": [i32, vp, vp, vp, vp],
         "bridges_bits_to_f32": [i32, vp, vp, vp],
@@ -152,7 +155,7 @@ EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",
 )
 

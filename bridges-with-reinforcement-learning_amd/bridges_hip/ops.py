@@ -1,0 +1,197 @@
+"""Thin host wrappers of the stand-alone HIP operators (single calls on caller-shaped batches).
+
+Used by the single-environment ``assembly_gym`` API; every function launches a kernel of
+libbridges_hip.so on the current torch stream and returns device tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from .shapes import ShapeGeometry
+
+_tables = {}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ShapeRegistry:
+    """Process-wide device table of every ShapeGeometry seen so far (ids are stable)."""
+
+    def __init__(self):
+        self.geoms = []
+        self._dev = None
+        self._dev_count = 0
+
+    def id_of(self, geom: ShapeGeometry):
+        for i, g in enumerate(self.geoms):
+            if g is geom:
+                return i
+        self.geoms.append(geom)
+        return len(self.geoms) - 1
+
+    def device_table(self):
+        L = abi.require_gpu()
+        if self._dev is None or self._dev_count != len(self.geoms):
+            if self._dev is not None:
+                L.bridges_shapes_free(self._dev)
+            arr = (abi.Shape * len(self.geoms))(*[g.to_struct() for g in self.geoms])
+            dev = C.c_void_p()
+            abi.check(L.bridges_shapes_upload(arr, len(self.geoms), C.byref(dev)), "bridges_shapes_upload")
+            self._dev, self._dev_count = dev, len(self.geoms)
+        return self._dev
+
+
+REGISTRY = ShapeRegistry()
+
+
+def device():
+    abi.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def place(frame1, geom, face, ox, oy):
+    """create_block / align_frames_2d (gym_env.py:204-216, geometry.py:39-50) for ONE placement.
+    frame1 = (cx, cz, tx, tz, nx, nz).  Returns (pose[4], verts[nv,2]) as float64 numpy arrays."""
+    L = abi.require_gpu()
+    dev = device()
+    sid = REGISTRY.id_of(geom)
+    tab = REGISTRY.device_table()
+    f1 = torch.tensor([list(frame1)], dtype=torch.float64, device=dev)
+    sh = torch.tensor([sid], dtype=torch.int32, device=dev)
+    fc = torch.tensor([int(face)], dtype=torch.int32, device=dev)
+    oxs = torch.tensor([float(ox)], dtype=torch.float64, device=dev)
+    oys = torch.tensor([float(oy)], dtype=torch.float64, device=dev)
+    pose = torch.empty((1, 4), dtype=torch.float64, device=dev)
+    verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
+    abi.check(L.bridges_place(tab, 1, _ptr(f1), _ptr(sh), _ptr(fc), _ptr(oxs), _ptr(oys), _ptr(pose), _ptr(verts),
+                              _stream()), "bridges_place")
+    return pose[0].cpu().numpy(), verts[0, :len(geom.verts)].cpu().numpy()
+
+
+def raster_bits(blocks, xlim, ylim):
+    """One bit raster per posed block: int64 [n,64] on the device (rendering.py:105-113 per block)."""
+    L = abi.require_gpu()
+    dev = device()
+    n = len(blocks)
+    if n == 0:
+        return torch.zeros((0, 64), dtype=torch.int64, device=dev)
+    verts = np.zeros((n, 6, 2))
+    ids = np.zeros(n, dtype=np.int32)
+    for i, b in enumerate(blocks):
+        verts[i, :len(b.verts_2d)] = b.verts_2d
+        ids[i] = REGISTRY.id_of(b.geometry)
+    tab = REGISTRY.device_table()
+    v = torch.tensor(verts, dtype=torch.float64, device=dev)
+    s = torch.tensor(ids, dtype=torch.int32, device=dev)
+    gx = torch.tensor(np.linspace(xlim[0], xlim[1], 64), dtype=torch.float64, device=dev)
+    gy = torch.tensor(np.linspace(ylim[1], ylim[0], 64), dtype=torch.float64, device=dev)
+    bits = torch.empty((n, 64), dtype=torch.int64, device=dev)
+    abi.check(L.bridges_raster(tab, n, _ptr(v), _ptr(s), _ptr(gx), _ptr(gy), _ptr(bits), None, _stream()),
+              "bridges_raster")
+    return bits
+
+
+def bits_or(bits):
+    L = abi.require_gpu()
+    dev = bits.device
+    out = torch.zeros(64, dtype=torch.int64, device=dev)
+    if bits.shape[0] == 0:
+        return out
+    off = torch.tensor([0, bits.shape[0]], dtype=torch.int32, device=dev)
+    abi.check(L.bridges_bits_or(1, _ptr(off), _ptr(bits), _ptr(out), _stream()), "bridges_bits_or")
+    return out
+
+
+def bits_to_f32(bits):
+    """[n,64] int64 -> [n,64,64] float32 {0,1}."""
+    L = abi.require_gpu()
+    bits = bits.reshape(-1, 64).contiguous()
+    img = torch.empty((bits.shape[0], 64, 64), dtype=torch.float32, device=bits.device)
+    if bits.shape[0]:
+        abi.check(L.bridges_bits_to_f32(bits.shape[0], _ptr(bits), _ptr(img), _stream()), "bridges_bits_to_f32")
+    return img
+
+
+def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
+    """is_stable_rbe (stability.py:49-71) of ONE assembly.  Returns (stable: bool, info: dict)."""
+    L = abi.require_gpu()
+    dev = device()
+    K = abi.MAX_BLOCKS
+    n = len(blocks)
+    if n > K:
+        raise abi.BridgesHipError(f"{n} blocks > BRIDGES_MAX_BLOCKS ({K})")
+    pose = np.zeros((1, K, 4))
+    verts = np.zeros((1, K, 6, 2))
+    ids = np.zeros((1, K), dtype=np.int32)
+    mask = 0
+    for i, b in enumerate(blocks):
+        pose[0, i] = b.pose
+        verts[0, i, :len(b.verts_2d)] = b.verts_2d
+        ids[0, i] = REGISTRY.id_of(b.geometry)
+        if i in fixed:
+            mask |= 1 << i
+    tab = REGISTRY.device_table()
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
+    ws_stride = 9 * abi.MAX_INTERFACES + (3 * K + 1) * (4 * abi.MAX_INTERFACES + 2)
+    ws = torch.empty((1, ws_stride), dtype=torch.float64, device=dev)
+    stable = torch.zeros(1, dtype=torch.uint8, device=dev)
+    info = torch.zeros((1, 8), dtype=torch.float64, device=dev)
+    # keep every argument tensor alive until the call returned (a temporary's storage would be recycled at once)
+    a_pose, a_verts, a_ids = t(pose, torch.float64), t(verts, torch.float64), t(ids, torch.int32)
+    a_n, a_mask = t([n], torch.int32), t([mask], torch.int32)
+    abi.check(L.bridges_stability(tab, 1, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
+                                  float(mu), float(density), float(floor_half_width), float(floor_depth),
+                                  _ptr(stable), _ptr(info), _ptr(ws), ws_stride, _stream()), "bridges_stability")
+    inf = info[0].cpu().numpy()
+    if inf[3] != 0:
+        return None, dict(error="lp", objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
+    return bool(stable.item()), dict(objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
+
+
+def create_block(target_block, target_face, geom, face, ox, oy):
+    """AssemblyGym.create_block on the device.  target_block = None for the floor, else an object with
+    ``verts_2d`` / ``geometry``.  Returns (pose[4], verts[nv,2], frames[nv,6]) float64 numpy."""
+    L = abi.require_gpu()
+    dev = device()
+    sid = REGISTRY.id_of(geom)
+    tsid = REGISTRY.id_of(target_block.geometry) if target_block is not None else sid
+    tab = REGISTRY.device_table()
+    tv = np.zeros((1, 6, 2))
+    if target_block is not None:
+        tv[0, :len(target_block.verts_2d)] = target_block.verts_2d
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
+    pose = torch.empty((1, 4), dtype=torch.float64, device=dev)
+    verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
+    frames = torch.empty((1, 6, 6), dtype=torch.float64, device=dev)
+    sh = t([sid], torch.int32)
+    a_tv, a_ts = t(tv, torch.float64), t([tsid], torch.int32)
+    a_tf = t([int(target_face) if target_block is not None else -1], torch.int32)
+    a_face, a_ox, a_oy = t([int(face)], torch.int32), t([float(ox)], torch.float64), t([float(oy)], torch.float64)
+    abi.check(L.bridges_create_block(tab, 1, _ptr(a_tv), _ptr(a_ts), _ptr(a_tf), _ptr(sh), _ptr(a_face), _ptr(a_ox),
+                                     _ptr(a_oy), _ptr(pose), _ptr(verts), None, _stream()), "bridges_create_block")
+    abi.check(L.bridges_face_frames(tab, 1, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
+    nv = len(geom.verts)
+    return pose[0].cpu().numpy(), verts[0, :nv].cpu().numpy(), frames[0, :nv].cpu().numpy()
+
+
+def pose_block(geom, pose4):
+    """Block.__init__ on the device: world vertices and face frames of a shape posed by (x, z, cos, sin)."""
+    L = abi.require_gpu()
+    dev = device()
+    sid = REGISTRY.id_of(geom)
+    tab = REGISTRY.device_table()
+    sh = torch.tensor([sid], dtype=torch.int32, device=dev)
+    p = torch.tensor([list(pose4)], dtype=torch.float64, device=dev)
+    verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
+    frames = torch.empty((1, 6, 6), dtype=torch.float64, device=dev)
+    abi.check(L.bridges_pose_block(tab, 1, _ptr(sh), _ptr(p), _ptr(verts), _stream()), "bridges_pose_block")
+    abi.check(L.bridges_face_frames(tab, 1, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
+    nv = len(geom.verts)
+    return verts[0, :nv].cpu().numpy(), frames[0, :nv].cpu().numpy()

@@ -241,6 +241,38 @@ int bridges_place(const bridges_shape* shapes_dev, int32_t n, const double* fram
     return BRIDGES_OK;
 }
 
+int bridges_create_block(const bridges_shape* shapes_dev, int32_t n, const double* target_verts,
+                         const int32_t* target_shape, const int32_t* target_face, const int32_t* shape_id,
+                         const int32_t* face, const double* ox, const double* oy, double* pose, double* verts,
+                         double* target_frame_out, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_create_block");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_create_block, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shapes_dev, n,
+                       target_verts, target_shape, target_face, shape_id, face, ox, oy, pose, verts, target_frame_out);
+    LAUNCH_CHECK("k_create_block");
+    return BRIDGES_OK;
+}
+
+int bridges_pose_block(const bridges_shape* shapes_dev, int32_t n, const int32_t* shape_id, const double* pose,
+                       double* verts, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_pose_block");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_pose_block, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shapes_dev, n, shape_id,
+                       pose, verts);
+    LAUNCH_CHECK("k_pose_block");
+    return BRIDGES_OK;
+}
+
+int bridges_face_frames(const bridges_shape* shapes_dev, int32_t n, const int32_t* shape_id, const double* verts,
+                        double* frames, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_face_frames");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_face_frames, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shapes_dev, n, shape_id,
+                       verts, frames);
+    LAUNCH_CHECK("k_face_frames");
+    return BRIDGES_OK;
+}
+
 static int grid_for_waves(int64_t n_items) {
     int64_t blocks = (n_items + 3) / 4;
     if (blocks > 2048) blocks = 2048;

@@ -31,6 +31,80 @@ __global__ void k_place(const bridges_shape* shapes, int n, const double* frame1
     }
 }
 
+// K1 as AssemblyGym.create_block states it (gym_env.py:204-216): the target frame is the floor (target_face < 0,
+// assembly_env.py:339-340) or face `target_face` of a posed block given by its world vertices.
+__global__ void k_create_block(const bridges_shape* shapes, int n, const double* target_verts,
+                               const int32_t* target_shape, const int32_t* target_face, const int32_t* shape_id,
+                               const int32_t* face, const double* ox, const double* oy, double* pose, double* verts,
+                               double* frame_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Frame2 f1;
+    if (target_face[i] < 0) {
+        f1.cx = 0.0; f1.cz = 0.0; f1.tx = 1.0; f1.tz = 0.0; f1.nx = 0.0; f1.nz = 1.0;
+    } else {
+        const bridges_shape& st = shapes[target_shape[i]];
+        const double* v = target_verts + (size_t)i * MAXV * 2;
+        const int tf = target_face[i];
+        f1 = edge_frame(v[2 * st.fa[tf]], v[2 * st.fa[tf] + 1], v[2 * st.fb[tf]], v[2 * st.fb[tf] + 1]);
+    }
+    if (frame_out) {
+        double* fo = frame_out + 6 * i;
+        fo[0] = f1.cx; fo[1] = f1.cz; fo[2] = f1.tx; fo[3] = f1.tz; fo[4] = f1.nx; fo[5] = f1.nz;
+    }
+    const bridges_shape& s = shapes[shape_id[i]];
+    int f = face[i];
+    double px, pz, c, sn;
+    align_place(f1, s.fcx[f], s.fcz[f], s.fnx[f], s.fnz[f], ox[i], oy[i], px, pz, c, sn);
+    pose[4 * i + 0] = px; pose[4 * i + 1] = pz; pose[4 * i + 2] = c; pose[4 * i + 3] = sn;
+    for (int k = 0; k < MAXV; ++k) {
+        double wx = 0.0, wz = 0.0;
+        if (k < s.nv) {
+            double rx, rz;
+            rot2(s.vx[k], s.vz[k], c, sn, rx, rz);
+            wx = px + rx; wz = pz + rz;
+        }
+        verts[(size_t)i * MAXV * 2 + 2 * k] = wx;
+        verts[(size_t)i * MAXV * 2 + 2 * k + 1] = wz;
+    }
+}
+
+// Pose a shape directly: world vertices = pos + R(c,s) * local vertices (Block.__init__, assembly_env.py:146-153).
+__global__ void k_pose_block(const bridges_shape* shapes, int n, const int32_t* shape_id, const double* pose, double* verts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bridges_shape& s = shapes[shape_id[i]];
+    const double px = pose[4 * i], pz = pose[4 * i + 1], c = pose[4 * i + 2], sn = pose[4 * i + 3];
+    for (int k = 0; k < MAXV; ++k) {
+        double wx = 0.0, wz = 0.0;
+        if (k < s.nv) {
+            double rx, rz;
+            rot2(s.vx[k], s.vz[k], c, sn, rx, rz);
+            wx = px + rx; wz = pz + rz;
+        }
+        verts[(size_t)i * MAXV * 2 + 2 * k] = wx;
+        verts[(size_t)i * MAXV * 2 + 2 * k + 1] = wz;
+    }
+}
+
+// World face frames of posed blocks: [n,6,6] (centre.xz, tangent.xz, normal.xz) -- Shape.get_face_frame_2d on a
+// Block (assembly_env.py:118-124).
+__global__ void k_face_frames(const bridges_shape* shapes, int n, const int32_t* shape_id, const double* verts, double* frames) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bridges_shape& s = shapes[shape_id[i]];
+    const double* v = verts + (size_t)i * MAXV * 2;
+    for (int f = 0; f < MAXV; ++f) {
+        double* o = frames + ((size_t)i * MAXV + f) * 6;
+        if (f < s.nv) {
+            Frame2 fr = edge_frame(v[2 * s.fa[f]], v[2 * s.fa[f] + 1], v[2 * s.fb[f]], v[2 * s.fb[f] + 1]);
+            o[0] = fr.cx; o[1] = fr.cz; o[2] = fr.tx; o[3] = fr.tz; o[4] = fr.nx; o[5] = fr.nz;
+        } else {
+            for (int k = 0; k < 6; ++k) o[k] = 0.0;
+        }
+    }
+}
+
 // K4: one wave per posed outline (world vertices in shape-vertex order).
 __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* shapes, int n, const double* verts,
                                                         const int32_t* shape_id, const double* gx, const double* gy,
@@ -61,8 +135,7 @@ __global__ __launch_bounds__(256) void k_bits_to_f32(int n, const uint64_t* bits
         write_f32_image(img + (size_t)it * IMG * IMG, bits[(size_t)it * IMG + lane], lane);
 }
 
-// K2+K3: is_stable_rbe on independent assemblies; fixed blocks must be a suffix of the block list
-// (the reference only ever freezes the last block, gym_env.py:235-240); other masks are rejected (info[3]=2).
+// K2+K3: is_stable_rbe on independent assemblies; fixed_mask bit b = block b is_static.
 __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes, int n, int K, const double* pose_all,
                                                     const double* verts_all, const int32_t* shape_all,
                                                     const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
@@ -85,9 +158,7 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     double* tab_ws = ws + 9 * MAXIF;
     const int64_t tab_cap = ws_stride - 9 * MAXIF;
     const uint32_t fm = fixed_mask[e];
-    int n_free = nb;
-    while (n_free > 0 && ((fm >> (n_free - 1)) & 1u)) --n_free;
-    bool bad_mask = (fm & ((n_free >= 32) ? 0xffffffffu : ((1u << n_free) - 1u))) != 0u;
+    const bool bad_mask = false;
     const long long t0 = clock64();
     stage_faces(F, 0, 1 + nb * MAXV, verts, shape_id, shapes, floor_hw, lane);
     __syncthreads();
@@ -101,7 +172,7 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     double w = 0.0;
     int piv = 0;
     const long long t1 = clock64();
-    bool st = rbe_stable(tab, tab_ws, tab_cap, S, n_if, if_body, if_geom, n_free,
+    bool st = rbe_stable(tab, tab_ws, tab_cap, S, n_if, if_body, if_geom, nb, fm,
                          pose, shape_id, shapes, mu, density, lane, &w, &piv, &err);
     if (lane == 0) {
         stable[e] = (uint8_t)(st && !bad_mask);

@@ -126,9 +126,9 @@ __device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int3
 // the simplex from stalling.
 template <typename TP>
 __device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const int32_t* if_body,
-                                const double* if_geom, int n_free, const double* pose /*[K,4]*/,
-                                const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
-                                int lane) {
+                                const double* if_geom, const int* row_of /*LDS [K]*/, int n_blocks,
+                                const double* pose /*[K,4]*/, const int32_t* shape_id, const bridges_shape* shapes,
+                                double mu, double density, int lane) {
     int cells = (m + 1) * stride;
     for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
     __syncthreads();
@@ -142,7 +142,8 @@ __device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const 
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             int body = if_body[2 * k + (side == 0 ? 1 : 0)];   // side 0: body B (+), side 1: body A (-)
-            if (body >= 0 && body < n_free) {
+            const int r = body >= 0 ? row_of[body] : -1;
+            if (r >= 0) {
                 double sgx = side == 0 ? gx : -gx;
                 double sgz = side == 0 ? gz : -gz;
                 const bridges_shape& sh = shapes[shape_id[body]];
@@ -150,17 +151,17 @@ __device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const 
                 double rgx, rgz;
                 rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
                 double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
-                int r = 3 * body;
                 T[(r + 0) * stride + j] = sgx;
                 T[(r + 1) * stride + j] = sgz;
                 T[(r + 2) * stride + j] = rx * sgz - rz * sgx;
             }
         }
     }
-    for (int i = lane; i < m; i += WAVE) {
-        double rhs = (i % 3 == 1) ? density * shapes[shape_id[i / 3]].volume : 0.0;
-        T[i * stride + n] = rhs + LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-    }
+    for (int i = lane; i < m; i += WAVE)
+        T[i * stride + n] = LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    __syncthreads();
+    for (int b = lane; b < n_blocks; b += WAVE)
+        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + n] += density * shapes[shape_id[b]].volume;
     __syncthreads();
     for (int q = lane; q <= n; q += WAVE) {
         double s = 0.0;
@@ -174,6 +175,7 @@ struct LpScratch {                 // LDS scratch of one wave's simplex
     double col[WAVE];              // entering column (row i in slot i, cost entry in slot m)
     double rowr[LP_MAX_COLS + 2];  // normalised pivot row
     int basis[WAVE];
+    int row_of[MAXK];              // first tableau row of block b, or -1 if the block is fixed (is_static)
 };
 
 // Ordering point between the lanes of the ONE wave that owns a tableau.  LDS operations of a wave execute in
@@ -331,27 +333,34 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S,
     return w;
 }
 
-// Stability of one assembly variant.  n_free = number of leading free blocks.
+// Stability of one assembly variant.  fixed_mask bit b = block b is_static (fixed).
 __device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
-                                  const int32_t* if_body, const double* if_geom, int n_free,
+                                  const int32_t* if_body, const double* if_geom, int n_blocks, uint32_t fixed_mask,
                                   const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
                                   double mu, double density, int lane, double* w_out, int* pivots_out,
                                   bool* error) {
     *w_out = 0.0;
     *pivots_out = 0;
+    const uint32_t all = n_blocks >= 32 ? 0xffffffffu : ((1u << n_blocks) - 1u);
+    const uint32_t free_mask = all & ~fixed_mask;
+    const int n_free = __popc(free_mask);
     if (n_if == 0) return n_free == 0;                 // stability.py:53-56
     if (n_free == 0) return true;
+    __syncthreads();
+    if (lane < MAXK)
+        S.row_of[lane] = ((free_mask >> lane) & 1u) ? 3 * __popc(free_mask & ((1u << lane) - 1u)) : -1;
+    __syncthreads();
     const int m = 3 * n_free, n = 4 * n_if;
     int stride = n + 1;
     if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
     const int64_t cells = (int64_t)(m + 1) * stride;
     double w;
     if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
-        lp_build(tab_lds, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
+        lp_build(tab_lds, stride, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
         w = lp_phase1<true>(tab_lds, stride, m, n, S, lane, pivots_out, error);
     } else {
         if (cells > ws_cap) { *error = true; return false; }
-        lp_build(tab_ws, stride, m, n, n_if, if_body, if_geom, n_free, pose, shape_id, shapes, mu, density, lane);
+        lp_build(tab_ws, stride, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
         w = lp_phase1<false>(tab_ws, stride, m, n, S, lane, pivots_out, error);
     }
     *w_out = w;
@@ -366,12 +375,12 @@ __device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap,
                                 int lane, bool* st_frozen, bool* st_free, bool* error) {
     double w;
     int piv;
-    *st_free = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu,
-                          density, lane, &w, &piv, error);
+    *st_free = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, 0u, pose, shape_id, shapes,
+                          mu, density, lane, &w, &piv, error);
     __syncthreads();
     if (*st_free) { *st_frozen = true; return; }
-    *st_frozen = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks - 1, pose, shape_id, shapes,
-                            mu, density, lane, &w, &piv, error);
+    *st_frozen = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, 1u << (n_blocks - 1), pose,
+                            shape_id, shapes, mu, density, lane, &w, &piv, error);
     __syncthreads();
 }
 

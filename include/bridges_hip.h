@@ -165,6 +165,18 @@ int bridges_env_refresh(bridges_env* env, void* stream);
 int bridges_place(const bridges_shape* shapes_dev, int32_t n, const double* frame1, const int32_t* shape_id,
                   const int32_t* face, const double* ox, const double* oy, double* pose, double* verts,
                   void* stream);
+/* K1 as AssemblyGym.create_block (gym_env.py:204-216): target = floor (target_face[i] < 0) or face target_face[i]
+ * of a posed block (target_verts [n,6,2], target_shape [n]).  target_frame_out [n,6] may be NULL. */
+int bridges_create_block(const bridges_shape* shapes_dev, int32_t n, const double* target_verts,
+                         const int32_t* target_shape, const int32_t* target_face, const int32_t* shape_id,
+                         const int32_t* face, const double* ox, const double* oy, double* pose, double* verts,
+                         double* target_frame_out, void* stream);
+/* Block.__init__ (assembly_env.py:146-153): world vertices of shapes posed by (x, z, cos, sin). */
+int bridges_pose_block(const bridges_shape* shapes_dev, int32_t n, const int32_t* shape_id, const double* pose,
+                       double* verts, void* stream);
+/* Shape.get_face_frame_2d on posed blocks (assembly_env.py:118-124): frames [n,6,6] = centre.xz, x-axis.xz, normal.xz. */
+int bridges_face_frames(const bridges_shape* shapes_dev, int32_t n, const int32_t* shape_id, const double* verts,
+                        double* frames, void* stream);
 /* K4: render_blocks_2d (rendering.py:105-113) of n posed outlines, one image each.
  * verts [n,6,2] world vertices in shape-vertex order, shape_id [n], grid_x/grid_y [64] DEVICE
  * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */
@@ -176,7 +188,7 @@ int bridges_bits_or(int32_t n_groups, const int32_t* group_offset, const uint64_
 int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream);
 /* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
  * padded block lists.  verts [n,K,6,2], shape_id [n,K], n_blocks [n], fixed_mask [n] (bit b = block b
- * is_static; must be a suffix of the block list, as the reference only freezes the last block)
+ * is_static)
  * -> stable [n] u8, info [n,8] f64 (phase-1 objective, n_interfaces, pivots, error, shader cycles spent in
  *    interface detection, shader cycles spent in the LP, 0, 0).
  * lp_ws: [n, lp_ws_stride] doubles, lp_ws_stride >= 9*MAX_INTERFACES + (3K+1)*(4*MAX_INTERFACES+2). */
