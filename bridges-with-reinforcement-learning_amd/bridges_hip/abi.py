@@ -140,7 +140,7 @@ def lib():
         "bridges_bits_or": [i32, vp, vp, vp, vp],
         "bridges_bits_to_f32": [i32, vp, vp, vp],
         "bridges_stability": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp, vp, vp, i64, vp],
-        "bridges_soft_update": [vp, vp, i64, f32, vp],
+        "bridges_soft_update": [vp, vp, i64, f32, f32, vp],
         "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
     }
     for name, argtypes in sigs.items():

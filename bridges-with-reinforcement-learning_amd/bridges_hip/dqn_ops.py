@@ -1,0 +1,73 @@
+"""Host wrappers of the fused DQN ops (K7): TD / successor-feature target construction and Polyak soft update."""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def td_target(seg_offset, next_q, lin_reward, done, gamma, next_sf=None, action_raster=None):
+    """Target construction of train_policy_net (successor_dqn.py:197-213, 222, 230) in one kernel.
+
+    seg_offset int32 [B+1]: rows [seg_offset[i], seg_offset[i+1]) of next_q / next_sf belong to transition i.
+    next_q f32 [R]; next_sf f32 [R, D] view (row stride may exceed D, e.g. psi[:, 0] of a [R,2,64,64] tensor);
+    action_raster f32 [B, D]; lin_reward f32 [B]; done uint8/bool [B].
+    Returns (q_target [B], sf_target [B, D] or None, argmax_row int32 [B])."""
+    L = abi.require_gpu()
+    B = seg_offset.numel() - 1
+    dev = next_q.device
+    assert next_q.is_contiguous() and next_q.dtype == torch.float32
+    seg_offset = seg_offset.to(device=dev, dtype=torch.int32).contiguous()
+    lin_reward = lin_reward.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+    done_u8 = done.to(device=dev).to(torch.uint8).contiguous()
+    q_target = torch.empty(B, dtype=torch.float32, device=dev)
+    argmax_row = torch.empty(B, dtype=torch.int32, device=dev)
+    sf_dim, sf_target, stride = 0, None, 0
+    if next_sf is not None:
+        D = next_sf[0].numel()
+        stride = next_sf.stride(0)
+        assert next_sf.dtype == torch.float32 and next_sf[0].is_contiguous()
+        action_raster = action_raster.to(torch.float32).reshape(B, D).contiguous()
+        sf_target = torch.empty((B, D), dtype=torch.float32, device=dev)
+        sf_dim = D
+    abi.check(L.bridges_td_target(B, _ptr(seg_offset), _ptr(next_q), _ptr(next_sf), stride, _ptr(action_raster),
+                                  _ptr(lin_reward), _ptr(done_u8), float(gamma), sf_dim, _ptr(q_target), _ptr(sf_target),
+                                  _ptr(argmax_row), _stream()), "bridges_td_target")
+    return q_target, sf_target, argmax_row
+
+
+def soft_update_(target, policy, tau):
+    """target <- policy * tau + target * (1 - tau) in place (successor_dqn.py:280-288); float32 contiguous tensors."""
+    L = abi.require_gpu()
+    assert target.dtype == torch.float32 and policy.dtype == torch.float32
+    assert target.is_contiguous() and policy.is_contiguous() and target.numel() == policy.numel()
+    abi.check(L.bridges_soft_update(_ptr(target), _ptr(policy), target.numel(), float(tau), float(1.0 - tau), _stream()),
+              "bridges_soft_update")
+    return target
+
+
+class FlatParameters:
+    """All parameters and float buffers of a module re-pointed into ONE contiguous float32 device buffer, so the
+    Polyak update of a 6.4 M-parameter SuccessorMLP is a single launch instead of one per state_dict key."""
+
+    def __init__(self, module):
+        tensors = [p for p in module.parameters()] + [b for b in module.buffers() if b.dtype == torch.float32]
+        offsets, n = [], 0
+        for t in tensors:
+            offsets.append(n)
+            n += (t.numel() + 3) // 4 * 4                  # keep every tensor 16-byte aligned
+        dev = tensors[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        for t, off in zip(tensors, offsets):
+            view = self.flat[off:off + t.numel()].view_as(t)
+            view.copy_(t.data)
+            t.data = view
+        self.module = module

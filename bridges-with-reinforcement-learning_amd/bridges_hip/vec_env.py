@@ -243,6 +243,51 @@ class VecAssemblyGym:
         abi.check(self.L.bridges_env_timing_end(self._env, C.byref(ms), C.byref(n)), "bridges_env_timing_end")
         return ms.value, n.value
 
+    def refresh(self):
+        """Recompute the candidate set (enumerate, rasterise, mask) after the host edited the state arrays."""
+        abi.check(self.L.bridges_env_refresh(self._env, _stream()), "bridges_env_refresh")
+
+    def load_states(self, n_blocks, blk_shape, blk_pose, blk_occ):
+        """Overwrite the state of every env with caller-supplied block lists (replay re-rasterisation): world
+        vertices, the state raster and the candidate set are rebuilt by the HIP operators."""
+        E, K = self.E, self.K
+        self.buf["n_blocks"].copy_(n_blocks)
+        self.buf["blk_shape"].copy_(blk_shape)
+        self.buf["blk_pose"].copy_(blk_pose)
+        self.buf["blk_occ"].copy_(blk_occ)
+        self.buf["needs_reset"].zero_()
+        self.buf["n_if"].zero_()                      # interfaces are only needed by step(); replay states never step
+        flat_shape = self.buf["blk_shape"].reshape(E * K)
+        abi.check(self.L.bridges_pose_block(self.table.ptr, E * K, _ptr(flat_shape), _ptr(self.buf["blk_pose"]),
+                                            _ptr(self.buf["blk_verts"]), _stream()), "bridges_pose_block")
+        bits = torch.empty((E * K, 64), dtype=torch.int64, device=self.device)
+        abi.check(self.L.bridges_raster(self.table.ptr, E * K, _ptr(self.buf["blk_verts"]), _ptr(flat_shape),
+                                        _ptr(self.grid_x_dev), _ptr(self.grid_y_dev), _ptr(bits), None, _stream()),
+                  "bridges_raster")
+        start = torch.arange(E, dtype=torch.int32, device=self.device) * K
+        ranges = torch.stack([start, start + self.buf["n_blocks"]], dim=1).contiguous()
+        abi.check(self.L.bridges_bits_or(E, _ptr(ranges), _ptr(bits), _ptr(self.buf["state_bits"]), _stream()),
+                  "bridges_bits_or")
+        self._keep = (bits, ranges, flat_shape)       # alive until the stream has consumed them
+        # candidate counts of the loaded states, then the usual refresh
+        nfree = torch.zeros(E, dtype=torch.int32, device=self.device)
+        nv = torch.tensor([g.num_faces_2d for g in self.table_geoms], dtype=torch.int32, device=self.device)
+        kidx = torch.arange(K, device=self.device)[None, :]
+        live = kidx < self.buf["n_blocks"][:, None]
+        faces = nv[self.buf["blk_shape"].long()]
+        occ = self.buf["blk_occ"].to(torch.int32)
+        popc = sum(((occ >> f) & 1) for f in range(abi.MAX_VERTS))
+        nfree = ((faces - popc) * live).sum(dim=1).to(torch.int32)
+        n_cand = len(self.groups) * (len(self.x_discr_ground) + nfree * len(self.offset_values))
+        self.buf["n_cand"].copy_(torch.clamp(n_cand, max=self.a_max).to(torch.int32))
+        self.refresh()
+
+    def valid_rows(self):
+        """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed."""
+        total = self.total_candidates()
+        idx = torch.nonzero(self.buf["cand_mask"][:total]).squeeze(1)
+        return idx, self.buf["cand_env"][idx].long()
+
     # ------------------------------------------------------------------ views
     def flags(self):
         f = self.buf["step_flags"]

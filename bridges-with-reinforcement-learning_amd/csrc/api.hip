@@ -290,10 +290,10 @@ int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* ver
     return BRIDGES_OK;
 }
 
-int bridges_bits_or(int32_t n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out, void* stream) {
+int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream) {
     if (n_groups < 0) return fail_arg("bridges_bits_or");
     if (n_groups == 0) return BRIDGES_OK;
-    hipLaunchKernelGGL(k_bits_or, dim3(n_groups), dim3(WAVE), 0, (hipStream_t)stream, n_groups, group_offset, bits, out);
+    hipLaunchKernelGGL(k_bits_or, dim3(n_groups), dim3(WAVE), 0, (hipStream_t)stream, n_groups, ranges, bits, out);
     LAUNCH_CHECK("k_bits_or");
     return BRIDGES_OK;
 }
@@ -321,14 +321,14 @@ int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, con
     return BRIDGES_OK;
 }
 
-int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, void* stream) {
+int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, float one_minus_tau, void* stream) {
     if (n < 0) return fail_arg("bridges_soft_update");
     if (n == 0) return BRIDGES_OK;
     if ((((uintptr_t)target) | ((uintptr_t)policy)) & 15) return fail_arg("soft_update pointers must be 16-byte aligned");
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_soft_update, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, target, policy, n, tau);
+    hipLaunchKernelGGL(k_soft_update, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, target, policy, n, tau, one_minus_tau);
     LAUNCH_CHECK("k_soft_update");
     return BRIDGES_OK;
 }

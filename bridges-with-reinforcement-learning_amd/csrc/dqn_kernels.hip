@@ -6,8 +6,7 @@ namespace bridges {
 // update_target_net (successor_dqn.py:280-288): target = policy * tau + target * (1 - tau), f32, 16 B per lane.
 // The two products are rounded separately, as torch does (no FMA: -ffp-contract=off).
 __global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ target, const float* __restrict__ policy,
-                                                     int64_t n, float tau) {
-    const float omt = 1.f - tau;
+                                                     int64_t n, float tau, float omt) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float4* t4 = reinterpret_cast<float4*>(target);

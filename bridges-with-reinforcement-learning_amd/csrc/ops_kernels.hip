@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* sha
     }
 }
 
-__global__ void k_bits_or(int n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out) {
+__global__ void k_bits_or(int n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out) {
     int g = blockIdx.x, lane = threadIdx.x;
     uint64_t acc = 0ull;
-    for (int i = group_offset[g]; i < group_offset[g + 1]; ++i) acc |= bits[(size_t)i * IMG + lane];
+    for (int i = ranges[2 * g]; i < ranges[2 * g + 1]; ++i) acc |= bits[(size_t)i * IMG + lane];
     out[(size_t)g * IMG + lane] = acc;
 }
 

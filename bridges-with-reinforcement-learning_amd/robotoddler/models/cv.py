@@ -1,0 +1,143 @@
+"""Q-networks of the successor-feature DQN (robotoddler/models/cv.py:5-271 of the reference).
+
+Same module / parameter names (state_dicts are interchangeable) and the same forward contract
+``net(block_f, binary_f, action_f, reward_f, obstacle_f) -> (q, succ_block_f, succ_binary_f)``.
+ConvNet implements the 5-argument forward the training loop calls (reference cv.py:67-73, commented out at HEAD,
+where only the 2-argument form used by Policy.SFStability is live); both forms are supported here.
+The networks stay in PyTorch-ROCm (MIOpen / hipBLASLt); only the target construction and the soft update around
+them are hand-written HIP (bridges_td_target, bridges_soft_update).
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+
+def _conv_pair(cin, cout):
+    return [nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.ReLU(),
+            nn.Conv2d(cout, cout, kernel_size=3, padding=1), nn.ReLU()]
+
+
+class ConvBlock(nn.Module):
+    """conv3x3-relu-conv3x3-relu-maxpool2 (cv.py:5-17)."""
+
+    def __init__(self, in_c, out_c):
+        super().__init__()
+        self.layers = nn.Sequential(*_conv_pair(in_c, out_c), nn.MaxPool2d((2, 2)))
+
+    def forward(self, inputs):
+        return self.layers(inputs)
+
+
+class MLP(nn.Module):
+    """Linear-ReLU stack with a linear head (cv.py:20-38)."""
+
+    def __init__(self, in_d, out_d, hidden_dim=None):
+        super().__init__()
+        dims = [in_d] + list(hidden_dim if hidden_dim is not None else [64])
+        mods = []
+        for a, b in zip(dims[:-1], dims[1:]):
+            mods += [nn.Linear(a, b), nn.ReLU()]
+        mods.append(nn.Linear(dims[-1], out_d))
+        self.layers = nn.Sequential(*mods)
+
+    def forward(self, inputs):
+        return self.layers(inputs)
+
+
+class ConvNet(nn.Module):
+    """Four ConvBlocks (16/32/64/128) + MLP head -> q-value and binary successor features (cv.py:41-73)."""
+
+    def __init__(self, in_channels=4, img_size=(512, 512), num_features=6):
+        super().__init__()
+        self.layers = nn.Sequential(ConvBlock(in_channels, 16), ConvBlock(16, 32), ConvBlock(32, 64), ConvBlock(64, 128))
+        self.bottleneck_size = 128 * (img_size[0] // 16) * (img_size[1] // 16)
+        self.num_features = num_features
+        self.mlp = MLP(self.bottleneck_size + num_features, 2 * num_features + 1)
+
+    def forward(self, block_features, *rest):
+        if len(rest) == 1:                                   # (block, action): Policy.SFStability (cv.py:61-65)
+            x = torch.cat([block_features, rest[0]], dim=1)
+            return self.mlp(self.layers(x).reshape(-1, self.bottleneck_size))
+        binary_features, action_features, reward_features, obstacle_features = rest          # cv.py:67-73
+        x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1)
+        x = self.layers(x).reshape(-1, self.bottleneck_size)
+        x = self.mlp(torch.cat([x, binary_features], dim=1))
+        q_values = x[:, 0]
+        succ_binary_features = x[:, 1:].reshape(-1, 2, binary_features.shape[1])
+        return q_values, None, succ_binary_features
+
+
+class SuccessorMLP(nn.Module):
+    """MLP with a bottleneck predicting successor images/features; q = sum(softmax(psi)[:,1] * reward map)
+    (cv.py:76-105)."""
+
+    def __init__(self, in_channels=4, img_size=(512, 512), num_features=6, hidden_dims=None):
+        super().__init__()
+        self.img_size = img_size
+        px = img_size[0] * img_size[1]
+        self.mlp = MLP(in_channels * px + num_features, 2 * px + 2 * num_features,
+                       hidden_dims if hidden_dims is not None else [128, 64, 128])
+
+    def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
+        n = block_features.shape[0]
+        x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1).reshape(n, -1)
+        x = self.mlp(torch.cat([x, binary_features], dim=1))
+        img_dim = 2 * self.img_size[0] * self.img_size[1]
+        succ_block_features = x[:, :img_dim].reshape(-1, 2, *self.img_size)
+        succ_binary_features = x[:, img_dim:].reshape(-1, 2, binary_features.shape[1])
+        q_values = torch.sum(succ_block_features.softmax(dim=1)[:, 1] * reward_features.squeeze(1), dim=(-1, -2))
+        return q_values, succ_block_features, succ_binary_features
+
+
+class UNet(nn.Module):
+    """Three-level U-Net on the 4 stacked rasters (cv.py:138-254; the deeper levels are disabled there too)."""
+
+    def __init__(self, n_class):
+        super().__init__()
+        self.n_class = n_class
+        self.e11 = nn.Conv2d(4, 16, kernel_size=3, padding=1)
+        self.e12 = nn.Conv2d(16, 16, kernel_size=3, padding=1)
+        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.e21 = nn.Conv2d(16, 32, kernel_size=3, padding=1)
+        self.e22 = nn.Conv2d(32, 32, kernel_size=3, padding=1)
+        self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.e31 = nn.Conv2d(32, 64, kernel_size=3, padding=1)
+        self.e32 = nn.Conv2d(64, 64, kernel_size=3, padding=1)
+        self.upconv3 = nn.ConvTranspose2d(64, 32, kernel_size=2, stride=2)
+        self.d31 = nn.Conv2d(64, 32, kernel_size=3, padding=1)
+        self.d32 = nn.Conv2d(32, 32, kernel_size=3, padding=1)
+        self.upconv4 = nn.ConvTranspose2d(32, 16, kernel_size=2, stride=2)
+        self.d41 = nn.Conv2d(32, 16, kernel_size=3, padding=1)
+        self.d42 = nn.Conv2d(16, 16, kernel_size=3, padding=1)
+        self.outconv = nn.Conv2d(16, n_class, kernel_size=1)
+
+    def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
+        x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1)
+        s1 = F.relu(self.e12(F.relu(self.e11(x))))
+        s2 = F.relu(self.e22(F.relu(self.e21(self.pool1(s1)))))
+        b = F.relu(self.e32(F.relu(self.e31(self.pool2(s2)))))
+        u = torch.cat([self.upconv3(b), s2], dim=1)
+        u = F.relu(self.d32(F.relu(self.d31(u))))
+        u = torch.cat([self.upconv4(u), s1], dim=1)
+        u = F.relu(self.d42(F.relu(self.d41(u))))
+        out = self.outconv(u)
+        if self.n_class == 2:
+            out = out.softmax(dim=1)[:, 1]
+        return out
+
+
+class Policy(nn.Module):
+    """U-Net successor image + ConvNet stability head (cv.py:257-271):
+    q = sum(psi * w) * (1 - exp(-10 s)) - exp(-10 s)."""
+
+    def __init__(self):
+        super().__init__()
+        self.SFImage = UNet(1)
+        self.SFStability = ConvNet(in_channels=2, img_size=(64, 64), num_features=0)
+
+    def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
+        succ_block_features = self.SFImage(block_features, binary_features, action_features, reward_features, obstacle_features)
+        stability = torch.sigmoid(self.SFStability(block_features, action_features))
+        gate = torch.exp(-10 * stability.squeeze())
+        q_values = torch.sum(succ_block_features[:, 0] * reward_features.squeeze(1), dim=(-1, -2)) * (1 - gate) - gate
+        return q_values, succ_block_features, stability

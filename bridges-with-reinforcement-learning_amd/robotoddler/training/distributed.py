@@ -1,0 +1,49 @@
+"""Multi-GPU plumbing of the vectorised DQN loop: one process per GPU, environments sharded by rank (no halo, no
+data-path collective in the simulator), ONE all-gather per lock-step that replicates the new transition records
+into every rank's replay ring (RCCL over xGMI on the GPU box: backend 'nccl'; 'gloo' for the CPU tests).
+
+Records are fixed-size float64 rows (records.RECORD_WIDTH), padded per rank to the per-rank env count so a single
+``all_gather_into_tensor`` suffices; the payload is tiny (E x 872 B per rank), i.e. latency-bound, not per-link
+bandwidth-bound."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = dict(device_id=device) if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def all_gather_records(rec, valid):
+    """rec [E, W] float64, valid [E] bool -> the valid records of every rank, rank-major ([N, W]).
+    Every rank gets the same rows in the same order, so the replicated replay rings stay identical."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rec[valid]
+    world = dist.get_world_size()
+    E, W = rec.shape
+    payload = torch.cat([rec, valid.to(rec.dtype).unsqueeze(1)], dim=1).contiguous()     # validity travels in-band
+    out = torch.empty((world * E, W + 1), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, payload)
+    keep = out[:, W] > 0.5
+    return out[keep][:, :W]
+
+
+def broadcast_module(module, src=0):
+    """Re-synchronise replicated parameters (float atomics in backward can let replicas drift by ulps)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flat = getattr(module, "_flat_params", None)
+        if flat is not None:
+            dist.broadcast(flat.flat, src)
+        else:
+            for t in module.state_dict().values():
+                dist.broadcast(t, src)

@@ -1,0 +1,377 @@
+"""Successor-feature DQN with the reference's CLI surface (robotoddler/training/successor_dqn.py of the reference).
+
+Two ways to run:
+
+* ``--num_envs 1`` (default): the reference's single-environment loop -- rollout_episode / train_policy_net /
+  update_target_net with the same signatures and Transition layout -- on the assembly_gym drop-in (every
+  placement, stability solve and raster is a HIP operator call).
+* ``--num_envs N`` (N > 1): N environments in lock-step on the GPU (VecAssemblyGym) with a device replay buffer
+  of compact transition records that are re-rasterised when sampled (robotoddler/training/vec_dqn.py).
+
+Flags are the reference's (successor_dqn.py:573-596) plus ``--tower_height`` (README / BASELINE.json name for
+``bridge_setup(num_stories=N)``; absent from the reference's argparse at HEAD), ``--num_envs``, ``--shapes``.
+There is no CPU path: ``--device cpu`` is rejected.
+"""
+import argparse
+import os
+import random
+import sys
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from assembly_gym.envs.assembly_env import AssemblyEnv, Block, Shape                      # noqa: E402
+from assembly_gym.envs.gym_env import (AssemblyGym, bridge_setup, horizontal_bridge_setup,  # noqa: E402
+                                       sparse_reward)
+from assembly_gym.utils.rendering import render_blocks_2d_bits                            # noqa: E402
+from bridges_hip import dqn_ops, ops                                                      # noqa: E402
+from robotoddler.models.cv import ConvNet, Policy, SuccessorMLP                           # noqa: E402
+from robotoddler.utils.actions import filter_actions, generate_actions                    # noqa: E402
+from robotoddler.utils.replay_memory import ReplayBuffer                                  # noqa: E402
+from robotoddler.utils.utils import convolve_with_gaussian, init_weights, parse_img_size  # noqa: E402
+
+Transition = namedtuple('Transition',
+                        ('block_features', 'binary_features', 'action', 'action_features', 'reward', 'lin_reward',
+                         'done', 'reward_features', 'obstacle_features', 'next_block_features',
+                         'next_binary_features', 'next_available_actions', 'next_actions_features',
+                         'next_reward_features', 'next_obstacle_features', 'td_error'))
+
+
+def _check_img(img_size):
+    if tuple(img_size) != (64, 64):
+        raise NotImplementedError("the HIP rasteriser renders 64x64 images")
+
+
+# ---- feature extraction (successor_dqn.py:47-94) ---------------------------------------------------------------
+def get_state_features(observation, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
+    _check_img(img_size)
+    binary = [observation['stable'], observation['collision'], observation['collision_block'],
+              observation['collision_obstacle'], observation['collision_floor'], observation['collision_boundary']]
+    image = ops.bits_to_f32(render_blocks_2d_bits(observation['blocks'], xlim, ylim))      # [1,64,64] f32
+    return image.to(device), torch.tensor(binary, dtype=torch.float32, device=image.device).to(device)
+
+
+def get_task_features(obs, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
+    _check_img(img_size)
+    cube = Shape(urdf_file='shapes/cube06.urdf')
+    target_blocks = [Block(shape=cube, position=target) for target in obs['targets']]
+    reward = ops.bits_to_f32(render_blocks_2d_bits(target_blocks, xlim, ylim))[0]
+    reward = convolve_with_gaussian(reward, 101, 16)                                      # successor_dqn.py:80-82
+    obstacle = ops.bits_to_f32(render_blocks_2d_bits(obs['obstacle_blocks'], xlim, ylim))
+    return reward.unsqueeze(0).to(device), obstacle.to(device)
+
+
+def get_action_features(env, actions, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
+    _check_img(img_size)
+    blocks = [env.create_block(action) for action in actions]
+    return ops.bits_to_f32(ops.raster_bits(blocks, xlim, ylim)).unsqueeze(1).to(device)   # [A,1,64,64]
+
+
+# ---- policies (successor_dqn.py:98-132) -------------------------------------------------------------------------
+class EpsilonGreedy:
+    """epsilon-greedy with count-based exploration: explore = the action whose raster overlaps least with the
+    rasters already tried at this episode step."""
+
+    def __init__(self, eps_start=0.5, eps_end=0.05, gamma=0.99, episode=0, max_steps=10, device=torch.device('cpu')):
+        self.epsilon = (eps_start - eps_end) * (gamma ** episode) + eps_end
+        self.eps_start, self.eps_end, self.gamma = eps_start, eps_end, gamma
+        self.max_steps, self.device = max_steps, device
+        self.step_images = [torch.zeros(64, 64, device=device) for _ in range(max_steps)]
+
+    def step(self):
+        self.epsilon = (self.epsilon - self.eps_end) * self.gamma + self.eps_end
+        return self
+
+    def __call__(self, q_values, step_index, action_features, *args, **kwargs):
+        if random.random() > self.epsilon:
+            return torch.argmax(q_values).item()
+        if step_index >= len(self.step_images):            # the reference indexes past max_steps=10 (latent IndexError)
+            self.step_images += [torch.zeros(64, 64, device=self.device) for _ in range(step_index + 1 - len(self.step_images))]
+        feats = action_features.squeeze(1).to(self.device)
+        join = torch.sum(self.step_images[step_index] * feats, dim=(-1, -2))
+        sel = torch.argmin(join).item()
+        self.step_images[step_index] += feats[sel]
+        return sel
+
+
+# ---- training (successor_dqn.py:157-288) ------------------------------------------------------------------------
+def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, loss_fct='mse_q_values', scheduler=None,
+                     n_steps=10, batch_size=16, verbose=False, device='cuda'):
+    if len(replay_buffer) < batch_size:
+        return
+    loss_fct = loss_fct.split('+')
+    policy_net.train()
+    target_net.eval()
+    mse = torch.nn.MSELoss()
+    losses = []
+    for _ in range(n_steps):
+        transitions, batch = replay_buffer.sample(batch_size=batch_size, stack_tensors=True, device=device)
+        q_values, succ_block_features, succ_binary_features = policy_net(
+            batch.block_features, batch.binary_features, batch.action_features, batch.reward_features,
+            batch.obstacle_features)
+        with torch.no_grad():
+            next_q, next_sf, _next_bin = target_net(
+                batch.next_block_features, batch.next_binary_features, batch.next_actions_features,
+                batch.next_reward_features, batch.next_obstacle_features)
+            num_actions = [max(1, len(a)) for a in batch.next_available_actions]
+            seg = torch.tensor(np.cumsum([0] + num_actions), dtype=torch.int32, device=next_q.device)
+            done = torch.tensor(batch.done, dtype=torch.bool, device=next_q.device)
+            use_sf = 'mse_block_features' in loss_fct
+            if use_sf and succ_block_features is None:
+                raise ValueError("No successor block features available from the chosen policy net.")
+            # fused HIP op: segmented argmax over the ragged next-action rows, done masking, a + gamma psi'.
+            # lin_reward = 0, gamma_q = 1 makes q_sel the done-masked next q of the selected action; the reward is
+            # added below with torch broadcasting, because the reference adds a [B,1] lin_reward to a [B] vector
+            # (successor_dqn.py:222 with :435) and thereby trains on a [B,B] target -- reproduced as is.
+            zeros = torch.zeros(len(num_actions), dtype=torch.float32, device=next_q.device)
+            q_sel, _, sel_rows = dqn_ops.td_target(seg, next_q.contiguous().float(), zeros, done, 1.0)
+            sf_target = None
+            if use_sf:
+                _, sf_target, _ = dqn_ops.td_target(seg, next_q.contiguous().float(), zeros, done, gamma,
+                                                    next_sf=next_sf[:, 0],
+                                                    action_raster=batch.action_features.squeeze(1))
+        loss = 0.
+        if 'mse_q_values' in loss_fct:
+            loss = loss + mse(q_values, batch.lin_reward + gamma * q_sel)
+        if use_sf:
+            loss = loss + mse(succ_block_features[:, 0], sf_target.view_as(succ_block_features[:, 0]))
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        losses.append(loss.item())
+    return losses
+
+
+def update_target_net(policy_net, target_net, tau=0.01):
+    """theta_target <- tau * theta + (1 - tau) * theta_target (successor_dqn.py:280-288) with the HIP soft-update
+    kernel: one launch when both nets were flattened (dqn_ops.FlatParameters), else one per tensor."""
+    fp, ft = getattr(policy_net, "_flat_params", None), getattr(target_net, "_flat_params", None)
+    if fp is not None and ft is not None:
+        dqn_ops.soft_update_(ft.flat, fp.flat, tau)
+        return
+    tsd, psd = target_net.state_dict(), policy_net.state_dict()
+    for key, p in psd.items():
+        t = tsd[key]
+        if t.dtype == torch.float32 and t.is_contiguous() and p.is_contiguous() and t.data_ptr() % 16 == 0 and p.data_ptr() % 16 == 0:
+            dqn_ops.soft_update_(t, p, tau)
+        else:                                             # non-float / unaligned buffers: not on the hot path
+            t.copy_(p * tau + t * (1 - tau))
+
+
+def flatten_nets(*nets):
+    for n in nets:
+        n._flat_params = dqn_ops.FlatParameters(n)
+
+
+# ---- rollout (successor_dqn.py:365-475) -------------------------------------------------------------------------
+def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_values=[0.], img_size=(64, 64),
+                    xlim=(0, 1), ylim=(0, 1), log_images=False, device=None):
+    done, transitions = False, []
+    images = [] if log_images else None
+    policy_net.eval()
+    obs, info = env.reset(**setup_fct())
+    kw = dict(img_size=img_size, device=device, xlim=xlim, ylim=ylim)
+    reward_features, obstacle_features = get_task_features(obs, **kw)
+    block_features, binary_features = get_state_features(obs, **kw)
+
+    def candidates(block_f):
+        acts = [*generate_actions(env, x_discr_ground=x_discr_ground, offset_values=offset_values)]
+        feats = get_action_features(env, acts, **kw)
+        return filter_actions(env, acts, feats, block_features=block_f, obstacle_features=obstacle_features, xlim=xlim, ylim=ylim)
+
+    available_actions, action_features = candidates(block_features)
+    num_actions = len(available_actions)
+    step_index = 0
+
+    def qnet(bf, binf, af, n):
+        with torch.no_grad():
+            return policy_net(bf.expand(n, -1, -1, -1), binf.expand(n, -1), af, reward_features.expand(n, -1, -1, -1),
+                              obstacle_features.expand(n, -1, -1, -1))
+
+    while not done:
+        q_values, succ_block_features, succ_binary_features = qnet(block_features, binary_features, action_features, num_actions)
+        sel = policy(q_values, step_index, action_features, succ_block_features, succ_binary_features)
+        sel = int(sel)
+        action = available_actions[sel]
+        selected_action_features = action_features[sel]
+        next_observation, reward, terminated, truncated, info = env.step(action)
+        done = bool(terminated or truncated)
+        frozen_stable, unfrozen_stable = env.stabilities_freezing()
+        lin_reward = torch.zeros(1, device=device).view(-1)
+        if frozen_stable:
+            lin_reward = torch.sum(selected_action_features * reward_features).view(-1) / 100
+        if unfrozen_stable:
+            lin_reward = torch.sum(selected_action_features * reward_features).view(-1)
+        next_block_features, next_binary_features = get_state_features(next_observation, **kw)
+        next_available_actions, next_action_features = candidates(next_block_features)
+        num_actions = len(next_available_actions)
+        if num_actions == 0:
+            done = True
+            next_action_features = torch.zeros([1, 1, *img_size], device=device)
+        q_value = q_values[sel].item()
+        next_q_value = 0
+        if not done:
+            next_q_value = qnet(next_block_features, next_binary_features, next_action_features, num_actions)[0].max().item()
+        td_error = abs(q_value - (reward + 0.95 * next_q_value))          # successor_dqn.py:425 (hard-coded 0.95)
+        n1 = max(1, num_actions)
+        transitions.append(Transition(
+            block_features=block_features.unsqueeze(0), binary_features=binary_features.unsqueeze(0),
+            action_features=selected_action_features.unsqueeze(0), reward_features=reward_features.unsqueeze(0),
+            obstacle_features=obstacle_features.unsqueeze(0), action=action, lin_reward=lin_reward.unsqueeze(0),
+            reward=torch.Tensor([reward]), done=done,
+            next_block_features=next_block_features.expand(n1, -1, -1, -1),
+            next_binary_features=next_binary_features.expand(n1, -1), next_actions_features=next_action_features,
+            next_reward_features=reward_features.expand(n1, -1, -1, -1),
+            next_obstacle_features=obstacle_features.expand(n1, -1, -1, -1),
+            next_available_actions=next_available_actions, td_error=td_error))
+        block_features, binary_features = next_block_features, next_binary_features
+        action_features, available_actions = next_action_features, next_available_actions
+        if log_images:
+            if succ_block_features is None:
+                raise ValueError("No successor block features available from the chosen policy net. Disable image "
+                                 "logging or use a different model.")
+            images.append(dict(succ_block_features=succ_block_features[sel][0].cpu().numpy()))
+        step_index += 1
+    return transitions, images
+
+
+def log_episode(episode, transitions, losses, gamma, context='training', policy=None, images=None, log_images=False,
+                wandb_run=None, aim_run=None, verbose=False):
+    """Episode summary (successor_dqn.py:479-567) without the matplotlib figure; aim / wandb sinks are used when the
+    caller passes live run objects."""
+    info = {
+        'reward': sum(gamma ** i * t.reward for i, t in enumerate(transitions)).item(),
+        'lin_reward': sum(gamma ** i * t.lin_reward for i, t in enumerate(transitions)).item(),
+        'avg_loss': sum(losses) / len(losses) if losses else None,
+        'num_steps': len(transitions),
+        'stable': transitions[-1].next_binary_features[0, 0].item(),
+        'collision': transitions[-1].next_binary_features[0, 1].item(),
+    }
+    if policy is not None and hasattr(policy, 'epsilon'):
+        info['epsilon'] = policy.epsilon
+    if aim_run is not None:
+        for k, v in info.items():
+            if v is not None:
+                aim_run.track(v, name=k, step=episode, context=dict(context=context))
+    if wandb_run is not None:
+        wandb_run.log(dict(episode=episode, **{k: v for k, v in info.items()}))
+    return info, None
+
+
+# ---- CLI (successor_dqn.py:570-787) -----------------------------------------------------------------------------
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--num_episodes", type=int, default=1000, help="Number of episodes for training.")
+    p.add_argument("--max_steps", type=int, default=10, help="Max steps per episode.")
+    p.add_argument("--seed", type=int, default=None, help="Random seed.")
+    p.add_argument("--num_training_steps", type=int, default=20, help="Number of training steps in each episode.")
+    p.add_argument("--learning_rate", type=float, default=0.01, help="Adam learning rate.")
+    p.add_argument("--loss_function", choices=['mse_q_values', 'mse_block_features', 'mse_q_values+mse_block_features'],
+                   default='mse_q_values', help="Loss function for training")
+    p.add_argument("--tau", type=float, default=0.01, help="Step size for updating target net.")
+    p.add_argument("--batch_size", type=int, default=32, help="Batch size.")
+    p.add_argument("--gamma", type=float, default=0.8, help="Discount factor.")
+    p.add_argument("--model", choices=['SuccessorMLP', 'ConvNet', 'UNet'], default='UNet', help="Model type.")
+    p.add_argument("--device", choices=['cpu', 'cuda'], default='cuda', help="Device to use (this build is GPU-only).")
+    p.add_argument("--image_size", type=parse_img_size, default="64x64", help="Size of image features {width}x{height}.")
+    p.add_argument("--load_checkpoint", type=str, default=None, help="Path to a checkpoint to load.")
+    p.add_argument("--save_checkpoint", type=str, default=None, help="Path to save the checkpoint.")
+    p.add_argument("--checkpoint_every", type=int, default=1000, help="")
+    p.add_argument("--evaluate_every", type=int, default=100, help="")
+    p.add_argument("--aim", action='store_true', help="Use aim logging.")
+    p.add_argument("--aim_repo", type=str, default='aim-data/', help="Path to aim repository.")
+    p.add_argument("--bridge_length", type=int, default=1, help="Length of the bridge in blocks")
+    p.add_argument("--tower_height", type=int, default=None,
+                   help="Height of the tower: bridge_setup(num_stories=N) (README / BASELINE.json flag).")
+    p.add_argument("--verbose", action='store_true', help="Verbose output.")
+    p.add_argument("--log_images", action='store_true', help="Log images.")
+    p.add_argument("--replay_buffer_capacity", type=int, default=2000, help="Replay buffer capacity.")
+    p.add_argument("--wandb", type=bool, default=False, help="Use wandb logging.")
+    p.add_argument("--num_envs", type=int, default=1, help="Environments advanced in lock-step on the GPU.")
+    p.add_argument("--shapes", choices=['trapezoid', 'hexagon', 'both'], default='trapezoid')
+    return p
+
+
+def make_setup_fct(args):
+    trap, hexa = args['shapes'] in ('trapezoid', 'both'), args['shapes'] in ('hexagon', 'both')
+    if args.get('tower_height'):
+        return lambda: bridge_setup(num_stories=args['tower_height'], trapezoid=trap, hexagon=hexa)
+    return lambda: horizontal_bridge_setup(num_obstacles=args['bridge_length'], trapezoid=trap, hexagon=hexa)
+
+
+def make_nets(args, device):
+    if args['model'] == 'SuccessorMLP':
+        mk = lambda: SuccessorMLP(img_size=args['image_size'], hidden_dims=[256, 128, 64, 128, 256])
+    elif args['model'] == 'ConvNet':
+        mk = lambda: ConvNet(img_size=args['image_size'])
+    elif args['model'] == 'UNet':
+        mk = Policy
+    else:
+        raise ValueError(f"Unknown model type {args['model']}.")
+    policy_net, target_net = mk().to(device), mk().to(device)
+    policy_net.apply(init_weights)
+    target_net.load_state_dict(policy_net.state_dict())
+    flatten_nets(policy_net, target_net)
+    return policy_net, target_net
+
+
+def main(argv=None):
+    args = vars(build_parser().parse_args(argv))
+    if args['device'] == 'cpu':
+        raise SystemExit("this build has no CPU path: the simulator and the DQN ops are HIP kernels (use --device cuda)")
+    from bridges_hip import abi
+    abi.require_gpu()
+    device = torch.device('cuda', torch.cuda.current_device())
+    if args['seed'] is not None:
+        random.seed(args['seed'])
+        np.random.seed(args['seed'])
+        torch.manual_seed(args['seed'])
+    if args['load_checkpoint']:
+        raise NotImplementedError("Loading checkpoints is not tested.")     # successor_dqn.py:655
+    if args['num_envs'] > 1:
+        from robotoddler.training.vec_dqn import run_vectorised
+        return run_vectorised(args, device)
+
+    x_discr_ground = np.linspace(-2, 0, 10)
+    offset_values = [0]
+    xlim, ylim = (-3, 7), (0., 10)
+    gamma = args['gamma']
+    policy_net, target_net = make_nets(args, device)
+    replay_buffer = ReplayBuffer(capacity=args['replay_buffer_capacity'])
+    eps_greedy = EpsilonGreedy(eps_start=0.5, gamma=0.999, eps_end=0.05, episode=0, max_steps=args['max_steps'], device=device)
+    greedy = lambda q, *a, **k: torch.argmax(q)
+    setup_fct = make_setup_fct(args)
+    env = AssemblyGym(reward_fct=sparse_reward, max_steps=args['max_steps'], restrict_2d=True,
+                      assembly_env=AssemblyEnv(render=False))
+    optimizer = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'])
+    history = []
+    roll = dict(env=env, policy_net=policy_net, setup_fct=setup_fct, x_discr_ground=x_discr_ground, xlim=xlim, ylim=ylim,
+                offset_values=offset_values, img_size=args['image_size'], device=device, log_images=False)
+    for i in range(1, args['num_episodes'] + 1):
+        transitions, images = rollout_episode(policy=eps_greedy.step(), **roll)
+        replay_buffer.push(transitions)
+        losses = train_policy_net(policy_net=policy_net, target_net=target_net, optimizer=optimizer,
+                                  loss_fct=args['loss_function'], replay_buffer=replay_buffer, gamma=gamma,
+                                  batch_size=args['batch_size'], n_steps=args['num_training_steps'], device=device)
+        update_target_net(policy_net=policy_net, target_net=target_net, tau=args['tau'])
+        log_info, _ = log_episode(episode=i, transitions=transitions, policy=eps_greedy, losses=losses, gamma=gamma)
+        history.append(log_info)
+        if args['verbose']:
+            print(f"episode {i}: {log_info}")
+        if i % args['evaluate_every'] == 0:
+            transitions, _ = rollout_episode(policy=greedy, **roll)
+            ev, _ = log_episode(episode=i, transitions=transitions, losses=None, context='evaluation', gamma=gamma)
+            if args['verbose']:
+                print(f"evaluation {i}: {ev}")
+    return history
+
+
+if __name__ == '__main__':
+    main()

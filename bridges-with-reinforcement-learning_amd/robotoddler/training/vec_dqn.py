@@ -1,0 +1,203 @@
+"""Vectorised successor-feature DQN: E environments per GPU in lock-step (VecAssemblyGym), device replay ring of
+compact records re-rasterised on sample, fused HIP target / soft-update ops, one all-gather of records per
+lock-step across ranks.
+
+Semantics follow rollout_episode / train_policy_net / update_target_net of the reference
+(robotoddler/training/successor_dqn.py:157-288, 365-475) with these batched readings:
+* epsilon-greedy draws one uniform per env; exploring envs take the candidate whose raster overlaps least with the
+  per-episode-step count images (successor_dqn.py:112-132), all envs scored against the images of the lock-step
+  start and the chosen rasters added afterwards;
+* the TD target is the elementwise  lin_reward + gamma * q'  (the single-env reference path trains on a [B,B]
+  broadcast of it because its lin_reward is [B,1]; that quirk is reproduced only in the single-env loop);
+* "done" of a transition = terminated | truncated | no next action (successor_dqn.py:393, 409-411).
+"""
+import time
+
+import numpy as np
+import torch
+
+from bridges_hip import dqn_ops
+from bridges_hip.shapes import load_urdf
+from bridges_hip.vec_env import VecAssemblyGym
+from robotoddler.training import distributed as D
+from robotoddler.training import records as R
+
+
+class VecDQN:
+    def __init__(self, policy_net, target_net, optimizer, env, replay_capacity, batch_size, gamma, tau, loss_function,
+                 seed=0, rank=0, eps_start=0.5, eps_end=0.05, eps_decay=0.999):
+        self.policy_net, self.target_net, self.opt, self.env = policy_net, target_net, optimizer, env
+        self.device = env.device
+        self.B, self.gamma, self.tau = batch_size, gamma, tau
+        self.loss_parts = loss_function.split('+')
+        self.ring = R.ReplayRing(replay_capacity, self.device)
+        # replay sampling must be identical on every rank (replicated rings) -> shared seed; exploration differs
+        self.sample_gen = torch.Generator(device=self.device).manual_seed(1234567 + seed)
+        self.explore_gen = torch.Generator(device=self.device).manual_seed(7654321 + seed * 1000 + rank)
+        self.epsilon, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
+        self.step_images = torch.zeros((env.K + 1, 64, 64), dtype=torch.float32, device=self.device)
+        # scratch env used to rebuild the candidate sets of sampled next states
+        self.replay_env = VecAssemblyGym(batch_size, env.shapes, env.obstacles, env.targets, max_steps=env.max_steps,
+                                         mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
+                                         ylim=env.ylim, x_discr_ground=env.x_discr_ground,
+                                         offset_values=env.offset_values, device=self.device, a_max=env.a_max)
+        self.mse = torch.nn.MSELoss()
+        self.episodes_done = 0
+        self.env_steps = 0
+
+    # ------------------------------------------------------------------ features of the rows a net is fed
+    def _row_features(self, env, idx, row_env, stable_flag):
+        n = idx.numel()
+        block = env.state_raster[row_env].unsqueeze(1)
+        action = env.cand_raster[idx].unsqueeze(1)
+        binary = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
+        binary[:, 0] = stable_flag[row_env].float()
+        reward = env.reward_features.unsqueeze(0).expand(n, -1, -1, -1)
+        obstacle = env.obstacle_raster.unsqueeze(0).expand(n, -1, -1, -1)
+        return block, binary, action, reward, obstacle
+
+    @staticmethod
+    def _segments(row_env, E, device):
+        counts = torch.bincount(row_env, minlength=E)
+        seg = torch.zeros(E + 1, dtype=torch.int32, device=device)
+        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return seg, counts
+
+    # ------------------------------------------------------------------ one lock-step of acting
+    @torch.no_grad()
+    def act(self, greedy=False):
+        env, E = self.env, self.env.E
+        idx, row_env = env.valid_rows()
+        fresh = env.n_blocks == 0
+        stable = torch.where(fresh, torch.ones_like(fresh), env.step_flags[:, 1].bool())
+        seg, counts = self._segments(row_env, E, self.device)
+        sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
+        if idx.numel():
+            self.policy_net.eval()
+            q, _, _ = self.policy_net(*self._row_features(env, idx, row_env, stable))
+            zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
+            nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
+            _, _, arg_q = dqn_ops.td_target(seg, q.contiguous().float(), zeros, nodone, 1.0)       # segmented argmax
+            step_of_row = env.n_blocks[row_env].long()
+            join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
+            _, _, arg_x = dqn_ops.td_target(seg, (-join).contiguous(), zeros, nodone, 1.0)          # segmented argmin
+            explore = (torch.rand(E, generator=self.explore_gen, device=self.device) <= self.epsilon) & (not greedy)
+            sel_row = torch.where(explore, arg_x.long(), arg_q.long())
+            has = counts > 0
+            sel_row = torch.where(has, sel_row, torch.zeros_like(sel_row))
+            ex = explore & has
+            if ex.any():
+                rows = sel_row[ex]
+                self.step_images.index_add_(0, step_of_row[rows], env.cand_raster[idx[rows]])
+            sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
+        else:
+            sel_compact = torch.zeros(E, dtype=torch.long, device=self.device)
+        sel_index = (sel_compact - env.cand_offset[:E].long()).clamp(min=0).to(torch.int32)
+        snap = R.snapshot(env)
+        sel_rows = (env.cand_desc[sel_compact].clone(), env.cand_pose[sel_compact].clone())
+        env.step(sel_index)
+        rec, valid = R.make_records(env, snap, sel_rows)
+        return rec, valid
+
+    # ------------------------------------------------------------------ one gradient step on a sampled batch
+    def train_step(self):
+        if len(self.ring) < self.B:
+            return None
+        rec = self.ring.sample(self.B, self.sample_gen)
+        renv, K = self.replay_env, self.replay_env.K
+        (nb, shape, pose, occ), (nnb, nshape, npose, nocc) = R.unpack_states(rec, K)
+        with torch.no_grad():
+            # state s: raster of its blocks; action raster = the placed block
+            renv.load_states(nb, shape, pose, occ)
+            block_f = renv.state_raster.clone().unsqueeze(1)
+            # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout
+            renv.load_states(nnb, nshape, npose, nocc)
+            next_state = renv.state_raster
+            action_f = (next_state - block_f.squeeze(1)).clamp_(0, 1).unsqueeze(1)       # s' minus s = the new block
+            idx, row_env = renv.valid_rows()
+            seg, counts = self._segments(row_env, self.B, self.device)
+            done = (rec[:, R.O_DONE] > 0.5) | (counts == 0)
+            use_sf = 'mse_block_features' in self.loss_parts
+            stable_n = rec[:, R.O_STABLE_N] > 0.5
+            if idx.numel():
+                self.target_net.eval()
+                nq, nsf, _ = self.target_net(*self._row_features(renv, idx, row_env, stable_n))
+                if use_sf and nsf is None:
+                    raise ValueError("No successor block features available from the chosen policy net.")
+                q_target, sf_target, _ = dqn_ops.td_target(
+                    seg, nq.contiguous().float(), rec[:, R.O_LIN].float(), done, self.gamma,
+                    next_sf=nsf[:, 0] if use_sf else None,
+                    action_raster=action_f.squeeze(1) if use_sf else None)
+            else:
+                q_target = rec[:, R.O_LIN].float()
+                sf_target = action_f.reshape(self.B, -1) if use_sf else None
+        binary = torch.zeros((self.B, 6), dtype=torch.float32, device=self.device)
+        binary[:, 0] = rec[:, R.O_STABLE_S].float()
+        self.policy_net.train()
+        q, sf, _ = self.policy_net(block_f, binary, action_f, self.env.reward_features.unsqueeze(0).expand(self.B, -1, -1, -1),
+                                   self.env.obstacle_raster.unsqueeze(0).expand(self.B, -1, -1, -1))
+        loss = 0.
+        if 'mse_q_values' in self.loss_parts:
+            loss = loss + self.mse(q, q_target)
+        if use_sf:
+            loss = loss + self.mse(sf[:, 0], sf_target.view_as(sf[:, 0]))
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return float(loss.item())
+
+    def update_target(self):
+        from robotoddler.training.successor_dqn import update_target_net
+        update_target_net(self.policy_net, self.target_net, self.tau)
+
+    # ------------------------------------------------------------------ driver
+    def lockstep(self, n_train_steps):
+        rec, valid = self.act()
+        self.env_steps += int(valid.sum().item())
+        allrec = D.all_gather_records(rec, valid)
+        self.ring.push(allrec)
+        self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())
+        losses = [l for l in (self.train_step() for _ in range(n_train_steps)) if l is not None]
+        self.update_target()
+        self.epsilon = (self.epsilon - self.eps_end) * self.eps_decay + self.eps_end
+        return losses, allrec
+
+
+def run_vectorised(args, device):
+    from robotoddler.training.successor_dqn import make_nets
+    rank, world = D.init(device=device)
+    names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[args['shapes']]
+    geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
+    if args.get('tower_height'):
+        H, N = 0.8, args['tower_height']
+        targets = [(0.5, 0, N * H + H / 2)]
+        obstacles = [(0.5, 0., i * H + H / 2) for i in range(N)]
+    else:
+        sq, n = 0.6, args['bridge_length']
+        targets = [(n * sq + 2.5 * sq, 0, sq / 2)]
+        obstacles = [(i * sq, 0, sq / 2) for i in range(1, n + 1)]
+    seed = args['seed'] or 0
+    env = VecAssemblyGym(args['num_envs'], geoms, obstacles, targets, max_steps=args['max_steps'],
+                         seed=seed * 1000003 + rank, device=device, env_id_base=rank * args['num_envs'])
+    torch.manual_seed(seed)                                    # identical initial weights on every rank
+    policy_net, target_net = make_nets(args, device)
+    opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'])
+    capacity = max(args['replay_buffer_capacity'], 4 * args['num_envs'] * world)
+    agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],
+                   args['loss_function'], seed=seed, rank=rank)
+    history, t0, it = [], time.time(), 0
+    while agent.episodes_done < args['num_episodes']:
+        losses, rec = agent.lockstep(args['num_training_steps'])
+        it += 1
+        if it % 100 == 0:
+            D.broadcast_module(policy_net)
+            D.broadcast_module(target_net)
+        info = dict(lockstep=it, episodes=agent.episodes_done, env_steps=agent.env_steps,
+                    avg_loss=float(np.mean(losses)) if losses else None,
+                    mean_reward=float(rec[:, R.O_REWARD].mean().item()) if rec.numel() else None,
+                    mean_lin_reward=float(rec[:, R.O_LIN].mean().item()) if rec.numel() else None,
+                    epsilon=agent.epsilon, steps_per_s=agent.env_steps * world / (time.time() - t0))
+        history.append(info)
+        if args['verbose'] and rank == 0:
+            print(info)
+    return history

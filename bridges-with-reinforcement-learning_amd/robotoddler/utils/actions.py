@@ -1,0 +1,40 @@
+"""generate_actions / filter_actions (robotoddler/utils/actions.py:7-82 of the reference) for the single-environment
+API.  (The vectorised path does both on the device: k_enumerate, k_raster.)"""
+import numpy as np
+import torch
+
+from assembly_gym.envs.gym_env import Action, AssemblyGym
+
+
+def generate_actions(gym: AssemblyGym, x_discr_ground, offset_values=None, max_angle_rad=2 * np.pi + 0.1,
+                     max_blocks_per_face=1, include_frozen=False, x_block_offset=None):
+    if offset_values is None:
+        offset_values = [0.]
+    if include_frozen:
+        raise NotImplementedError
+    for shape_index, shape in enumerate(gym.shapes):
+        for face in shape.target_faces_2d:
+            for offset_x in x_discr_ground:
+                yield Action(-1, 0, shape_index, face, offset_x, offset_y=0.)
+            for target_block, block in enumerate(gym.assembly_env.blocks):
+                for target_face in block.receiving_faces_2d:
+                    normal = block.get_face_frame_2d(target_face).normal
+                    if max_angle_rad is not None and np.arccos(np.clip(normal[2], -1.0, 1.0)) > max_angle_rad:
+                        continue
+                    if max_blocks_per_face and len(gym.block_graph.get((target_block, target_face), ())) >= max_blocks_per_face:
+                        continue
+                    for offset_x in offset_values:
+                        yield Action(target_block, target_face, shape_index, face, offset_x, offset_y=0.)
+
+
+def filter_actions(gym_env, available_actions, action_features, block_features, obstacle_features, xlim, ylim):
+    """Keep actions that stay in bounds and overlap neither the state nor the obstacle raster."""
+    mask = torch.zeros(len(available_actions), dtype=bool)
+    kept = []
+    for i, action in enumerate(available_actions):
+        if (not gym_env.collision_on_action(action, xlim, ylim)
+                and torch.sum(action_features[i] * block_features) == 0
+                and torch.sum(action_features[i] * obstacle_features) == 0):
+            mask[i] = True
+            kept.append(action)
+    return kept, action_features[mask.to(action_features.device)]

@@ -1,0 +1,75 @@
+"""Training utilities (robotoddler/utils/utils.py:12-115 of the reference): weight init, image-size parsing,
+checkpoint directory layout (<path>/<episode>/{policy_net,target_net,optimizer,replay_buffer}.pt + meta.json +
+'latest' symlink), Gaussian target map."""
+import argparse
+import json
+import os
+from datetime import datetime
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def init_weights(m):
+    """xavier_uniform weights, bias 0.01 for Conv2d / Linear (utils.py:12-19)."""
+    if type(m) in (nn.Conv2d, nn.Linear):
+        torch.nn.init.xavier_uniform_(m.weight)
+        m.bias.data.fill_(0.01)
+
+
+def parse_img_size(s):
+    try:
+        return tuple(map(int, s.split('x')))
+    except Exception:
+        raise argparse.ArgumentTypeError("Image size must be a tuple of integers.")
+
+
+def optimizer_to(optimizer, device):
+    for state in optimizer.state.values():
+        for k, v in state.items():
+            if isinstance(v, torch.Tensor):
+                state[k] = v.to(device)
+
+
+def save_checkpoint(path, policy_net, target_net, replay_buffer, optimizer, episode, config, aim_run=None, wandb_run=None):
+    current = os.path.join(path, str(episode))
+    os.makedirs(current, exist_ok=True)
+    torch.save(policy_net.state_dict(), os.path.join(current, 'policy_net.pt'))
+    torch.save(target_net.state_dict(), os.path.join(current, 'target_net.pt'))
+    torch.save(optimizer.state_dict(), os.path.join(current, 'optimizer.pt'))
+    replay_buffer.save(os.path.join(current, 'replay_buffer.pt'))
+    meta = dict(episode=episode, timestamp=str(datetime.now()), config=config)
+    if aim_run is not None:
+        meta['aim_hash'] = aim_run.hash
+    with open(os.path.join(current, 'meta.json'), 'w') as f:
+        json.dump(meta, f, indent=2, default=str)
+    latest = os.path.join(path, 'latest')
+    if os.path.lexists(latest):
+        os.remove(latest)
+    os.symlink(os.path.abspath(current), latest)
+
+
+def load_checkpoint(path, policy_net, target_net, replay_buffer, optimizer, devices=None):
+    if not os.path.exists(path) or not os.path.isdir(path):
+        raise FileNotFoundError(f"Path {path} does not exist or is not a directory.")
+    with open(os.path.join(path, 'meta.json')) as f:
+        meta = json.load(f)
+    devices = devices or dict()
+    policy_net.load_state_dict(torch.load(os.path.join(path, 'policy_net.pt'), map_location=devices.get('policy_net')))
+    target_net.load_state_dict(torch.load(os.path.join(path, 'target_net.pt'), map_location=devices.get('target_net')))
+    optimizer.load_state_dict(torch.load(os.path.join(path, 'optimizer.pt'), map_location=devices.get('optimizer')))
+    replay_buffer.load(os.path.join(path, 'replay_buffer.pt'))
+    return meta
+
+
+def gaussian_kernel(kernel_size, sigma):
+    coords = torch.arange(kernel_size) - kernel_size // 2
+    k = torch.exp(-(coords.float() ** 2) / (2 * sigma ** 2))
+    k = k / k.sum()
+    return k.unsqueeze(0) * k.unsqueeze(1)
+
+
+def convolve_with_gaussian(input_tensor, kernel_size, sigma):
+    kernel = gaussian_kernel(kernel_size, sigma).to(input_tensor.device)
+    return F.conv2d(input_tensor[None, None], kernel[None, None], padding=kernel_size // 2)[0, 0]

@@ -182,8 +182,8 @@ int bridges_face_frames(const bridges_shape* shapes_dev, int32_t n, const int32_
  * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */
 int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
                    const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream);
-/* OR-reduce groups of bit rasters: out[g] = OR bits[group_offset[g] .. group_offset[g+1]). */
-int bridges_bits_or(int32_t n_groups, const int32_t* group_offset, const uint64_t* bits, uint64_t* out, void* stream);
+/* OR-reduce groups of bit rasters: out[g] = OR bits[ranges[g][0] .. ranges[g][1]);  ranges int32 [n_groups,2]. */
+int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream);
 /* bit raster -> f32 image. */
 int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream);
 /* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
@@ -202,8 +202,9 @@ int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, br
 int bridges_shapes_free(bridges_shape* dev);
 
 /* --- K7: DQN ops (robotoddler/training/successor_dqn.py) --------------------- */
-/* update_target_net (successor_dqn.py:280-288): target = policy*tau + target*(1-tau). */
-int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, void* stream);
+/* update_target_net (successor_dqn.py:280-288): target = policy*tau + target*one_minus_tau, the two products and the
+ * sum rounded separately in float32 as torch evaluates it (one_minus_tau = (float)(1.0 - tau) from the host). */
+int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, float one_minus_tau, void* stream);
 /* train_policy_net target construction (successor_dqn.py:197-213, 222, 230):
  * per transition i with rows [seg_offset[i], seg_offset[i+1]) of the target net's output:
  *   j* = argmax next_q (first maximum), q_target[i] = lin_reward[i] + gamma * (done ? 0 : next_q[j*]),
