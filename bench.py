@@ -156,6 +156,14 @@ def main():
     if rank == 0:
         units = args.envs * args.steps                      # env slots processed by the timed rasteriser launches
         n_launch = max(n_launch, 1)
+        # HBM traffic per launch: measured/algorithmic ratio of the committed PMC passes (profiles/), applied to
+        # this run's launch size -- PMC counters cannot be collected inside an un-profiled bench run
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_raster.json")))
+            # counters were taken at 4096 envs in one group; scale to this run's launch size
+            traffic_ratio = pm["hbm_bytes_per_launch"] / pm["algorithmic_bytes_per_launch"]
+        except Exception:
+            traffic_ratio = None
         alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units)
         per_launch = alg / max(n_launch, 1)
         avg_ms = raster_ms / max(n_launch, 1)
@@ -190,7 +198,7 @@ def main():
                 "bound": "hbm", "kernel": "k_raster",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (traffic_ratio * per_launch) if traffic_ratio else None,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_launch,
                 "whole_step_GBps": alg / dt / 1e9,
             },

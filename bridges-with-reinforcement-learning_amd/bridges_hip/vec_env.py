@@ -332,11 +332,28 @@ class VecAssemblyGymGroups:
             self.streams.append(st)
             start += n
         self._stream_ptrs = [C.c_void_p(st.cuda_stream) for st in self.streams]
+        # one raster gate per GPU: the bandwidth-bound rasterisers of the groups run one after another, the
+        # latency-bound task kernels of the other groups run beside them
+        self._gate = C.c_void_p()
+        L = self.envs[0].L
+        abi.check(L.bridges_gate_create(C.byref(self._gate)), "bridges_gate_create")
+        if self.G > 1:
+            for env in self.envs:
+                abi.check(L.bridges_env_set_gate(env._env, self._gate), "bridges_env_set_gate")
         self.sync()
 
     def sync(self):
         for st in self.streams:
             st.synchronize()
+
+    def __del__(self):
+        try:
+            self.sync()
+            for env in self.envs:
+                env.L.bridges_env_set_gate(env._env, None)
+            self.envs[0].L.bridges_gate_destroy(self._gate)
+        except Exception:
+            pass
 
     def reset(self):
         for env, st in zip(self.envs, self.streams):

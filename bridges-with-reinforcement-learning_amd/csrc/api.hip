@@ -32,10 +32,17 @@ static int fail_arg(const char* what) {
         if (e_ != hipSuccess) return fail_hip(e_, name);         \
     } while (0)
 
+struct bridges_gate {
+    hipEvent_t last;           // completion of the most recent rasteriser launch attached to this gate (or null)
+};
+
 struct bridges_env {
+    bridges_gate* gate;
+    hipEvent_t raster_done;
     DevCtx ctx;
     TaskTable* tt_dev;
-    int raster_blocks;
+    int32_t* h_total;          // pinned: candidate count of the previous lock-step (sizes the raster / expand grids)
+    int max_blocks;            // upper bound of a useful grid
     // optional per-launch timing of the dominant kernel (k_raster) with HIP events on the launch stream
     hipEvent_t* ev_start;
     hipEvent_t* ev_stop;
@@ -106,16 +113,15 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     (void)hipGetDevice(&dev);
     env->ev_start = env->ev_stop = nullptr;
     env->ev_cap = env->ev_used = 0;
+    env->gate = nullptr;
+    env->raster_done = nullptr;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    // persistent rasteriser grid: <= 8 x 256-thread workgroups per CU, sized so a wave sees >= ~8 work items
-    {
-        long long est_items = (long long)t->n_envs * 64;
-        long long blocks = est_items / (4 * 8);
-        if (blocks > (long long)cus * 8) blocks = (long long)cus * 8;
-        if (blocks < cus) blocks = cus;
-        env->raster_blocks = (int)blocks;
-    }
+    (void)cus;
+    e = hipHostMalloc((void**)&env->h_total, sizeof(int32_t), hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipFree(env->tt_dev); delete env; return fail_hip(e, "hipHostMalloc"); }
+    *env->h_total = t->n_envs * 64;        // first guess; replaced after every scan
+    env->max_blocks = 1 << 22;
     *out = env;
     return BRIDGES_OK;
 }
@@ -134,8 +140,31 @@ static void free_events(bridges_env* env) {
 int bridges_env_destroy(bridges_env* env) {
     if (!env) return BRIDGES_OK;
     free_events(env);
+    if (env->raster_done) (void)hipEventDestroy(env->raster_done);
     (void)hipFree(env->tt_dev);
+    (void)hipHostFree(env->h_total);
     delete env;
+    return BRIDGES_OK;
+}
+
+int bridges_gate_create(bridges_gate** out) {
+    if (!out) return fail_arg("gate_create");
+    bridges_gate* g = new (std::nothrow) bridges_gate();
+    if (!g) return fail_arg("oom");
+    g->last = nullptr;
+    *out = g;
+    return BRIDGES_OK;
+}
+
+int bridges_gate_destroy(bridges_gate* gate) {
+    delete gate;
+    return BRIDGES_OK;
+}
+
+int bridges_env_set_gate(bridges_env* env, bridges_gate* gate) {
+    if (!env) return fail_arg("set_gate");
+    if (gate && !env->raster_done) HIP_TRY(hipEventCreateWithFlags(&env->raster_done, hipEventDisableTiming));
+    env->gate = gate;
     return BRIDGES_OK;
 }
 
@@ -175,11 +204,24 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     LAUNCH_CHECK("k_scan");
     hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_enumerate");
+    // grids from the previous lock-step's candidate count (+3 %); the kernels grid-stride, so a stale or low
+    // estimate costs time, never correctness.  The fresh count is copied back asynchronously for the next call.
+    long long est = (long long)(*(volatile int32_t*)env->h_total);
+    if (est < c.E) est = c.E;
+    est += est / 32 + 64;
+    HIP_TRY(hipMemcpyAsync(env->h_total, c.b.cand_offset + c.E, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    long long rblocks = (est + c.E + 3) / 4;          // one wave per image (candidates + state rasters)
+    if (rblocks > env->max_blocks) rblocks = env->max_blocks;
     const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
+    if (env->gate && env->gate->last) HIP_TRY(hipStreamWaitEvent(s, env->gate->last, 0));
     if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
-    hipLaunchKernelGGL(k_raster, dim3(env->raster_blocks), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, s, c);
     LAUNCH_CHECK("k_raster");
     if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
+    if (env->gate) {
+        HIP_TRY(hipEventRecord(env->raster_done, s));
+        env->gate->last = env->raster_done;
+    }
     hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
     LAUNCH_CHECK("k_select");
     return BRIDGES_OK;

@@ -380,7 +380,6 @@ __device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, 
         txf[f] = (X - cxf) * nxf;
     }
     uint64_t mybits = 0ull;
-    double acc = 0.0;
     for (int r = r_lo; r <= r_hi; ++r) {
         const double Y = readlane_d(gyv, r);
         bool in = true;
@@ -393,9 +392,25 @@ __device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, 
         }
         const uint64_t m = __ballot(in);
         if (lane == r) mybits = m;
-        if (s_w != nullptr && in) acc += (double)s_w[r * IMG + lane];
     }
-    if (lin) *lin = acc;
+    if (lin) {
+        // linear reward: sum of reward_map over the inside pixels; the row loads are independent of the masks, so
+        // they are issued four at a time ahead of the bit tests (L2-resident 16 KiB map)
+        double acc = 0.0;
+        for (int r0 = r_lo; r0 <= r_hi; r0 += 4) {
+            float wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = (r0 + u <= r_hi) ? s_w[(r0 + u) * IMG + lane] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u <= r_hi) {
+                    const uint64_t m = shfl_u64(mybits, r0 + u);
+                    if ((m >> lane) & 1ull) acc += (double)wv[u];
+                }
+            }
+        }
+        *lin = acc;
+    }
     return mybits;
 }
 
@@ -438,22 +453,17 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
     return mybits;
 }
 
-// Persistent rasteriser: work item i < total -> candidate i (compact index), else state raster of env i-total.
-// One wave per image; the 16 KiB reward map is staged once per workgroup in LDS.
+// Rasteriser: work item i < total -> candidate i (compact index), else the state raster of env i - total.  One
+// wave per image.  The grid is sized by the host from the previous lock-step's candidate count (kept in pinned
+// memory) so that a wave sees about one item -- short-lived waves dispatched in item order keep the HBM write
+// stream close to linear, which sustains ~14 % more bandwidth than a persistent grid (tools/store_bench.hip) -- and
+// the grid-stride loop makes any count correct.  The half-plane tests hide behind the 16 KiB of stores per image.
 __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
-    __shared__ float s_w[IMG * IMG];
-    for (int i = threadIdx.x; i < IMG * IMG / 4; i += blockDim.x)
-        reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(c.b.reward_map)[i];
-    __syncthreads();
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     const int total = c.b.cand_offset[c.E];
-    const int items = total + c.E;
-    const bridges_shape* shapes = c.tt->shapes;
-    const double X = c.tt->grid_x[lane];
-    const double gyv = c.tt->grid_y[lane];
-    const uint64_t obst = c.b.obstacle_bits[lane];
+    const int items = total + (c.b.state_raster ? c.E : 0);
     for (int itv = wave; itv < items; itv += nwaves) {
         const int it = __builtin_amdgcn_readfirstlane(itv);       // wave-uniform: metadata comes through scalar loads
         if (it < total) {
@@ -462,9 +472,12 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
             const int e = c.b.cand_rows[ci * 2 + 1];
             const int r_lo = meta & 0xff, r_hi = (meta >> 8) & 0xff, nv = (meta >> 16) & 0xff;
             const bool inb = (meta >> 24) & 1;
-            double linp;
-            const uint64_t bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, X, gyv, s_w, &linp, lane);
-            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | obst;
+            double linp = 0.0;
+            uint64_t bits = 0ull;
+            if (!(c.debug & 2))
+                bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, c.tt->grid_x[lane], c.tt->grid_y[lane],
+                                     c.b.reward_map, &linp, lane);
+            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | c.b.obstacle_bits[lane];
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
             const double lin = wave_sum_d(linp);
             c.b.cand_bits[ci * IMG + lane] = bits;
@@ -472,11 +485,45 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
                 c.b.cand_lin[ci] = (float)lin;
                 c.b.cand_mask[ci] = (uint8_t)(inb && !overlap);
             }
-            if (c.b.cand_raster) write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane);
-        } else if (c.b.state_raster) {
+            if (c.b.cand_raster && !(c.debug & 4)) write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane);
+        } else {
             const int e = it - total;
             write_f32_image(c.b.state_raster + (size_t)e * IMG * IMG, c.b.state_bits[(size_t)e * IMG + lane], lane);
         }
+    }
+}
+
+// f32 expansion of the bit rasters (what the reference surfaces: torch.Tensor(render_blocks_2d(...))).  Pure HBM
+// write stream, the dominant kernel of a lock-step.  Unit = one 1 KiB chunk (4 image rows); chunk ch belongs to
+// image ch >> 4 (candidates first, then the E state rasters) and wave w writes chunk w: consecutive waves write
+// consecutive KiB, which is the order the memory system sustains best (6.9 TB/s for this shape on MI355X, against
+// 5.0-5.7 TB/s for one-wave-per-16-KiB-image orders; tools/store_bench.hip).
+__global__ __launch_bounds__(256) void k_expand(DevCtx c) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) / WAVE;
+    const int total = c.b.cand_offset[c.E];
+    const long long cand_chunks = (long long)total * 16;
+    const long long nchunks = cand_chunks + (c.b.state_raster ? (long long)c.E * 16 : 0);
+    const int sub = lane >> 4, col4 = (lane & 15) * 4;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    for (long long ch = wave; ch < nchunks; ch += nwaves) {
+        const uint64_t* src;
+        float* dst;
+        if (ch < cand_chunks) {
+            if (!c.b.cand_raster) continue;
+            src = c.b.cand_bits + (size_t)(ch >> 4) * IMG;
+            dst = c.b.cand_raster + (size_t)ch * 256;
+        } else {
+            const long long sc = ch - cand_chunks;
+            src = c.b.state_bits + (size_t)(sc >> 4) * IMG;
+            dst = c.b.state_raster + (size_t)sc * 256;
+        }
+        const int row = (int)(ch & 15) * 4 + sub;
+        const uint64_t m = src[row];
+        const uint32_t nib = (uint32_t)(m >> col4) & 0xFu;
+        f32x4_t v = {(nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f};
+        *reinterpret_cast<f32x4_t*>(dst + lane * 4) = v;
     }
 }
 

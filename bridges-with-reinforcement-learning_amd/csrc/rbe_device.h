@@ -125,7 +125,7 @@ __device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int3
 // equilibrium systems are massively degenerate (most rhs entries are exactly 0) and the perturbation is what keeps
 // the simplex from stalling.
 template <typename TP>
-__device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const int32_t* if_body,
+__device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n_if, const int32_t* if_body,
                                 const double* if_geom, const int* row_of /*LDS [K]*/, int n_blocks,
                                 const double* pose /*[K,4]*/, const int32_t* shape_id, const bridges_shape* shapes,
                                 double mu, double density, int lane) {
@@ -163,9 +163,9 @@ __device__ inline void lp_build(TP T, int stride, int m, int n, int n_if, const 
     for (int b = lane; b < n_blocks; b += WAVE)
         if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + n] += density * shapes[shape_id[b]].volume;
     __syncthreads();
-    for (int q = lane; q <= n; q += WAVE) {
+    for (int q = lane; q <= n; q += WAVE) {          // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
         double s = 0.0;
-        for (int i = 0; i < m; ++i) s += T[i * stride + q];
+        for (int i = 0; i < m_act; ++i) s += T[i * stride + q];
         T[m * stride + q] = -s;
     }
     __syncthreads();
@@ -176,6 +176,8 @@ struct LpScratch {                 // LDS scratch of one wave's simplex
     double rowr[LP_MAX_COLS + 2];  // normalised pivot row
     int basis[WAVE];
     int row_of[MAXK];              // first tableau row of block b, or -1 if the block is fixed (is_static)
+    short rows_nz[WAVE];           // rows touched by the current pivot (entering column entry != 0)
+    short cols_nz[LP_MAX_COLS + 2];// columns touched by the current pivot (pivot row entry != 0)
 };
 
 // Ordering point between the lanes of the ONE wave that owns a tableau.  LDS operations of a wave execute in
@@ -221,20 +223,23 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // read from the cost row (the exact artificial sum is recomputed only to confirm a "feasible" exit).
 // Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
 template <bool IN_LDS, typename TP>
-__device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S, int lane, int* pivots_out,
-                                   bool* error) {
+__device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, LpScratch& S, int lane, int* pivots_out,
+                                   bool* error, bool init_basis) {
+    // m rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials (the others
+    // are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
     int* basis = S.basis;
-    for (int i = lane; i < m; i += WAVE) basis[i] = n + i;       // artificial i
-    wave_sync<IN_LDS>();
-    int pivots = 0, stall = 0;
+    if (init_basis) {
+        for (int i = lane; i < m; i += WAVE) basis[i] = (i < m_act) ? n + i : -1;
+        wave_sync<IN_LDS>();
+    }
+    int pivots = *pivots_out, stall = 0;
     bool bland = false;
     const int nchunk = (n + WAVE - 1) / WAVE;
     const int ncols = n + 1;
-    const int cells = (m + 1) * ncols;
-    double w = -T[m * stride + n];
+    double w = artificial_sum(T, stride, m_act, n, basis, lane);
     for (;;) {
         if (w <= RBE_FEAS_TOL) {                                   // confirm with the exact artificial sum
-            w = artificial_sum(T, stride, m, n, basis, lane);
+            w = artificial_sum(T, stride, m_act, n, basis, lane);
             if (w <= RBE_FEAS_TOL) break;
         }
         // ---- entering column ----
@@ -260,13 +265,13 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S,
             }
         }
         if (jin < 0) {                                             // optimal: w is the true minimum
-            w = artificial_sum(T, stride, m, n, basis, lane);
+            w = artificial_sum(T, stride, m_act, n, basis, lane);
             break;
         }
         // ---- ratio test, lanes over rows (m <= 48 < 64) ----
         double col = (lane <= m) ? T[lane * stride + jin] : 0.0;   // lane m holds the cost entry
         double ratio = 1e300;
-        if (lane < m && col > LP_TAU) {
+        if (lane < m_act && col > LP_TAU) {
             double rhs = T[lane * stride + n];
             ratio = (rhs > 0.0 ? rhs : 0.0) * fast_rcp(col);
         }
@@ -287,27 +292,44 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S,
             r = __ffsll((long long)__ballot(tie && col == cmax)) - 1;
         }
         const double ipiv = fast_rcp(readlane_d(col, r));
-        // ---- stage the entering column and the normalised pivot row ----
+        // ---- stage the entering column, the normalised pivot row and the lists of rows / columns the rank-1
+        //      update actually touches (equilibrium tableaux are sparse: typically a fraction of the cells) ----
         S.col[lane] = col;
-        for (int q = lane; q < ncols; q += WAVE) S.rowr[q] = (q == jin) ? 1.0 : T[r * stride + q] * ipiv;
+        const uint64_t rbal = __ballot(lane <= m && (col != 0.0 || lane == r));
+        if ((rbal >> lane) & 1ull) S.rows_nz[__popcll(rbal & ((1ull << lane) - 1ull))] = (short)lane;
+        const int nr = __popcll(rbal);
+        int nc = 0;
+        for (int c = 0; c * WAVE < ncols; ++c) {
+            const int q = c * WAVE + lane;
+            double v = 0.0;
+            if (q < ncols) {
+                v = (q == jin) ? 1.0 : T[r * stride + q] * ipiv;
+                S.rowr[q] = v;
+            }
+            const uint64_t cbal = __ballot(q < ncols && v != 0.0);
+            if ((cbal >> lane) & 1ull) S.cols_nz[nc + __popcll(cbal & ((1ull << lane) - 1ull))] = (short)q;
+            nc += __popcll(cbal);
+        }
         wave_sync<IN_LDS>();
-        // ---- flat elimination sweep, 4 independent cells per lane per trip (loads first, then stores: the
-        //      cells are distinct, which the compiler cannot prove, so the batching is explicit) ----
+        // ---- elimination over the touched cells only, 4 independent cells per lane per trip (loads first, then
+        //      stores: the cells are distinct, which the compiler cannot prove, so the batching is explicit) ----
         {
-            const int di = WAVE / ncols, dq = WAVE - di * ncols;
-            int i = lane / ncols, q = lane - i * ncols;
+            const int cells = nr * nc;
+            const int di = WAVE / nc, dq = WAVE - di * nc;
+            int a = lane / nc, b = lane - a * nc;
             for (int idx = lane; idx < cells; idx += 4 * WAVE) {
                 int ii[4], qq[4];
                 double tv[4], cv[4], rv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    ii[u] = i; qq[u] = q;
                     const bool ok = idx + u * WAVE < cells;
+                    const int i = ok ? S.rows_nz[a] : 0, q = ok ? S.cols_nz[b] : 0;
+                    ii[u] = i; qq[u] = q;
                     tv[u] = ok ? T[i * stride + q] : 0.0;
                     cv[u] = ok ? S.col[i] : 0.0;
                     rv[u] = ok ? S.rowr[q] : 0.0;
-                    i += di; q += dq;
-                    if (q >= ncols) { q -= ncols; ++i; }
+                    a += di; b += dq;
+                    if (b >= nc) { b -= nc; ++a; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -327,10 +349,35 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int n, LpScratch& S,
         if (wn < w - 1e-12) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
-        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m, n, basis, lane); break; }
+        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m_act, n, basis, lane); break; }
     }
     *pivots_out = pivots;
     return w;
+}
+
+// Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
+// price it into the cost row.  The tableau then continues from the basis reached so far (warm start).
+template <bool IN_LDS, typename TP>
+__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n, LpScratch& S, int lane) {
+    for (int i = m_act; i < m; ++i) {
+        const bool neg = T[i * stride + n] < 0.0;                  // uniform
+        wave_sync<IN_LDS>();
+        for (int q = lane; q <= n; q += WAVE) {
+            double v = T[i * stride + q];
+            if (neg) { v = -v; T[i * stride + q] = v; }
+            T[m * stride + q] -= v;
+        }
+        if (lane == 0) S.basis[i] = n + i;
+    }
+    wave_sync<IN_LDS>();
+}
+
+// Shared setup of a solve: row map of the free blocks, tableau placement.  Returns false on overflow.
+__device__ inline void lp_row_map(LpScratch& S, uint32_t free_mask, int lane) {
+    __syncthreads();
+    if (lane < MAXK)
+        S.row_of[lane] = ((free_mask >> lane) & 1u) ? 3 * __popc(free_mask & ((1u << lane) - 1u)) : -1;
+    __syncthreads();
 }
 
 // Stability of one assembly variant.  fixed_mask bit b = block b is_static (fixed).
@@ -346,41 +393,66 @@ __device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_ca
     const int n_free = __popc(free_mask);
     if (n_if == 0) return n_free == 0;                 // stability.py:53-56
     if (n_free == 0) return true;
-    __syncthreads();
-    if (lane < MAXK)
-        S.row_of[lane] = ((free_mask >> lane) & 1u) ? 3 * __popc(free_mask & ((1u << lane) - 1u)) : -1;
-    __syncthreads();
+    lp_row_map(S, free_mask, lane);
     const int m = 3 * n_free, n = 4 * n_if;
     int stride = n + 1;
     if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
     const int64_t cells = (int64_t)(m + 1) * stride;
     double w;
     if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
-        lp_build(tab_lds, stride, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
-        w = lp_phase1<true>(tab_lds, stride, m, n, S, lane, pivots_out, error);
+        lp_build(tab_lds, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
+        w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true);
     } else {
         if (cells > ws_cap) { *error = true; return false; }
-        lp_build(tab_ws, stride, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
-        w = lp_phase1<false>(tab_ws, stride, m, n, S, lane, pivots_out, error);
+        lp_build(tab_ws, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
+        w = lp_phase1<false>(tab_ws, stride, m, m, n, S, lane, pivots_out, error, true);
     }
     *w_out = w;
     return w <= RBE_FEAS_TOL;
 }
 
-// Both variants of gym_env.py:325-333 with one or two LPs: the unfrozen system is the frozen one plus three more
-// equilibrium rows, so "stable with nothing frozen" implies "stable with the last block frozen".
+// Both variants of gym_env.py:325-333 in ONE tableau.  Stage 1 solves "last block frozen" (the rows of the last
+// block are carried along passively); if it is infeasible so is the unfrozen system (a superset of its rows).
+// Otherwise stage 2 enforces the last block's three equilibrium rows and continues from the stage-1 basis.
+template <bool IN_LDS, typename TP>
+__device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S, int n_if, const int32_t* if_body,
+                                   const double* if_geom, int n_blocks, const double* pose, const int32_t* shape_id,
+                                   const bridges_shape* shapes, double mu, double density, int lane, bool* st_frozen,
+                                   bool* st_free, bool* error) {
+    const int m_act = m - 3;
+    lp_build(T, stride, m, m_act, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
+    int piv = 0;
+    double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, true);
+    *st_frozen = w <= RBE_FEAS_TOL;
+    if (!*st_frozen) { *st_free = false; return; }
+    lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane);
+    w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false);
+    *st_free = w <= RBE_FEAS_TOL;
+}
+
 __device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
                                 const int32_t* if_body, const double* if_geom, int n_blocks, const double* pose,
                                 const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
                                 int lane, bool* st_frozen, bool* st_free, bool* error) {
-    double w;
-    int piv;
-    *st_free = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, 0u, pose, shape_id, shapes,
-                          mu, density, lane, &w, &piv, error);
-    __syncthreads();
-    if (*st_free) { *st_frozen = true; return; }
-    *st_frozen = rbe_stable(tab_lds, tab_ws, ws_cap, S, n_if, if_body, if_geom, n_blocks, 1u << (n_blocks - 1), pose,
-                            shape_id, shapes, mu, density, lane, &w, &piv, error);
+    if (n_if == 0) {                                   // stability.py:53-56: no edges -> stable iff no free node
+        *st_frozen = n_blocks == 1;
+        *st_free = false;
+        return;
+    }
+    const uint32_t all = n_blocks >= 32 ? 0xffffffffu : ((1u << n_blocks) - 1u);
+    lp_row_map(S, all, lane);
+    const int m = 3 * n_blocks, n = 4 * n_if;
+    int stride = n + 1;
+    if ((stride & 1) == 0) stride += 1;
+    const int64_t cells = (int64_t)(m + 1) * stride;
+    if (cells <= LP_TAB_LDS) {
+        rbe_both_in<true>(tab_lds, stride, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density,
+                          lane, st_frozen, st_free, error);
+    } else {
+        if (cells > ws_cap) { *error = true; *st_frozen = false; *st_free = false; return; }
+        rbe_both_in<false>(tab_ws, stride, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density,
+                           lane, st_frozen, st_free, error);
+    }
     __syncthreads();
 }
 

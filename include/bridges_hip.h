@@ -155,6 +155,14 @@ int bridges_env_lockstep_random(bridges_env* env, void* stream);
  * the launch stream; timing_end synchronises on them and returns the summed duration. */
 int bridges_env_timing_begin(bridges_env* env, int32_t max_launches);
 int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n_launches);
+/* Raster gate: environments that share a gate (one per GPU) never run their rasterisers concurrently -- each
+ * rasteriser launch waits (hipStreamWaitEvent) for the previous one of the gate.  With several env groups on several
+ * streams this serialises the bandwidth-bound kernels while the latency-bound task kernels of the other groups run
+ * beside them.  A gate must outlive the environments attached to it. */
+typedef struct bridges_gate bridges_gate;
+int bridges_gate_create(bridges_gate** out);
+int bridges_gate_destroy(bridges_gate* gate);
+int bridges_env_set_gate(bridges_env* env, bridges_gate* gate);
 /* Candidate refresh only (used after the host edited the state). */
 int bridges_env_refresh(bridges_env* env, void* stream);
 

@@ -1,0 +1,88 @@
+// Micro-benchmark: which launch structure reaches the HBM write ceiling for 16 KiB-per-item f32 images?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void st(float* p, f32x4 v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = v;
+}
+// A: persistent, wave w takes items w, w+W, ...
+template <bool NT> __global__ __launch_bounds__(256) void kA(float* out, int items) {
+    int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
+    f32x4 z = {0.f, 0.f, 0.f, (float)lane};
+    for (int it = wave; it < items; it += W) {
+        float* img = out + (size_t)it * 4096;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st<NT>(img + r * 256 + lane * 4, z);
+    }
+}
+// B: persistent, wave w takes a contiguous chunk of items
+template <bool NT> __global__ __launch_bounds__(256) void kB(float* out, int items) {
+    int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = (gridDim.x * blockDim.x) >> 6;
+    int per = (items + W - 1) / W, lo = wave * per, hi = lo + per < items ? lo + per : items;
+    f32x4 z = {0.f, 0.f, 0.f, (float)lane};
+    for (int it = lo; it < hi; ++it) {
+        float* img = out + (size_t)it * 4096;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st<NT>(img + r * 256 + lane * 4, z);
+    }
+}
+// C: persistent, a 256-thread block shares one item (4 KiB per wave)
+template <bool NT> __global__ __launch_bounds__(256) void kC(float* out, int items) {
+    int t = threadIdx.x;
+    f32x4 z = {0.f, 0.f, 0.f, (float)t};
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        float* img = out + (size_t)it * 4096;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st<NT>(img + r * 1024 + t * 4, z);
+    }
+}
+// D: non-persistent, one wave per item
+template <bool NT> __global__ __launch_bounds__(256) void kD(float* out, int items) {
+    int lane = threadIdx.x & 63, it = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (it >= items) return;
+    f32x4 z = {0.f, 0.f, 0.f, (float)lane};
+    float* img = out + (size_t)it * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st<NT>(img + r * 256 + lane * 4, z);
+}
+// E: plain linear fill (grid-stride, 16 B per thread), the torch-fill shape
+template <bool NT> __global__ __launch_bounds__(256) void kE(float* out, int items) {
+    size_t n4 = (size_t)items * 1024, stride = (size_t)gridDim.x * blockDim.x;
+    f32x4 z = {0.f, 0.f, 0.f, 1.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st<NT>(out + i * 4, z);
+}
+template <typename F> void run(const char* name, F launch, float* buf, int items) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 10; ++i) launch();
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
+    printf("%-28s %.3f ms  %.2f TB/s\n", name, ms, (double)items * 16384 / (ms * 1e-3) / 1e12);
+}
+int main() {
+    int items = 262144;   // 4.29 GB
+    float* buf; CHECK(hipMalloc(&buf, (size_t)items * 16384));
+    for (int bpc : {4, 8, 16}) {
+        int grid = 256 * bpc;
+        printf("-- persistent grid %d blocks (%d per CU)\n", grid, bpc);
+        run("A strided items", [&] { hipLaunchKernelGGL(kA<false>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("A strided items nt", [&] { hipLaunchKernelGGL(kA<true>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("B contiguous chunks", [&] { hipLaunchKernelGGL(kB<false>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("B contiguous chunks nt", [&] { hipLaunchKernelGGL(kB<true>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("C block per item", [&] { hipLaunchKernelGGL(kC<false>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("C block per item nt", [&] { hipLaunchKernelGGL(kC<true>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("E linear fill", [&] { hipLaunchKernelGGL(kE<false>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+        run("E linear fill nt", [&] { hipLaunchKernelGGL(kE<true>, dim3(grid), dim3(256), 0, 0, buf, items); }, buf, items);
+    }
+    printf("-- non-persistent\n");
+    run("D wave per item", [&] { hipLaunchKernelGGL(kD<false>, dim3(items / 4), dim3(256), 0, 0, buf, items); }, buf, items);
+    run("D wave per item nt", [&] { hipLaunchKernelGGL(kD<true>, dim3(items / 4), dim3(256), 0, 0, buf, items); }, buf, items);
+    run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
+    return 0;
+}
