@@ -188,6 +188,7 @@ class VecAssemblyGym:
         t.mu, t.density = self.mu, self.density
         t.floor_half_width = (self.bounds[1][0] - self.bounds[0][0]) / 2.0      # assembly_env.py:290-296
         t.floor_depth = self.bounds[1][1] - self.bounds[0][1]
+        self._create_args = (float(t.floor_half_width), float(t.floor_depth))
         t.xlim[0], t.xlim[1], t.ylim[0], t.ylim[1] = *self.xlim, *self.ylim
         if len(self.targets) > abi.MAX_TARGETS:
             raise ValueError("too many targets")
@@ -281,6 +282,45 @@ class VecAssemblyGym:
         n_cand = len(self.groups) * (len(self.x_discr_ground) + nfree * len(self.offset_values))
         self.buf["n_cand"].copy_(torch.clamp(n_cand, max=self.a_max).to(torch.int32))
         self.refresh()
+
+    def candidate_stability(self, chunk=8192):
+        """is_action_stable_rbe (assembly_gym/utils/stability.py:122-130 of the reference) for EVERY valid candidate
+        of every env in one batch: the candidate block is appended to its env's assembly (the last placed block
+        stays frozen, gym_env.py:238-240) and the HIP contact + simplex kernel decides.  Returns (rows, stable):
+        compact candidate indices and a bool per row."""
+        idx, row_env = self.valid_rows()
+        n = idx.numel()
+        K16 = abi.MAX_BLOCKS
+        out = torch.zeros(n, dtype=torch.bool, device=self.device)
+        if n == 0:
+            return idx, out
+        ws_stride = 9 * abi.MAX_INTERFACES + (3 * K16 + 1) * (4 * abi.MAX_INTERFACES + 2)
+        if getattr(self, "_stab_ws", None) is None:
+            self._stab_ws = torch.empty((chunk, ws_stride), dtype=torch.float64, device=self.device)
+        for lo in range(0, n, chunk):
+            ii, ee = idx[lo:lo + chunk], row_env[lo:lo + chunk]
+            m = ii.numel()
+            nb = self.buf["n_blocks"][ee].long()
+            pose = torch.zeros((m, K16, 4), dtype=torch.float64, device=self.device)
+            verts = torch.zeros((m, K16, 6, 2), dtype=torch.float64, device=self.device)
+            shape = torch.zeros((m, K16), dtype=torch.int32, device=self.device)
+            pose[:, :self.K] = self.buf["blk_pose"][ee]
+            verts[:, :self.K] = self.buf["blk_verts"][ee]
+            shape[:, :self.K] = self.buf["blk_shape"][ee]
+            r = torch.arange(m, device=self.device)
+            pose[r, nb] = self.buf["cand_pose"][ii]
+            verts[r, nb] = self.buf["cand_verts"][ii]
+            shape[r, nb] = self.buf["cand_desc"][ii, 2]
+            nblocks = (nb + 1).to(torch.int32)
+            fixed = torch.where(nb > 0, torch.ones_like(nb) << (nb - 1).clamp(min=0), torch.zeros_like(nb)).to(torch.int32)
+            stable = torch.zeros(m, dtype=torch.uint8, device=self.device)
+            info = torch.zeros((m, 8), dtype=torch.float64, device=self.device)
+            t = self._create_args
+            abi.check(self.L.bridges_stability(self.table.ptr, m, K16, _ptr(pose), _ptr(verts), _ptr(shape), _ptr(nblocks),
+                                               _ptr(fixed), self.mu, self.density, t[0], t[1], _ptr(stable), _ptr(info),
+                                               _ptr(self._stab_ws), ws_stride, _stream()), "bridges_stability")
+            out[lo:lo + m] = stable.bool() & (info[:, 3] == 0)
+        return idx, out
 
     def valid_rows(self):
         """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed."""

@@ -33,7 +33,8 @@ from bridges_hip import dqn_ops, ops                                            
 from robotoddler.models.cv import ConvNet, Policy, SuccessorMLP                           # noqa: E402
 from robotoddler.utils.actions import filter_actions, generate_actions                    # noqa: E402
 from robotoddler.utils.replay_memory import ReplayBuffer                                  # noqa: E402
-from robotoddler.utils.utils import convolve_with_gaussian, init_weights, parse_img_size  # noqa: E402
+from robotoddler.utils.utils import (convolve_with_gaussian, init_weights, parse_img_size,   # noqa: E402
+                                     save_checkpoint)
 
 Transition = namedtuple('Transition',
                         ('block_features', 'binary_features', 'action', 'action_features', 'reward', 'lin_reward',
@@ -365,6 +366,9 @@ def main(argv=None):
         history.append(log_info)
         if args['verbose']:
             print(f"episode {i}: {log_info}")
+        if args['save_checkpoint'] and i % args['checkpoint_every'] == 0:     # utils.py:54-89 layout
+            save_checkpoint(args['save_checkpoint'], policy_net, target_net, replay_buffer, optimizer, i,
+                            {k: (str(v) if not isinstance(v, (int, float, str, bool, type(None))) else v) for k, v in args.items()})
         if i % args['evaluate_every'] == 0:
             transitions, _ = rollout_episode(policy=greedy, **roll)
             ev, _ = log_episode(episode=i, transitions=transitions, losses=None, context='evaluation', gamma=gamma)

@@ -146,6 +146,13 @@ class OracleGym:
     def stabilities_freezing(self):
         return self._rbe(len(self.blocks) - 1), self._rbe(None)
 
+    def is_action_stable(self, action):
+        """is_action_stable_rbe (assembly_gym/assembly_gym/utils/stability.py:122-130): the candidate block is appended
+        (free), boundary conditions of the existing blocks stay (the last placed block is frozen)."""
+        blocks = self.blocks + [create_block(self.shapes, self.blocks, action)]
+        fixed = set() if self.frozen is None else {self.frozen}
+        return is_stable_rbe(blocks, fixed, self.mu, self.density, self.bounds)
+
     def distance_to_targets(self):          # gym_env.py:154-161
         if not self.blocks:
             return [float("inf")] * len(self.targets)

@@ -131,3 +131,33 @@ def test_task_features_match_oracle():
     g = oracles[0].gym
     assert np.array_equal(bits_to_bool(vec.obstacle_bits.cpu().numpy()), g.obstacle_raster)
     np.testing.assert_allclose(vec.reward_map.cpu().numpy(), g.reward_map, rtol=1e-5, atol=1e-7)
+
+
+def test_candidate_stability_mask_matches_is_action_stable_rbe():
+    """stability of every valid candidate placement, batched."""
+    E, seed = 24, 7
+    vec, oracles = make_pair(dict(num_stories=2), bridge_setup, E, 10, seed, ["trapezoid"])
+    counters = [0] * E
+    checked = 0
+    for it in range(5):
+        rows, stable = vec.candidate_stability()
+        rows, stable = rows.cpu().numpy(), stable.cpu().numpy()
+        off = vec.cand_offset.cpu().numpy()
+        k = 0
+        for e, o in enumerate(oracles):
+            valid = np.flatnonzero(o.cand["mask"])
+            for a in valid:
+                assert rows[k] == off[e] + a
+                assert bool(stable[k]) == o.gym.is_action_stable(o.cand["actions"][a]), (it, e, a)
+                k += 1
+                checked += 1
+        assert k == len(rows)
+        vec.select_random()
+        for e, o in enumerate(oracles):
+            def pick(nv, e=e):
+                r = policy_draw(seed, e, counters[e]) % nv
+                counters[e] += 1
+                return r
+            o.lockstep(pick)
+        vec.step()
+    assert checked > 500
