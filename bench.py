@@ -44,34 +44,34 @@ def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4):
 # ------------------------------------------------------------------------- CPU baseline (oracle)
 def _cpu_worker(args):
     seed, env_id, seconds, tower_height, max_steps = args
-    from oracle.env import OracleGym, OracleLockstep, bridge_setup, policy_draw
-    g = OracleGym(**bridge_setup(num_stories=tower_height), max_steps=max_steps)
-    L = OracleLockstep(g)
-    ctr = [0]
-
-    def pick(nv):
-        r = policy_draw(seed, env_id, ctr[0]) % nv
-        ctr[0] += 1
-        return r
-    n = 0
+    from oracle.c_env import CEnv
+    from oracle.env import OracleGym, bridge_setup
+    ce = CEnv(OracleGym(**bridge_setup(num_stories=tower_height), max_steps=max_steps))
+    ce.enable_f32()                                  # same unit of work: f32 rasters for every raw candidate
+    ce.run(seed, env_id, 200)                        # warm-up
+    n, chunk = 0, 2000
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        n += int(L.lockstep(pick)["valid_step"])
+        n += ce.run(seed, env_id, chunk)
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(tower_height, max_steps, seconds=12.0):
-    """The oracle (numpy + HiGHS restatement of the reference path) on the host cores, one env per process."""
+def cpu_baseline(tower_height, max_steps, seconds=10.0):
+    """The plain-C restatement of the path (oracle/c, tested bit for bit against the numpy + HiGHS oracle), one
+    environment per process on every host core."""
     import multiprocessing as mp
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    from oracle import c_env
+    c_env.lib()                                      # build once before forking
+    cores = max(1, min(len(os.sched_getaffinity(0)), 256))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(0, i, seconds, tower_height, max_steps) for i in range(cores)])
     steps = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
     return dict(value=steps / wall, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} oracle processes x {seconds:.0f} s of tower_height={tower_height} "
-                       f"random-policy lock-steps ({steps} env-steps; numpy float64 + scipy HiGHS)")
+                sample=f"{cores} processes x {seconds:.0f} s of tower_height={tower_height} random-policy lock-steps "
+                       f"({steps} env-steps) with oracle/c/oracle_env.c (scalar C, -O2, float64, own simplex, "
+                       f"bit + f32 rasters); the numpy/HiGHS oracle it mirrors runs ~30 env-steps/s per core")
 
 
 # ------------------------------------------------------------------------- main

@@ -7,7 +7,9 @@ may, and there only as the checker / timed CPU baseline.
 
 It is a plain float64 restatement (numpy + scalar Python; HiGHS via
 ``scipy.optimize.linprog`` for the LP) of the reference's algorithm for the
-path SURVEY.md §8 names.  Every function cites the reference file:line it
+path SURVEY.md §8 names, plus a second, independent restatement in plain C
+(``oracle/c/oracle_env.c``: own simplex, used as the timed CPU baseline) that is
+tested bit for bit against the first.  Every function cites the reference file:line it
 follows (paths relative to ``/root/reference``).
 
 Parity status

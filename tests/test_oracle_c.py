@@ -1,0 +1,75 @@
+"""CPU: the plain-C restatement (oracle/c) against the numpy + HiGHS oracle, lock-step by lock-step: candidates,
+poses and vertices bit-exact, rasters and masks bit-exact, both stability booleans (own simplex vs HiGHS), rewards,
+termination, selected actions.  Two independent implementations of the same contract keep each other honest."""
+import numpy as np
+import pytest
+
+from oracle.c_env import CEnv, bits_from_bool
+from oracle.env import OracleGym, OracleLockstep, bridge_setup, horizontal_bridge_setup, policy_draw
+
+
+@pytest.mark.parametrize("setup,kw,max_steps,seed,n_env,n_lock", [
+    (bridge_setup, dict(num_stories=4), 15, 3, 6, 40),
+    (bridge_setup, dict(num_stories=2), 10, 5, 4, 30),
+    (horizontal_bridge_setup, dict(num_obstacles=3, trapezoid=False, hexagon=True), 15, 11, 4, 30),
+    (horizontal_bridge_setup, dict(num_obstacles=2, trapezoid=True, hexagon=True), 12, 2, 2, 25),
+])
+def test_c_oracle_equals_numpy_oracle(setup, kw, max_steps, seed, n_env, n_lock):
+    steps = 0
+    for env_id in range(n_env):
+        gym = OracleGym(**setup(**kw), max_steps=max_steps)
+        ce = CEnv(gym)
+        L = OracleLockstep(gym)
+        ctr = [0]
+
+        def pick(nv):
+            r = policy_draw(seed, env_id, ctr[0]) % nv
+            ctr[0] += 1
+            return r
+
+        def check_candidates():
+            cands, nvalid = ce.candidates()
+            c = L.cand
+            assert len(cands) == len(c["actions"])
+            assert nvalid == int(c["mask"].sum())
+            for i, cd in enumerate(cands):
+                a, b = c["actions"][i], c["blocks"][i]
+                assert (cd.tb, cd.tf, cd.sh, cd.fc, cd.ox) == (a[0], a[1], a[2], a[3], a[4])
+                assert tuple(cd.pose) == (b.pos[0], b.pos[1], b.cs[0], b.cs[1])
+                assert [tuple(v) for v in cd.verts][:len(b.verts)] == b.verts
+                assert list(cd.bits) == bits_from_bool(c["rasters"][i])
+                assert bool(cd.mask) == bool(c["mask"][i])
+                assert abs(cd.lin - c["lin_reward"][i]) <= 1e-5 * max(1.0, abs(c["lin_reward"][i]))
+            assert ce.state_bits() == bits_from_bool(c["state"])
+
+        check_candidates()
+        for it in range(n_lock):
+            o = ce.lockstep(seed, env_id)
+            ref = L.lockstep(pick)
+            assert bool(o.valid_step) == ref["valid_step"] and bool(o.no_actions) == ref["no_actions"]
+            if ref["valid_step"]:
+                steps += 1
+                assert o.action_index == ref["action_index"]
+                assert (bool(o.stable_frozen), bool(o.stable_unfrozen)) == (ref["stable_frozen"], ref["stable_unfrozen"]), (env_id, it)
+                assert (bool(o.terminated), bool(o.truncated), bool(o.done)) == (ref["terminated"], ref["truncated"], ref["done"])
+                assert o.reward == ref["reward"] and o.n_reached == ref["targets_reached"]
+                assert abs(o.lin_reward - ref["lin_reward"]) <= 1e-5 * max(1.0, abs(ref["lin_reward"]))
+            if it % 5 == 0:
+                check_candidates()
+    assert steps > n_env * n_lock * 0.8
+
+
+def test_c_oracle_f32_rasters():
+    gym = OracleGym(**bridge_setup(num_stories=2), max_steps=10)
+    ce = CEnv(gym)
+    ce.enable_f32()
+    L = OracleLockstep(gym)
+    for it in range(4):
+        ce.lockstep(1, 0)
+        cands, _ = ce.candidates()
+        imgs = ce.f32_images(len(cands) + 1)
+        for i, cd in enumerate(cands):
+            ref = np.array([[(b >> q) & 1 for q in range(64)] for b in cd.bits], dtype=np.float32)
+            assert np.array_equal(imgs[i], ref)
+        sb = ce.state_bits()
+        assert np.array_equal(imgs[len(cands)], np.array([[(b >> q) & 1 for q in range(64)] for b in sb], dtype=np.float32))
