@@ -106,11 +106,19 @@ def main():
     from bridges_hip.shapes import load_urdf
     from bridges_hip.vec_env import VecAssemblyGymGroups
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one card to rehearse the N>1 code path
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     H = 0.8                                                     # gym_env.py:46 bridge_setup(H=.8, num_stories=N)
     targets = [(0.5, 0.0, args.tower_height * H + H / 2)]
@@ -144,7 +152,7 @@ def main():
 
     env_steps = float(d["env_steps"])
     if world > 1:
-        t = torch.tensor([dt, env_steps], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, env_steps], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()

@@ -1,0 +1,86 @@
+"""GPU: size-independent properties at BASELINE.json's full size (4096 envs, tower_height=4, max_steps=15) -- the
+oracle cannot follow 4096 envs in seconds, so the checks are invariants of the domain:
+determinism, grouping independence, mask/raster consistency, conservation of counts."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+H = 0.8
+
+
+def make(E, groups=None, seed=0, f32=False, **kw):
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym, VecAssemblyGymGroups
+    args = ([load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(4)], [(0.5, 0, 4 * H + H / 2)])
+    if groups:
+        return VecAssemblyGymGroups(E, *args, groups=groups, max_steps=15, seed=seed, f32_rasters=f32, **kw)
+    return VecAssemblyGym(E, *args, max_steps=15, seed=seed, f32_rasters=f32, **kw)
+
+
+def trajectory(env, n, grouped):
+    out = []
+    for _ in range(n):
+        if grouped:
+            env.lockstep_random()
+            env.sync()
+            parts = env.envs
+        else:
+            env.select_random()
+            env.step()
+            parts = [env]
+        out.append(tuple(torch.cat([getattr(p, name).reshape(p.E, -1).cpu() for p in parts]) for name in
+                         ("step_flags", "reward", "lin_reward", "n_blocks", "n_cand", "n_valid", "state_bits")))
+    return out
+
+
+def test_full_size_determinism_and_grouping_independence():
+    E, n = 4096, 25
+    a = trajectory(make(E, seed=5), n, False)
+    b = trajectory(make(E, seed=5), n, False)
+    c = trajectory(make(E, groups=3, seed=5), n, True)
+    for sa, sb, sc in zip(a, b, c):
+        for xa, xb, xc in zip(sa, sb, sc):
+            assert torch.equal(xa, xb)          # same seed -> bit-identical run
+            assert torch.equal(xa, xc)          # env groups / streams do not change any env's trajectory
+
+
+def test_full_size_invariants():
+    E = 4096
+    env = make(E, seed=9, f32=True)
+    st0 = env.read_stats()
+    for it in range(20):
+        env.select_random()
+        sel = env.sel_index.clone()
+        off = env.cand_offset[:E].long()
+        nv_before, nc_before = env.n_valid.clone(), env.n_cand.clone()
+        picked_valid = env.cand_mask[off + sel.long()].bool() | (nv_before == 0)
+        assert bool(picked_valid.all())                                     # the policy only picks valid candidates
+        assert bool(((sel >= 0) & ((sel < nc_before) | (nv_before == 0))).all())
+        env.step()
+        fl = env.flags()
+        total = env.total_candidates()
+        assert total == int(env.n_cand.sum())                               # prefix sum closes
+        assert bool((env.cand_offset[1:] - env.cand_offset[:-1] == env.n_cand).all())
+        # frozen stability is implied by unfrozen stability; done <=> terminated | truncated; reward rule
+        assert bool((~fl["stable_unfrozen"] | fl["stable_frozen"])[fl["valid_step"]].all())
+        assert bool((fl["done"] == (fl["terminated"] | fl["truncated"]))[fl["valid_step"]].all())
+        assert bool((env.reward[fl["valid_step"] & ~fl["stable_frozen"]] == -1).all())
+        assert bool((env.lin_reward[fl["valid_step"] & ~fl["stable_frozen"]] == 0).all())
+        assert not bool(fl["lp_error"].any())
+        # a finished env is reset: no blocks, ground candidates only
+        assert bool((env.n_blocks[fl["done"]] == 0).all()) and bool((env.n_cand[fl["done"]] == 40).all())
+        # masks vs bits: a valid candidate overlaps neither the state nor the obstacles and is in bounds
+        env_of = env.cand_env[:total].long()
+        occupied = env.state_bits[env_of] | env.obstacle_bits[None, :]
+        overlap = ((env.cand_bits[:total] & occupied) != 0).any(dim=1)
+        assert bool((env.cand_mask[:total].bool() == (env.cand_inb[:total].bool() & ~overlap)).all())
+        # f32 rasters are the bit rasters
+        k = torch.randint(0, total, (64,), device=env.device)
+        bits = env.cand_bits[k]
+        expect = ((bits[:, :, None] >> torch.arange(64, device=env.device)[None, None, :]) & 1).float()
+        assert torch.equal(env.cand_raster[k], expect)
+        # the state raster is the OR of the placed blocks' rasters: popcount only grows within an episode
+    st = env.read_stats()
+    assert st["env_steps"] - st0["env_steps"] + st["reset_only"] - st0["reset_only"] == 20 * E
+    assert st["lp_errors"] == 0 and st["if_overflow"] == 0
