@@ -45,6 +45,19 @@ class VecDQN:
         self.episodes_done = 0
         self.env_steps = 0
 
+    ROW_BUCKET = 1024      # conv nets: MIOpen tunes per input shape, so row counts are padded to a few sizes
+
+    def _forward_rows(self, net, env, idx, row_env, stable_flag):
+        """net(...) over the candidate rows, with the row count padded to a multiple of ROW_BUCKET (the padding
+        repeats row 0 and is sliced off), so that the convolution shapes repeat from lock-step to lock-step."""
+        n = idx.numel()
+        pad = (-n) % self.ROW_BUCKET
+        if pad:
+            idx = torch.cat([idx, idx[:1].expand(pad)])
+            row_env = torch.cat([row_env, row_env[:1].expand(pad)])
+        q, sf, sb = net(*self._row_features(env, idx, row_env, stable_flag))
+        return q[:n], (sf[:n] if sf is not None else None), (sb[:n] if sb is not None else None)
+
     # ------------------------------------------------------------------ features of the rows a net is fed
     def _row_features(self, env, idx, row_env, stable_flag):
         n = idx.numel()
@@ -74,7 +87,7 @@ class VecDQN:
         sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
         if idx.numel():
             self.policy_net.eval()
-            q, _, _ = self.policy_net(*self._row_features(env, idx, row_env, stable))
+            q, _, _ = self._forward_rows(self.policy_net, env, idx, row_env, stable)
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
             nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
             _, _, arg_q = dqn_ops.td_target(seg, q.contiguous().float(), zeros, nodone, 1.0)       # segmented argmax
@@ -121,7 +134,7 @@ class VecDQN:
             stable_n = rec[:, R.O_STABLE_N] > 0.5
             if idx.numel():
                 self.target_net.eval()
-                nq, nsf, _ = self.target_net(*self._row_features(renv, idx, row_env, stable_n))
+                nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
                 if use_sf and nsf is None:
                     raise ValueError("No successor block features available from the chosen policy net.")
                 q_target, sf_target, _ = dqn_ops.td_target(

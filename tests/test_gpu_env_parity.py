@@ -16,11 +16,23 @@ def bits_to_bool(bits_row):
     return ((u[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
 
 
+class _ShapeSpec:
+    """A shape with the reference's optional face restrictions (gym_env.py:82-88 hard_tower_setup)."""
+
+    def __init__(self, geometry, target_faces_2d=None):
+        self.geometry = geometry
+        if target_faces_2d is not None:
+            self.target_faces_2d = target_faces_2d
+
+
 def make_pair(setup_kwargs, setup_fn, E, max_steps, seed, shapes_names, **kw):
     from bridges_hip.shapes import load_urdf
     from bridges_hip.vec_env import VecAssemblyGym
     setup = setup_fn(**setup_kwargs)
-    geoms = [load_urdf(f"shapes/{n}.urdf") for n in shapes_names]
+    geoms = []
+    for n, s in zip(shapes_names, setup["shapes"]):
+        g = load_urdf(f"shapes/{n}.urdf")
+        geoms.append(_ShapeSpec(g, list(s.target_faces_2d)) if s._target else g)
     vec = VecAssemblyGym(E, geoms, setup["obstacles"], setup["targets"], max_steps=max_steps, seed=seed, **kw)
     oracles = [OracleLockstep(OracleGym(**setup, max_steps=max_steps, **kw)) for _ in range(E)]
     return vec, oracles
@@ -161,3 +173,23 @@ def test_candidate_stability_mask_matches_is_action_stable_rbe():
             o.lockstep(pick)
         vec.step()
     assert checked > 500
+
+
+def test_mixed_shapes_high_friction_parity():
+    """trapezoid + hexagon in one task (10 candidate groups), mu = 2.0, a 4-obstacle bridge."""
+    E, seed = 24, 21
+    vec, oracles = make_pair(dict(num_obstacles=4, trapezoid=True, hexagon=True), horizontal_bridge_setup, E, 12, seed,
+                             ["trapezoid", "hexagon"], mu=2.0)
+    n = run_lockstep_parity(vec, oracles, seed, n_lock=14)
+    assert n > E * 8
+
+
+def test_restricted_target_faces_two_targets_no_step_limit_parity():
+    """hard_tower_setup: a cube that may only be attached by face 2, two targets, an obstacle, max_steps=None
+    (K = 16 block slots, 'truncated' never set)."""
+    from oracle.env import hard_tower_setup
+    E, seed = 16, 33
+    vec, oracles = make_pair({}, hard_tower_setup, E, None, seed, ["trapezoid", "cube1"])
+    assert len(vec.groups) == 5                      # 4 trapezoid faces + the cube's single target face
+    run_lockstep_parity(vec, oracles, seed, n_lock=14)
+    assert not bool(vec.flags()["truncated"].any())

@@ -1,0 +1,50 @@
+"""Training-in-the-loop throughput of the vectorised successor-DQN (reported separately from the simulator bench)."""
+import argparse, json, os, sys, time
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
+import torch
+from robotoddler.training.successor_dqn import build_parser, make_nets
+from robotoddler.training.vec_dqn import VecDQN
+from bridges_hip.shapes import load_urdf
+from bridges_hip.vec_env import VecAssemblyGym
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--tower", type=int, default=4)
+ap.add_argument("--max_steps", type=int, default=15)
+ap.add_argument("--model", default="SuccessorMLP")
+ap.add_argument("--loss", default="mse_block_features")
+ap.add_argument("--locksteps", type=int, default=20)
+ap.add_argument("--train_steps", type=int, default=25)
+ap.add_argument("--batch", type=int, default=32)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+args = vars(build_parser().parse_args(["--model", a.model, "--loss_function", a.loss, "--learning_rate", "1e-4"]))
+H = 0.8
+env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(a.tower)],
+                     [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev)
+torch.manual_seed(0)
+pol, tgt = make_nets(args, dev)
+opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
+for i in range(3):
+    agent.lockstep(a.train_steps)
+    print("warm-up lock-step", i, "done", flush=True)
+torch.cuda.synchronize(); s0 = agent.env_steps; t0 = time.perf_counter()
+t_act = t_train = 0.0
+for _ in range(a.locksteps):
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    rec, valid = agent.act()
+    agent.env_steps += int(valid.sum().item())
+    agent.ring.push(rec[valid])
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    losses = [agent.train_step() for _ in range(a.train_steps)]
+    agent.update_target()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    t_act += t2 - t1; t_train += t3 - t2
+    print("lock-step", _, round((t3 - t1) * 1e3, 1), "ms", flush=True)
+dt = time.perf_counter() - t0
+print(json.dumps(dict(config=vars(a), env_steps_per_s=(agent.env_steps - s0) / dt, ms_per_lockstep=dt / a.locksteps * 1e3,
+                      ms_act=t_act / a.locksteps * 1e3, ms_train=t_train / a.locksteps * 1e3,
+                      ms_per_train_step=t_train / a.locksteps / a.train_steps * 1e3, last_loss=losses[-1])))
