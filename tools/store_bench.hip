@@ -55,6 +55,27 @@ template <bool NT> __global__ __launch_bounds__(256) void kE(float* out, int ite
     f32x4 z = {0.f, 0.f, 0.f, 1.f};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st<NT>(out + i * 4, z);
 }
+// F: non-persistent, one wave per 16/PARTS KiB piece, pieces in linear order
+template <int PARTS> __global__ __launch_bounds__(256) void kF(float* out, long pieces) {
+    int lane = threadIdx.x & 63; long pc = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pc >= pieces) return;
+    f32x4 z = {0.f, 0.f, 0.f, (float)lane};
+    float* p = out + pc * (4096 / PARTS);
+#pragma unroll
+    for (int r = 0; r < 16 / PARTS; ++r) st<false>(p + r * 256 + lane * 4, z);
+}
+// G: like F but each wave first does a dependent load (models "metadata before the stores") and ~2 us of ALU work
+template <int PARTS> __global__ __launch_bounds__(256) void kG(float* out, long pieces, const int* meta) {
+    int lane = threadIdx.x & 63; long pc = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pc >= pieces) return;
+    int m = meta[pc & 1023];
+    double acc = lane * 0.5 + m;
+    for (int i = 0; i < 300; ++i) acc = acc * 1.0000001 + 0.5;      // ~ the half-plane tests of one image quarter
+    f32x4 z = {0.f, 0.f, (float)(acc > 1e300), (float)lane};
+    float* p = out + pc * (4096 / PARTS);
+#pragma unroll
+    for (int r = 0; r < 16 / PARTS; ++r) st<false>(p + r * 256 + lane * 4, z);
+}
 template <typename F> void run(const char* name, F launch, float* buf, int items) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -83,6 +104,14 @@ int main() {
     printf("-- non-persistent\n");
     run("D wave per item", [&] { hipLaunchKernelGGL(kD<false>, dim3(items / 4), dim3(256), 0, 0, buf, items); }, buf, items);
     run("D wave per item nt", [&] { hipLaunchKernelGGL(kD<true>, dim3(items / 4), dim3(256), 0, 0, buf, items); }, buf, items);
+    run("F wave per 8 KiB", [&] { hipLaunchKernelGGL(kF<2>, dim3(items * 2 / 4), dim3(256), 0, 0, buf, (long)items * 2); }, buf, items);
+    run("F wave per 4 KiB", [&] { hipLaunchKernelGGL(kF<4>, dim3(items * 4 / 4), dim3(256), 0, 0, buf, (long)items * 4); }, buf, items);
+    run("F wave per 2 KiB", [&] { hipLaunchKernelGGL(kF<8>, dim3(items * 8 / 4), dim3(256), 0, 0, buf, (long)items * 8); }, buf, items);
+    run("F wave per 1 KiB", [&] { hipLaunchKernelGGL(kF<16>, dim3(items * 16 / 4), dim3(256), 0, 0, buf, (long)items * 16); }, buf, items);
+    int* meta; CHECK(hipMalloc(&meta, 4096)); CHECK(hipMemset(meta, 0, 4096));
+    run("G 16 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
+    run("G 4 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<4>, dim3(items), dim3(256), 0, 0, buf, (long)items * 4, meta); }, buf, items);
+    run("G 1 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<16>, dim3(items * 4), dim3(256), 0, 0, buf, (long)items * 16, meta); }, buf, items);
     run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
     return 0;
 }
