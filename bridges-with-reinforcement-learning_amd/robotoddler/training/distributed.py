@@ -32,8 +32,12 @@ def all_gather_records(rec, valid):
     world = dist.get_world_size()
     E, W = rec.shape
     payload = torch.cat([rec, valid.to(rec.dtype).unsqueeze(1)], dim=1).contiguous()     # validity travels in-band
-    out = torch.empty((world * E, W + 1), dtype=rec.dtype, device=rec.device)
+    dev = rec.device
+    if dist.get_backend() == "gloo" and payload.is_cuda:        # rehearsal mode: gloo moves host memory
+        payload = payload.cpu()
+    out = torch.empty((world * E, W + 1), dtype=rec.dtype, device=payload.device)
     dist.all_gather_into_tensor(out, payload)
+    out = out.to(dev)
     keep = out[:, W] > 0.5
     return out[keep][:, :W]
 
@@ -42,8 +46,11 @@ def broadcast_module(module, src=0):
     """Re-synchronise replicated parameters (float atomics in backward can let replicas drift by ulps)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         flat = getattr(module, "_flat_params", None)
-        if flat is not None:
-            dist.broadcast(flat.flat, src)
-        else:
-            for t in module.state_dict().values():
+        tensors = [flat.flat] if flat is not None else list(module.state_dict().values())
+        for t in tensors:
+            if dist.get_backend() == "gloo" and t.is_cuda:
+                h = t.cpu()
+                dist.broadcast(h, src)
+                t.copy_(h)
+            else:
                 dist.broadcast(t, src)

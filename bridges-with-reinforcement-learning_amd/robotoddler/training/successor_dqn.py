@@ -329,7 +329,9 @@ def main(argv=None):
         raise SystemExit("this build has no CPU path: the simulator and the DQN ops are HIP kernels (use --device cuda)")
     from bridges_hip import abi
     abi.require_gpu()
-    device = torch.device('cuda', torch.cuda.current_device())
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
     if args['seed'] is not None:
         random.seed(args['seed'])
         np.random.seed(args['seed'])

@@ -178,7 +178,9 @@ class VecDQN:
 
 def run_vectorised(args, device):
     from robotoddler.training.successor_dqn import make_nets
-    rank, world = D.init(device=device)
+    import os
+    backend = os.environ.get("BRIDGES_DIST_BACKEND")          # 'gloo' = rehearsal with several ranks on one card
+    rank, world = D.init(backend=backend, device=device)
     names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[args['shapes']]
     geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
     if args.get('tower_height'):

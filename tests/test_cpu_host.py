@@ -153,16 +153,16 @@ w = [torch.zeros_like(lin.weight) for _ in range(world)]
 dist.all_gather(w, lin.weight.data)
 assert torch.equal(w[0], w[1])
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(%r, "ok_%%d" %% rank), "w").write("ok")
 '''
 
 
 def test_all_gather_of_records_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % (ROOT, PKG))
+    script.write_text(WORKER % (ROOT, PKG, str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), out.stdout + out.stderr
