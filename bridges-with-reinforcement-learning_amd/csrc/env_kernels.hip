@@ -65,6 +65,9 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     __shared__ LpScratch S;
     FaceLds& F = *reinterpret_cast<FaceLds*>(lds_tab);
     double* tab = lds_tab;
+    // latency-bound kernel that usually runs beside another env group's bandwidth-bound rasteriser: take the
+    // instruction arbiter's priority so the dependent pivot chain is not stretched by the co-resident store waves
+    __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
     const bridges_shape* shapes = c.tt->shapes;
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 __global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
+    __builtin_amdgcn_s_setprio(3);
     __shared__ unsigned long long red[16][6];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (t == 0) carry_s = 0;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
     __shared__ uint8_t free_b[MAXK * MAXV], free_f[MAXK * MAXV];
+    __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
     const bridges_shape* shapes = c.tt->shapes;
