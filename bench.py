@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
     ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
     args = ap.parse_args()
@@ -140,13 +141,14 @@ def main():
 
     sync()
     s0 = env.read_stats()
-    env.timing_begin(args.steps)
+    if not args.no_kernel_timing:
+        env.timing_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lockstep()
     sync()
     dt = time.perf_counter() - t0
-    raster_ms, n_launch = env.timing_end()
+    raster_ms, n_launch = (0.0, 0) if args.no_kernel_timing else env.timing_end()
     s1 = env.read_stats()
     d = {k: s1[k] - s0[k] for k in s1}
 

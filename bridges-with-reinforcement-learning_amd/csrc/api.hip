@@ -200,7 +200,7 @@ int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n
 
 static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     const DevCtx& c = env->ctx;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, c, after_step);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, c, after_step);
     LAUNCH_CHECK("k_scan");
     hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_enumerate");

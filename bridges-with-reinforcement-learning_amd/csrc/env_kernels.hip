@@ -177,17 +177,20 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 
 // ---------------------------------------------------------------------------------------------
 // exclusive prefix sum of n_cand -> cand_offset[E+1], plus the per-lock-step statistics (no atomics anywhere:
-// 4096 adds on one word cost ~50 us per kernel on this chip); single workgroup of 16 waves.
-__global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
-    __shared__ int wave_tot[16];
+// 4096 adds on one word cost ~50 us per kernel on this chip).  Single workgroup of only 4 waves: beside another env
+// group's rasteriser (28 of a CU's 32 wave slots taken) a 16-wave workgroup waited ~100 us for a CU to place it.
+#define SCAN_THREADS 256
+#define SCAN_WAVES (SCAN_THREADS / WAVE)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step) {
+    __shared__ int wave_tot[SCAN_WAVES];
     __shared__ int carry_s;
+    __shared__ unsigned long long red[SCAN_WAVES][6];
     __builtin_amdgcn_s_setprio(3);
-    __shared__ unsigned long long red[16][6];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (t == 0) carry_s = 0;
     __syncthreads();
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};   // blocks, env-steps, reset-only, lp errors, if overflow, valid
-    for (int base = 0; base < c.E; base += 1024) {
+    for (int base = 0; base < c.E; base += SCAN_THREADS) {
         const int i = base + t;
         const int v = i < c.E ? c.b.n_cand[i] : 0;
         if (i < c.E) {
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
         const int carry = carry_s;
         if (i < c.E) c.b.cand_offset[i] = carry + wbase + incl - v;
         __syncthreads();
-        if (t == 1023) carry_s = carry + wbase + incl;
+        if (t == SCAN_THREADS - 1) carry_s = carry + wbase + incl;
         __syncthreads();
     }
 #pragma unroll
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_scan(DevCtx c, int after_step) {
     __syncthreads();
     if (t == 0) {
         unsigned long long tot[6] = {0, 0, 0, 0, 0, 0};
-        for (int w = 0; w < 16; ++w)
+        for (int w = 0; w < SCAN_WAVES; ++w)
             for (int k = 0; k < 6; ++k) tot[k] += red[w][k];
         c.b.cand_offset[c.E] = carry_s;
         c.b.stats[ST_SUM_CAND] += (uint64_t)carry_s;

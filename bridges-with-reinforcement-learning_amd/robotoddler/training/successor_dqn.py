@@ -338,6 +338,19 @@ def main(argv=None):
         torch.manual_seed(args['seed'])
     if args['load_checkpoint']:
         raise NotImplementedError("Loading checkpoints is not tested.")     # successor_dqn.py:655
+    aim_run = wandb_run = None
+    if args['aim']:                                                         # successor_dqn.py:671-674
+        try:
+            import aim
+        except ImportError as e:
+            raise SystemExit("--aim was given but the 'aim' package is not installed") from e
+        aim_run = aim.Run(experiment="SuccessorQLearning", repo=args['aim_repo'])
+    if args['wandb']:
+        try:
+            import wandb
+        except ImportError as e:
+            raise SystemExit("--wandb was given but the 'wandb' package is not installed") from e
+        wandb_run = wandb.init(project="dual_arm", config=args)
     if args['num_envs'] > 1:
         from robotoddler.training.vec_dqn import run_vectorised
         return run_vectorised(args, device)
@@ -364,7 +377,8 @@ def main(argv=None):
                                   loss_fct=args['loss_function'], replay_buffer=replay_buffer, gamma=gamma,
                                   batch_size=args['batch_size'], n_steps=args['num_training_steps'], device=device)
         update_target_net(policy_net=policy_net, target_net=target_net, tau=args['tau'])
-        log_info, _ = log_episode(episode=i, transitions=transitions, policy=eps_greedy, losses=losses, gamma=gamma)
+        log_info, _ = log_episode(episode=i, transitions=transitions, policy=eps_greedy, losses=losses, gamma=gamma,
+                                  aim_run=aim_run, wandb_run=wandb_run)
         history.append(log_info)
         if args['verbose']:
             print(f"episode {i}: {log_info}")
@@ -373,7 +387,8 @@ def main(argv=None):
                             {k: (str(v) if not isinstance(v, (int, float, str, bool, type(None))) else v) for k, v in args.items()})
         if i % args['evaluate_every'] == 0:
             transitions, _ = rollout_episode(policy=greedy, **roll)
-            ev, _ = log_episode(episode=i, transitions=transitions, losses=None, context='evaluation', gamma=gamma)
+            ev, _ = log_episode(episode=i, transitions=transitions, losses=None, context='evaluation', gamma=gamma,
+                                aim_run=aim_run, wandb_run=wandb_run)
             if args['verbose']:
                 print(f"evaluation {i}: {ev}")
     return history

@@ -166,3 +166,30 @@ def test_all_gather_of_records_two_ranks_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), out.stdout + out.stderr
+
+
+def test_checkpoint_layout_matches_the_reference(tmp_path):
+    """utils.py:54-89: <path>/<episode>/{policy_net,target_net,optimizer,replay_buffer}.pt + meta.json + 'latest'."""
+    import json
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.utils.replay_memory import ReplayBuffer
+    from robotoddler.utils.utils import load_checkpoint, save_checkpoint
+    mk = lambda: SuccessorMLP(img_size=(8, 8), hidden_dims=[8])
+    pol, tgt = mk(), mk()
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    rb = ReplayBuffer(capacity=4)
+    for ep in (10, 20):
+        save_checkpoint(str(tmp_path), pol, tgt, rb, opt, ep, dict(model="SuccessorMLP"))
+    d = tmp_path / "20"
+    assert sorted(p.name for p in d.iterdir()) == ["meta.json", "optimizer.pt", "policy_net.pt", "replay_buffer.pt", "target_net.pt"]
+    assert os.path.realpath(tmp_path / "latest") == str(d)
+    meta = json.load(open(d / "meta.json"))
+    assert meta["episode"] == 20 and meta["config"] == {"model": "SuccessorMLP"} and "timestamp" in meta
+    pol2, tgt2 = mk(), mk()
+    meta2 = load_checkpoint(str(tmp_path / "latest"), pol2, tgt2, ReplayBuffer(capacity=4), torch.optim.Adam(pol2.parameters()))
+    assert meta2["episode"] == 20
+    for a, b in zip(pol.state_dict().values(), pol2.state_dict().values()):
+        assert torch.equal(a, b)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(str(tmp_path / "nope"), pol2, tgt2, rb, opt)
+
