@@ -62,7 +62,8 @@ def cpu_baseline(tower_height, max_steps, seconds=10.0):
     import multiprocessing as mp
     from oracle import c_env
     c_env.lib()                                      # build once before forking
-    cores = max(1, min(len(os.sched_getaffinity(0)), 256))
+    # a one-GPU box of this pool gives the job a 16-core share whatever the affinity mask says
+    cores = int(os.environ.get("BENCH_CPU_WORKERS", max(1, min(len(os.sched_getaffinity(0)), 16))))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(0, i, seconds, tower_height, max_steps) for i in range(cores)])
