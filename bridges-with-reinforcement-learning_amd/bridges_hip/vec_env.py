@@ -16,6 +16,7 @@ auto-resets finished envs and produces the candidate set of the new state.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -104,7 +105,7 @@ class VecAssemblyGym:
         self.x_discr_ground = [float(v) for v in x_discr_ground]
         self.offset_values = [float(v) for v in offset_values]
         self.seed = int(seed)
-        self.debug = int(debug)
+        self.debug = int(debug) | int(os.environ.get("BRIDGES_DEBUG", "0"))     # experiments only
         self.env_id_base = int(env_id_base)
         # the task's shape table = the env's shapes + cube06 for obstacles/targets (gym_env.py:277)
         self.cube06 = load_urdf("shapes/cube06.urdf")
