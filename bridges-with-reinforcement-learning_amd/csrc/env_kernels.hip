@@ -501,40 +501,6 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
     }
 }
 
-// f32 expansion of the bit rasters (what the reference surfaces: torch.Tensor(render_blocks_2d(...))).  Pure HBM
-// write stream, the dominant kernel of a lock-step.  Unit = one 1 KiB chunk (4 image rows); chunk ch belongs to
-// image ch >> 4 (candidates first, then the E state rasters) and wave w writes chunk w: consecutive waves write
-// consecutive KiB, which is the order the memory system sustains best (6.9 TB/s for this shape on MI355X, against
-// 5.0-5.7 TB/s for one-wave-per-16-KiB-image orders; tools/store_bench.hip).
-__global__ __launch_bounds__(256) void k_expand(DevCtx c) {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) / WAVE;
-    const int total = c.b.cand_offset[c.E];
-    const long long cand_chunks = (long long)total * 16;
-    const long long nchunks = cand_chunks + (c.b.state_raster ? (long long)c.E * 16 : 0);
-    const int sub = lane >> 4, col4 = (lane & 15) * 4;
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    for (long long ch = wave; ch < nchunks; ch += nwaves) {
-        const uint64_t* src;
-        float* dst;
-        if (ch < cand_chunks) {
-            if (!c.b.cand_raster) continue;
-            src = c.b.cand_bits + (size_t)(ch >> 4) * IMG;
-            dst = c.b.cand_raster + (size_t)ch * 256;
-        } else {
-            const long long sc = ch - cand_chunks;
-            src = c.b.state_bits + (size_t)(sc >> 4) * IMG;
-            dst = c.b.state_raster + (size_t)sc * 256;
-        }
-        const int row = (int)(ch & 15) * 4 + sub;
-        const uint64_t m = src[row];
-        const uint32_t nib = (uint32_t)(m >> col4) & 0xFu;
-        f32x4_t v = {(nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f};
-        *reinterpret_cast<f32x4_t*>(dst + lane * 4) = v;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // draw == 0: n_valid + no-action detection (successor_dqn.py:409-411), part of every lock-step;
 // draw == 1: the synthetic uniform-random policy over the valid candidates -> sel_index.
