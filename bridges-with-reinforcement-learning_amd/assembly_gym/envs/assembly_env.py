@@ -114,8 +114,8 @@ class Shape:
         return Frame2D(point=(c[0], 0.0, c[1]), xaxis=(t[0], 0.0, t[1]), yaxis=(0.0, 1.0, 0.0), normal=(n[0], 0.0, n[1]))
 
     def contains_2d(self, points):
-        raise NotImplementedError("use assembly_gym.utils.rendering.render_blocks_2d: the inside test runs in the "
-                                  "HIP rasteriser on the 64x64 grid")
+        """assembly_env.py:126-137 on the HIP point-in-outline kernel."""
+        return ops.contains_points(self, points)
 
 
 class Block(Shape):

@@ -139,6 +139,7 @@ def lib():
         "bridges_create_block": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_pose_block": [vp, i32, vp, vp, vp, vp],
         "bridges_face_frames": [vp, i32, vp, vp, vp, vp],
+        "bridges_contains_points": [vp, i32, vp, i32, vp, vp, vp],
         "bridges_raster": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
         "bridges_bits_or": [i32, vp, vp, vp, vp],
         "bridges_bits_to_f32": [i32, vp, vp, vp],
@@ -159,7 +160,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_stability",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",
 )
 

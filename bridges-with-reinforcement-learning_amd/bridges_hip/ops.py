@@ -197,3 +197,20 @@ def pose_block(geom, pose4):
     abi.check(L.bridges_face_frames(tab, 1, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
     nv = len(geom.verts)
     return verts[0, :nv].cpu().numpy(), frames[0, :nv].cpu().numpy()
+
+
+def contains_points(block, points):
+    """Shape.contains_2d (assembly_env.py:126-137): bool per (x, z) sample point, numpy in / numpy out."""
+    L = abi.require_gpu()
+    dev = device()
+    pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 2))
+    n = pts.shape[0]
+    sid = REGISTRY.id_of(block.geometry)
+    tab = REGISTRY.device_table()
+    v = np.zeros((6, 2))
+    v[:len(block.verts_2d)] = block.verts_2d
+    tv = torch.tensor(v, dtype=torch.float64, device=dev)
+    tp = torch.tensor(pts, dtype=torch.float64, device=dev)
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    abi.check(L.bridges_contains_points(tab, sid, _ptr(tv), n, _ptr(tp), _ptr(out), _stream()), "bridges_contains_points")
+    return out.cpu().numpy().astype(bool)

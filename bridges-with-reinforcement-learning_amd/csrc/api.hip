@@ -315,6 +315,16 @@ int bridges_face_frames(const bridges_shape* shapes_dev, int32_t n, const int32_
     return BRIDGES_OK;
 }
 
+int bridges_contains_points(const bridges_shape* shapes_dev, int32_t shape_id, const double* verts, int32_t n,
+                            const double* points, uint8_t* inside, void* stream) {
+    if (n < 0 || !shapes_dev) return fail_arg("bridges_contains_points");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_contains_points, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, shapes_dev, shape_id,
+                       verts, n, points, inside);
+    LAUNCH_CHECK("k_contains_points");
+    return BRIDGES_OK;
+}
+
 static int grid_for_waves(int64_t n_items) {
     int64_t blocks = (n_items + 3) / 4;
     if (blocks > 2048) blocks = 2048;

@@ -105,6 +105,29 @@ __global__ void k_face_frames(const bridges_shape* shapes, int n, const int32_t*
     }
 }
 
+// Shape.contains_2d (assembly_env.py:126-137) for arbitrary sample points: inside[i] = all faces of the posed outline
+// satisfy ((p.x - c.x) * n.x) + ((p.z - c.z) * n.z) <= 0.  One thread per point, one posed block per call.
+__global__ void k_contains_points(const bridges_shape* shapes, int shape_id, const double* verts /*[6,2]*/, int n,
+                                  const double* points /*[n,2]*/, uint8_t* inside) {
+    __shared__ double fr[MAXV][4];
+    const bridges_shape& s = shapes[shape_id];
+    if (threadIdx.x < s.nv) {
+        const int f = threadIdx.x;
+        Frame2 e = edge_frame(verts[2 * s.fa[f]], verts[2 * s.fa[f] + 1], verts[2 * s.fb[f]], verts[2 * s.fb[f] + 1]);
+        fr[f][0] = e.cx; fr[f][1] = e.cz; fr[f][2] = e.nx; fr[f][3] = e.nz;
+    }
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double px = points[2 * i], pz = points[2 * i + 1];
+    bool in = true;
+    for (int f = 0; f < s.nv; ++f) {
+        double d = (px - fr[f][0]) * fr[f][2] + (pz - fr[f][1]) * fr[f][3];
+        in = in && (d <= 0.0);
+    }
+    inside[i] = in;
+}
+
 // K4: one wave per posed outline (world vertices in shape-vertex order).
 __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* shapes, int n, const double* verts,
                                                         const int32_t* shape_id, const double* gx, const double* gy,

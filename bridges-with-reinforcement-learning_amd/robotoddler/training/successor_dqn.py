@@ -243,6 +243,43 @@ def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_v
     return transitions, images
 
 
+def rollout_episode_scripted(env, predefined_actions, setup_fct, x_discr_ground, offset_values=[0.], img_size=(64, 64),
+                             xlim=(-3, 7), ylim=(0., 10), log_images=False, device=None):
+    """Roll out predefined actions (successor_dqn.py:290-362): lin_reward = sum(action raster * reward map) without
+    the stability scaling, td_error = 0."""
+    done, transitions, images = False, [], ([] if log_images else None)
+    obs, info = env.reset(**setup_fct())
+    kw = dict(img_size=img_size, device=device, xlim=xlim, ylim=ylim)
+    reward_features, obstacle_features = get_task_features(obs, **kw)
+    block_features, binary_features = get_state_features(obs, **kw)
+    for action in predefined_actions:
+        if done:
+            break
+        selected_action_features = get_action_features(env, [action], **kw)[0]
+        next_observation, reward, terminated, truncated, info = env.step(action)
+        done = bool(terminated or truncated)
+        lin_reward = torch.sum(selected_action_features * reward_features)
+        next_block_features, next_binary_features = get_state_features(next_observation, **kw)
+        acts = [*generate_actions(env, x_discr_ground=x_discr_ground, offset_values=offset_values)]
+        feats = get_action_features(env, acts, **kw)
+        next_available_actions, next_action_features = filter_actions(env, acts, feats, next_block_features,
+                                                                      obstacle_features=obstacle_features, xlim=xlim, ylim=ylim)
+        n = len(next_available_actions)
+        transitions.append(Transition(
+            block_features=block_features.unsqueeze(0), binary_features=binary_features.unsqueeze(0),
+            action_features=selected_action_features.unsqueeze(0), reward_features=reward_features.unsqueeze(0),
+            obstacle_features=obstacle_features.unsqueeze(0), action=action, lin_reward=lin_reward.unsqueeze(0),
+            reward=torch.Tensor([reward]), done=done, next_block_features=next_block_features.expand(n, -1, -1, -1),
+            next_binary_features=next_binary_features.expand(n, -1), next_actions_features=next_action_features,
+            next_reward_features=reward_features.expand(n, -1, -1, -1),
+            next_obstacle_features=obstacle_features.expand(n, -1, -1, -1),
+            next_available_actions=next_available_actions, td_error=0))
+        block_features, binary_features = next_block_features, next_binary_features
+        if log_images:
+            images.append(dict(succ_block_features=next_block_features[0].cpu().numpy()))
+    return transitions, images
+
+
 def log_episode(episode, transitions, losses, gamma, context='training', policy=None, images=None, log_images=False,
                 wandb_run=None, aim_run=None, verbose=False):
     """Episode summary (successor_dqn.py:479-567) without the matplotlib figure; aim / wandb sinks are used when the

@@ -185,6 +185,10 @@ int bridges_pose_block(const bridges_shape* shapes_dev, int32_t n, const int32_t
 /* Shape.get_face_frame_2d on posed blocks (assembly_env.py:118-124): frames [n,6,6] = centre.xz, x-axis.xz, normal.xz. */
 int bridges_face_frames(const bridges_shape* shapes_dev, int32_t n, const int32_t* shape_id, const double* verts,
                         double* frames, void* stream);
+/* Shape.contains_2d (assembly_env.py:126-137) of ONE posed block for n arbitrary points (x, z):
+ * verts [6,2], points [n,2] f64 -> inside [n] u8. */
+int bridges_contains_points(const bridges_shape* shapes_dev, int32_t shape_id, const double* verts, int32_t n,
+                            const double* points, uint8_t* inside, void* stream);
 /* K4: render_blocks_2d (rendering.py:105-113) of n posed outlines, one image each.
  * verts [n,6,2] world vertices in shape-vertex order, shape_id [n], grid_x/grid_y [64] DEVICE
  * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */

@@ -99,3 +99,29 @@ def test_render_and_stabilities_freezing_match_oracle():
         assert np.array_equal(img, og.state_raster())
         for b, ob in zip(obs["blocks"], og.blocks):
             assert np.array_equal(b.verts_2d, np.array(ob.verts))
+
+
+def test_contains_2d_points_and_scripted_rollout():
+    import torch
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import Action, AssemblyGym, horizontal_bridge_setup, sparse_reward
+    from oracle.env import OracleGym
+    from oracle.env import horizontal_bridge_setup as o_setup
+    from oracle.raster import contains_2d, pixel_grid
+    from robotoddler.training.successor_dqn import rollout_episode_scripted
+    env = AssemblyGym(**horizontal_bridge_setup(num_obstacles=2), reward_fct=sparse_reward, restrict_2d=True, max_steps=10,
+                      assembly_env=AssemblyEnv(render=False))
+    acts = [Action(-1, 0, 0, 2, -0.9, 0.0), Action(0, 0, 0, 2, 0.0, 0.0)]
+    trans, _ = rollout_episode_scripted(env, acts, lambda: horizontal_bridge_setup(num_obstacles=2), np.linspace(-2, 0, 10),
+                                        device=torch.device("cuda"))
+    assert len(trans) == 2 and trans[0].td_error == 0 and trans[0].lin_reward.shape == (1,)
+    og = OracleGym(**o_setup(num_obstacles=2), max_steps=10)
+    for a in acts:
+        og.step((a.target_block, a.target_face, a.shape, a.face, a.offset_x, a.offset_y))
+    X, Y = pixel_grid((-3, 7), (0, 10))
+    XX, YY = np.meshgrid(X, Y)
+    pts = np.stack([XX.ravel(), YY.ravel()], axis=1)
+    for b, ob in zip(env.assembly_env.blocks, og.blocks):
+        assert np.array_equal(b.contains_2d(pts).reshape(64, 64), contains_2d(ob, X, Y))
+    # lin_reward of the scripted rollout = sum(action raster * reward map)
+    np.testing.assert_allclose(trans[0].lin_reward.item(), og.reward_map[contains_2d(og.blocks[0], X, Y)].sum(), rtol=1e-5)
