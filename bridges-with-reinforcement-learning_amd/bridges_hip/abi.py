@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbridges_hip.so")
+LIB_PATH = os.environ.get("BRIDGES_LIB", os.path.join(HERE, "libbridges_hip.so"))      # override: diagnostic builds
 
 MAX_VERTS = 6
 MAX_BLOCKS = 16

@@ -373,6 +373,17 @@ int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, con
     return BRIDGES_OK;
 }
 
+#ifdef LP_PROFILE
+int bridges_debug_lp_profile(unsigned long long* out8, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lp_prof), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lp_prof), z, sizeof(z)));
+    }
+    return BRIDGES_OK;
+}
+#endif
+
 int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, float one_minus_tau, void* stream) {
     if (n < 0) return fail_arg("bridges_soft_update");
     if (n == 0) return BRIDGES_OK;

@@ -12,12 +12,27 @@
 
 namespace bridges {
 
+#ifdef LP_PROFILE   // diagnostic build only (tools/lp_microbench.py --profile): shader cycles per pivot phase
+__device__ unsigned long long g_lp_prof[8];
+#define LP_PROF_DECL long long lp_acc_[6] = {0, 0, 0, 0, 0, 0}
+#define LP_STAMP(var) long long var = clock64()
+#define LP_ACC(slot, a, b) lp_acc_[slot] += (b) - (a)
+#define LP_PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_lp_prof[k_], (unsigned long long)lp_acc_[k_]); } while (0)
+#else
+#define LP_PROF_DECL
+#define LP_STAMP(var)
+#define LP_ACC(slot, a, b)
+#define LP_PROF_FLUSH
+#endif
+
 #define RBE_TOL_PARALLEL 1e-6
 #define RBE_TOL_COPLANAR 1e-6
 #define RBE_AMIN 0.001
 #define RBE_FEAS_TOL 1e-5     // oracle: HiGHS optimum <= 1e-7; observed gap between the classes: 0 vs >= 3e-2
 #define LP_EPS_COST 1e-9
-#define LP_TAU 1e-7           // smallest admissible pivot element
+#define LP_TAU 1e-5           // smallest admissible pivot element: above the ~1e-6 noise the float32 meshes put into the
+                              // tableau (angles off by ~7e-8 x lever arms x mu), below every real coefficient (>= ~1e-3)
+#define LP_VERIFY_TOL 1e-4    // L1 residual of the original rows accepted for a "feasible" verdict (rhs perturbation <= 2e-6)
 #define LP_TIE 1e-9           // ratios within this (relative) band are ties
 #define LP_STALL 40           // degenerate pivots before Bland's rule takes over
 #define LP_MAX_PIVOTS 5000
@@ -236,12 +251,14 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
     bool bland = false;
     const int nchunk = (n + WAVE - 1) / WAVE;
     const int ncols = n + 1;
+    LP_PROF_DECL;
     double w = artificial_sum(T, stride, m_act, n, basis, lane);
     for (;;) {
         if (w <= RBE_FEAS_TOL) {                                   // confirm with the exact artificial sum
             w = artificial_sum(T, stride, m_act, n, basis, lane);
             if (w <= RBE_FEAS_TOL) break;
         }
+        LP_STAMP(t_a);
         // ---- entering column ----
         int jin = -1;
         if (bland) {
@@ -268,6 +285,8 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
             w = artificial_sum(T, stride, m_act, n, basis, lane);
             break;
         }
+        LP_STAMP(t_b);
+        LP_ACC(0, t_a, t_b);
         // ---- ratio test, lanes over rows (m <= 48 < 64) ----
         double col = (lane <= m) ? T[lane * stride + jin] : 0.0;   // lane m holds the cost entry
         double ratio = 1e300;
@@ -292,6 +311,8 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
             r = __ffsll((long long)__ballot(tie && col == cmax)) - 1;
         }
         const double ipiv = fast_rcp(readlane_d(col, r));
+        LP_STAMP(t_c);
+        LP_ACC(1, t_b, t_c);
         // ---- stage the entering column, the normalised pivot row and the lists of rows / columns the rank-1
         //      update actually touches (equilibrium tableaux are sparse: typically a fraction of the cells) ----
         S.col[lane] = col;
@@ -311,6 +332,8 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
             nc += __popcll(cbal);
         }
         wave_sync<IN_LDS>();
+        LP_STAMP(t_d);
+        LP_ACC(2, t_c, t_d);
         // ---- elimination over the touched cells only, 4 independent cells per lane per trip (loads first, then
         //      stores: the cells are distinct, which the compiler cannot prove, so the batching is explicit) ----
         {
@@ -345,6 +368,9 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         }
         if (lane == 0) basis[r] = jin;
         wave_sync<IN_LDS>();
+        LP_STAMP(t_e);
+        LP_ACC(3, t_d, t_e);
+        LP_ACC(5, t_a, t_a + 1);       // pivot count
         const double wn = -T[m * stride + n];
         if (wn < w - 1e-12) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
@@ -352,7 +378,58 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m_act, n, basis, lane); break; }
     }
     *pivots_out = pivots;
+    LP_PROF_FLUSH;
     return w;
+}
+
+// Independent check of a "feasible" verdict: read the basic solution x off the tableau and evaluate the ORIGINAL
+// equilibrium rows  sum_j M_ij x_j - w_i  again from the contact list (nothing of the pivoted tableau is reused).
+// A tableau damaged by an ill-conditioned pivot cannot pass this.  Returns the L1 residual over rows < m_chk.
+template <typename TP>
+__device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, LpScratch& S, int n_if,
+                                   const int32_t* if_body, const double* if_geom, int n_blocks, const double* pose,
+                                   const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
+                                   int lane) {
+    for (int q = lane; q < n; q += WAVE) S.rowr[q] = 0.0;
+    __syncthreads();
+    if (lane < m && S.basis[lane] >= 0 && S.basis[lane] < n) {
+        double v = T[lane * stride + n];
+        S.rowr[S.basis[lane]] = v > 0.0 ? v : 0.0;
+    }
+    __syncthreads();
+    double res = 0.0;
+    if (lane < m_chk) {
+        // row -> (block, component): rows are 3 per free block in block order (row_of)
+        int b = -1;
+        for (int k = 0; k < n_blocks; ++k) if (S.row_of[k] >= 0 && S.row_of[k] <= lane && lane < S.row_of[k] + 3) b = k;
+        const int comp = lane - S.row_of[b];
+        const bridges_shape& sh = shapes[shape_id[b]];
+        const double* P = pose + 4 * b;
+        double rgx, rgz;
+        rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
+        const double gcx = P[0] + rgx, gcz = P[1] + rgz;
+        double acc = 0.0;
+        for (int k = 0; k < n_if; ++k) {
+            const int bA = if_body[2 * k], bB = if_body[2 * k + 1];
+            if (bA != b && bB != b) continue;
+            const double sign = (bB == b) ? 1.0 : -1.0;
+            const double* g = if_geom + 8 * k;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int ip = c4 >> 1, ig = c4 & 1;
+                const double x = S.rowr[4 * k + c4];
+                if (x == 0.0) continue;
+                const double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+                const double gx = sign * (ig ? g[4] - mu * g[6] : g[4] + mu * g[6]);
+                const double gz = sign * (ig ? g[5] - mu * g[7] : g[5] + mu * g[7]);
+                const double coef = comp == 0 ? gx : (comp == 1 ? gz : (px - gcx) * gz - (pz - gcz) * gx);
+                acc += coef * x;
+            }
+        }
+        const double rhs = comp == 1 ? density * sh.volume : 0.0;
+        res = fabs(acc - rhs);
+    }
+    return wave_sum_d(res);
 }
 
 // Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
@@ -402,10 +479,14 @@ __device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_ca
     if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
         lp_build(tab_lds, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
         w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true);
+        if (w <= RBE_FEAS_TOL && lp_verify(tab_lds, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes,
+                                           mu, density, lane) > LP_VERIFY_TOL) { *error = true; w = 1.0; }
     } else {
         if (cells > ws_cap) { *error = true; return false; }
         lp_build(tab_ws, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
         w = lp_phase1<false>(tab_ws, stride, m, m, n, S, lane, pivots_out, error, true);
+        if (w <= RBE_FEAS_TOL && lp_verify(tab_ws, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes,
+                                           mu, density, lane) > LP_VERIFY_TOL) { *error = true; w = 1.0; }
     }
     *w_out = w;
     return w <= RBE_FEAS_TOL;
@@ -424,10 +505,20 @@ __device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S,
     int piv = 0;
     double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, true);
     *st_frozen = w <= RBE_FEAS_TOL;
+    if (*st_frozen && m_act > 0 &&
+        lp_verify(T, stride, m, m_act, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density, lane) > LP_VERIFY_TOL) {
+        *st_frozen = false;                 // the verdict does not survive the check on the original rows
+        *error = true;
+    }
     if (!*st_frozen) { *st_free = false; return; }
     lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane);
     w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false);
     *st_free = w <= RBE_FEAS_TOL;
+    if (*st_free &&
+        lp_verify(T, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density, lane) > LP_VERIFY_TOL) {
+        *st_free = false;
+        *error = true;
+    }
 }
 
 __device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,

@@ -195,7 +195,7 @@ static void append_interfaces(orc_env* e, int nbn) {
 /* ---- phase-1 simplex: exists x >= 0 with M x = w ?  (oracle/rbe.py; same rules as the device kernel) ---- */
 #define FEAS_TOL 1e-5
 #define EPS_COST 1e-9
-#define TAU 1e-7
+#define TAU 1e-5
 #define TIE 1e-9
 #define STALL 40
 #define PERTURB 1e-8

@@ -51,7 +51,11 @@ for name, fn, kw, shapes, mu, n_env in TASKS:
                 out.append(rec)
             if not g.stable:
                 break
-json.dump(out, open(os.path.join(HERE, "large_assemblies.json"), "w"))
+# regression cases found by tools/stress_parity.py are kept across regenerations
+path = os.path.join(HERE, "large_assemblies.json")
+if os.path.exists(path):
+    out += [r for r in json.load(open(path)) if r["task"].startswith("regression_")]
+json.dump(out, open(path, "w"))
 vs = [c["v"] for r in out for c in r["cases"] if c["v"] is not None]
 print(len(out), "assemblies,", sum(len(r["cases"]) for r in out), "cases; blocks max", max(len(r["poses"]) for r in out),
       "n_if max", max(c["n_if"] for r in out for c in r["cases"]), "stable", sum(c["stable"] for r in out for c in r["cases"]))

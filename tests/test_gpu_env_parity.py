@@ -193,3 +193,15 @@ def test_restricted_target_faces_two_targets_no_step_limit_parity():
     assert len(vec.groups) == 5                      # 4 trapezoid faces + the cube's single target face
     run_lockstep_parity(vec, oracles, seed, n_lock=14)
     assert not bool(vec.flags()["truncated"].any())
+
+
+@pytest.mark.parametrize("task", ["tower4", "mixed"])
+def test_stress_parity_against_the_c_oracle(task):
+    """Thousands of env-steps against the plain-C oracle (fast enough to follow): every selected action, both
+    stability booleans, rewards, termination, candidate / valid counts."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--envs", "256", "--locksteps", "40",
+                          "--task", task, "--seed", "29"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 mismatches" in out.stdout

@@ -25,6 +25,7 @@ def test_fixture_is_well_separated_and_reproducible(fixture):
     vs = [c["v"] for r in fixture for c in r["cases"] if c["v"] is not None]
     assert not any(1e-6 < v < 1e-4 for v in vs)            # nothing near the 1e-5 decision threshold
     assert max(len(r["poses"]) for r in fixture) == 15
+    assert any(r["task"].startswith("regression_") for r in fixture)      # a noise-pivot case a 1e-7 pivot tolerance got wrong
     for r in fixture[::9]:
         shapes = [get_shape(n) for n in r["shapes"]]
         blocks = [Block(shapes[s], (p[0], p[1]), (p[2], p[3])) for s, p in zip(r["shape_ids"], r["poses"])]

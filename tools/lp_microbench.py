@@ -36,9 +36,21 @@ def run(nb_t, label):
           f"nb hist {np.bincount(nbc, minlength=16).tolist()}; errors {int((inf[:,3]!=0).sum())}")
     return inf
 
+prof = hasattr(L, "bridges_debug_lp_profile") and "--profile" in sys.argv
+def read_prof(label):
+    if not prof:
+        return
+    buf = (C.c_ulonglong * 8)()
+    L.bridges_debug_lp_profile(buf, 1)
+    v = list(buf)
+    n = max(v[5], 1)
+    print(f"   [{label}] cycles per pivot: price {v[0]/n:.0f}  ratio {v[1]/n:.0f}  stage {v[2]/n:.0f}  sweep {v[3]/n:.0f}  (pivots {v[5]})")
+read_prof("warm-up")
 inf = run(nb, "all envs")
+read_prof("all")
 for cap in (1, 2, 3, 4, 6, 8):
     run(torch.clamp(nb, max=cap), f"n_blocks clamped to {cap}")
+    read_prof(f"clamp {cap}")
 for lo, hi in ((0, 2), (2, 4), (4, 6), (6, 9), (9, 16)):
     sel = (nb.cpu().numpy() >= lo) & (nb.cpu().numpy() < hi)
     if sel.any():

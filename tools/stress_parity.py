@@ -1,0 +1,54 @@
+"""Large randomized parity run: the HIP lock-step environment against the plain-C oracle (oracle/c), env by env and
+step by step -- selected action, both stability booleans, reward, termination, candidate / valid counts, state raster.
+    python tools/stress_parity.py --envs 1024 --locksteps 100 [--task tower4|tower2|hexbridge|mixed]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
+import numpy as np, torch
+from oracle.c_env import CEnv
+from oracle.env import OracleGym, bridge_setup, horizontal_bridge_setup
+from bridges_hip.shapes import load_urdf
+from bridges_hip.vec_env import VecAssemblyGym
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=1024)
+ap.add_argument("--locksteps", type=int, default=100)
+ap.add_argument("--seed", type=int, default=17)
+ap.add_argument("--task", default="tower4")
+a = ap.parse_args()
+TASKS = dict(tower4=(bridge_setup, dict(num_stories=4), ["trapezoid"], 15, 0.8),
+             tower2=(bridge_setup, dict(num_stories=2), ["trapezoid"], 10, 0.8),
+             hexbridge=(horizontal_bridge_setup, dict(num_obstacles=3, trapezoid=False, hexagon=True), ["hexagon"], 15, 0.8),
+             mixed=(horizontal_bridge_setup, dict(num_obstacles=4, trapezoid=True, hexagon=True), ["trapezoid", "hexagon"], 12, 2.0))
+fn, kw, names, max_steps, mu = TASKS[a.task]
+setup = fn(**kw)
+vec = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], setup["obstacles"], setup["targets"],
+                     max_steps=max_steps, seed=a.seed, mu=mu, f32_rasters=False)
+gym = OracleGym(**setup, max_steps=max_steps, mu=mu)
+cenvs = [CEnv(gym) for _ in range(a.envs)]
+t0 = time.time(); steps = lps = 0; mism = 0
+for it in range(a.locksteps):
+    vec.select_random()
+    sel = vec.sel_index.cpu().numpy()
+    vec.step()
+    fl = vec.step_flags.cpu().numpy(); rew = vec.reward.cpu().numpy(); ncand = vec.n_cand.cpu().numpy()
+    nval = vec.n_valid.cpu().numpy(); sb = vec.state_bits.cpu().numpy().astype(np.uint64)
+    for e, ce in enumerate(cenvs):
+        o = ce.lockstep(a.seed, e)
+        ok = bool(fl[e, 0]) == bool(o.valid_step) and bool(fl[e, 6]) == bool(o.no_actions)
+        if o.valid_step:
+            steps += 1; lps += 2
+            ok = ok and sel[e] == o.action_index and fl[e, 1] == o.stable_frozen and fl[e, 2] == o.stable_unfrozen \
+                and fl[e, 3] == o.terminated and fl[e, 4] == o.truncated and rew[e] == o.reward and fl[e, 7] == 0
+        n_c, n_v = (lambda p: (p[0], p[1]))((lambda: (lambda c: (len(c[0]), c[1]))(ce.candidates()))()) if it % 10 == 0 else (ncand[e], nval[e])
+        ok = ok and n_c == ncand[e] and n_v == nval[e]
+        if it % 10 == 0:
+            ok = ok and list(sb[e]) == ce.state_bits()
+        if not ok:
+            mism += 1
+            print("MISMATCH lock-step", it, "env", e, fl[e], (o.valid_step, o.action_index, o.stable_frozen, o.stable_unfrozen, o.terminated, o.reward), sel[e])
+            if mism > 10: sys.exit(1)
+    if it % 10 == 9:
+        print(f"lock-step {it + 1}: {steps} env-steps compared, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"RESULT task={a.task} envs={a.envs} locksteps={a.locksteps}: {steps} env-steps ({lps} stability decisions) compared, {mism} mismatches")
+sys.exit(1 if mism else 0)
