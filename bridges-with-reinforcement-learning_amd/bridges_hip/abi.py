@@ -14,6 +14,14 @@ MAX_BLOCKS = 16
 MAX_GROUPS = 24
 MAX_TARGETS = 8
 MAX_INTERFACES = 64
+
+
+def lp_ws_stride(max_blocks):
+    """Doubles of simplex workspace per assembly (include/bridges_hip.h: lp_ws_stride): interface list + the largest
+    tableau, (3K equilibrium rows + budget + cost) x (4*MAX_IF generators + slack + rhs, padded to an odd stride)."""
+    return 9 * MAX_INTERFACES + (3 * max_blocks + 2) * (4 * MAX_INTERFACES + 3)
+
+
 IMG = 64
 
 FLAG_NAMES = ("valid_step", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",

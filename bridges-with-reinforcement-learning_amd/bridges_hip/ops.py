@@ -141,7 +141,7 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
             mask |= 1 << i
     tab = REGISTRY.device_table()
     t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
-    ws_stride = 9 * abi.MAX_INTERFACES + (3 * K + 1) * (4 * abi.MAX_INTERFACES + 2)
+    ws_stride = abi.lp_ws_stride(K)
     ws = torch.empty((1, ws_stride), dtype=torch.float64, device=dev)
     stable = torch.zeros(1, dtype=torch.uint8, device=dev)
     info = torch.zeros((1, 8), dtype=torch.float64, device=dev)

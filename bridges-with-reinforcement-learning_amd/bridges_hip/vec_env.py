@@ -127,7 +127,7 @@ class VecAssemblyGym:
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         E, K, Cc = self.E, self.K, self.E * self.a_max
-        self.ws_stride = 9 * abi.MAX_INTERFACES + (3 * K + 1) * (4 * abi.MAX_INTERFACES + 2)
+        self.ws_stride = abi.lp_ws_stride(K)
         dims = dict(E=E, K=K, C=Cc, E1=E + 1, IF=abi.MAX_INTERFACES, WS=self.ws_stride)
         self.buf = {}
         for name, dt, shape in abi.ENV_BUFFER_FIELDS:
@@ -295,7 +295,7 @@ class VecAssemblyGym:
         out = torch.zeros(n, dtype=torch.bool, device=self.device)
         if n == 0:
             return idx, out
-        ws_stride = 9 * abi.MAX_INTERFACES + (3 * K16 + 1) * (4 * abi.MAX_INTERFACES + 2)
+        ws_stride = abi.lp_ws_stride(K16)
         if getattr(self, "_stab_ws", None) is None:
             self._stab_ws = torch.empty((chunk, ws_stride), dtype=torch.float64, device=self.device)
         for lo in range(0, n, chunk):

@@ -68,7 +68,7 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (t->n_ground < 0 || t->n_ground > 32 || t->n_offsets <= 0 || t->n_offsets > 8) return fail_arg("n_ground/n_offsets");
     if (t->n_targets < 0 || t->n_targets > BRIDGES_MAX_TARGETS) return fail_arg("n_targets");
     if (t->a_max <= 0) return fail_arg("a_max");
-    if (buf->lp_ws_stride < (int64_t)(3 * t->max_blocks + 1) * (4 * BRIDGES_MAX_INTERFACES + 2)) return fail_arg("lp_ws_stride");
+    if (buf->lp_ws_stride < (int64_t)(3 * t->max_blocks + 2) * (4 * BRIDGES_MAX_INTERFACES + 3)) return fail_arg("lp_ws_stride");
     for (int g = 0; g < t->n_groups; ++g) {
         if (t->group_shape[g] < 0 || t->group_shape[g] >= t->n_shapes) return fail_arg("group_shape");
         if (t->group_face[g] < 0 || t->group_face[g] >= t->shapes[t->group_shape[g]].nv) return fail_arg("group_face");
@@ -364,7 +364,7 @@ int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, con
                       double* lp_ws, int64_t lp_ws_stride, void* stream) {
     if (n < 0 || !shapes_dev) return fail_arg("bridges_stability");
     if (K <= 0 || K > BRIDGES_MAX_BLOCKS) return fail_arg("K > BRIDGES_MAX_BLOCKS");
-    if (lp_ws_stride < 9 * BRIDGES_MAX_INTERFACES + (int64_t)(3 * K + 1) * (4 * BRIDGES_MAX_INTERFACES + 2))
+    if (lp_ws_stride < 9 * BRIDGES_MAX_INTERFACES + (int64_t)(3 * K + 2) * (4 * BRIDGES_MAX_INTERFACES + 3))
         return fail_arg("lp_ws_stride");
     if (n == 0) return BRIDGES_OK;
     hipLaunchKernelGGL(k_stability, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, shapes_dev, n, K, pose, verts, shape_id,

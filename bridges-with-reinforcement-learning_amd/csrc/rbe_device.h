@@ -37,10 +37,12 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_STALL 40           // degenerate pivots before Bland's rule takes over
 #define LP_MAX_PIVOTS 5000
 #define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
+#define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
+                              // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
 #define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (8 KiB); larger tableaux live in lp_ws
 #define MAXFACES (1 + MAXK * MAXV)            // floor + K blocks
 #define LP_MAX_COLS (4 * MAXIF)
-#define LP_MAX_CHUNKS ((LP_MAX_COLS + 1 + WAVE - 1) / WAVE)
+#define LP_MAX_CHUNKS ((LP_MAX_COLS + 2 + WAVE - 1) / WAVE)
 
 struct FaceLds {            // staged face frames of one assembly
     double ax[MAXFACES], az[MAXFACES], bx[MAXFACES], bz[MAXFACES];
@@ -134,7 +136,9 @@ __device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int3
     return n_if;
 }
 
-// Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = cost.
+// Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = the force budget
+// sum_j x_j + s = LP_S_MAX, row m+1 = cost.  Columns [0, n) = cone generators, column n = the budget slack s,
+// column n+1 = right-hand side.
 // Blocks >= n_free are fixed (only the last block is ever frozen, gym_env.py:235-240).
 // The right-hand side carries a tiny deterministic perturbation (<= 2e-7 per row, far below RBE_FEAS_TOL): these
 // equilibrium systems are massively degenerate (most rhs entries are exactly 0) and the perturbation is what keeps
@@ -144,7 +148,8 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n
                                 const double* if_geom, const int* row_of /*LDS [K]*/, int n_blocks,
                                 const double* pose /*[K,4]*/, const int32_t* shape_id, const bridges_shape* shapes,
                                 double mu, double density, int lane) {
-    int cells = (m + 1) * stride;
+    const int nn = n + 1;                              // structural columns incl. the budget slack; rhs column index
+    int cells = (m + 2) * stride;
     for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
     __syncthreads();
     for (int j = lane; j < n; j += WAVE) {
@@ -173,26 +178,27 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n
         }
     }
     for (int i = lane; i < m; i += WAVE)
-        T[i * stride + n] = LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+        T[i * stride + nn] = LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? 1.0 : LP_S_MAX;
     __syncthreads();
     for (int b = lane; b < n_blocks; b += WAVE)
-        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + n] += density * shapes[shape_id[b]].volume;
+        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * shapes[shape_id[b]].volume;
     __syncthreads();
-    for (int q = lane; q <= n; q += WAVE) {          // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
+    for (int q = lane; q <= nn; q += WAVE) {         // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
         double s = 0.0;
         for (int i = 0; i < m_act; ++i) s += T[i * stride + q];
-        T[m * stride + q] = -s;
+        T[(m + 1) * stride + q] = -s;
     }
     __syncthreads();
 }
 
 struct LpScratch {                 // LDS scratch of one wave's simplex
     double col[WAVE];              // entering column (row i in slot i, cost entry in slot m)
-    double rowr[LP_MAX_COLS + 2];  // normalised pivot row
+    double rowr[LP_MAX_COLS + 4];  // normalised pivot row
     int basis[WAVE];
     int row_of[MAXK];              // first tableau row of block b, or -1 if the block is fixed (is_static)
     short rows_nz[WAVE];           // rows touched by the current pivot (entering column entry != 0)
-    short cols_nz[LP_MAX_COLS + 2];// columns touched by the current pivot (pivot row entry != 0)
+    short cols_nz[LP_MAX_COLS + 4];// columns touched by the current pivot (pivot row entry != 0)
 };
 
 // Ordering point between the lanes of the ONE wave that owns a tableau.  LDS operations of a wave execute in
@@ -238,13 +244,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // read from the cost row (the exact artificial sum is recomputed only to confirm a "feasible" exit).
 // Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
 template <bool IN_LDS, typename TP>
-__device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, LpScratch& S, int lane, int* pivots_out,
+__device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, LpScratch& S, int lane, int* pivots_out,
                                    bool* error, bool init_basis) {
-    // m rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials (the others
-    // are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
+    // m equilibrium rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials
+    // (the others are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
+    // Row m is the force-budget row (always enforced, basic variable = its slack, column n_gen), row m+1 the cost.
     int* basis = S.basis;
+    const int n = n_gen + 1;                           // structural columns incl. the slack; also the rhs column index
+    const int mb = m, mc = m + 1;                      // budget row, cost row
     if (init_basis) {
-        for (int i = lane; i < m; i += WAVE) basis[i] = (i < m_act) ? n + i : -1;
+        for (int i = lane; i <= mb; i += WAVE) basis[i] = (i < m_act) ? n + i : (i == mb ? n_gen : -1);
         wave_sync<IN_LDS>();
     }
     int pivots = *pivots_out, stall = 0;
@@ -264,7 +273,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         if (bland) {
             for (int c = 0; c < nchunk && jin < 0; ++c) {
                 int j = c * WAVE + lane;
-                bool neg = (j < n) && (T[m * stride + j] < -LP_EPS_COST);
+                bool neg = (j < n) && (T[mc * stride + j] < -LP_EPS_COST);
                 uint64_t bal = __ballot(neg);
                 if (bal) jin = c * WAVE + (__ffsll((long long)bal) - 1);
             }
@@ -272,7 +281,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
             double dbest = 0.0;
             int jbest = 0;
             for (int j = lane; j < n; j += WAVE) {
-                double d = T[m * stride + j];
+                double d = T[mc * stride + j];
                 if (d < dbest) { dbest = d; jbest = j; }           // strict: keeps the lane's lowest column of a tie
             }
             double dmin = wave_min_d(dbest);
@@ -287,16 +296,16 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         }
         LP_STAMP(t_b);
         LP_ACC(0, t_a, t_b);
-        // ---- ratio test, lanes over rows (m <= 48 < 64) ----
-        double col = (lane <= m) ? T[lane * stride + jin] : 0.0;   // lane m holds the cost entry
+        // ---- ratio test, lanes over rows (m + 2 <= 50 < 64) ----
+        double col = (lane <= mc) ? T[lane * stride + jin] : 0.0;  // lane m: budget row, lane m+1: cost entry
         double ratio = 1e300;
-        if (lane < m_act && col > LP_TAU) {
+        if ((lane < m_act || lane == mb) && col > LP_TAU) {
             double rhs = T[lane * stride + n];
             ratio = (rhs > 0.0 ? rhs : 0.0) * fast_rcp(col);
         }
         const double rmin = wave_min_d(ratio);
         if (rmin >= 1e300) {                                       // no usable pivot in this column: retire it
-            if (lane == 0) T[m * stride + jin] = 0.0;
+            if (lane == 0) T[mc * stride + jin] = 0.0;
             wave_sync<IN_LDS>();
             continue;
         }
@@ -316,7 +325,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         // ---- stage the entering column, the normalised pivot row and the lists of rows / columns the rank-1
         //      update actually touches (equilibrium tableaux are sparse: typically a fraction of the cells) ----
         S.col[lane] = col;
-        const uint64_t rbal = __ballot(lane <= m && (col != 0.0 || lane == r));
+        const uint64_t rbal = __ballot(lane <= mc && (col != 0.0 || lane == r));
         if ((rbal >> lane) & 1ull) S.rows_nz[__popcll(rbal & ((1ull << lane) - 1ull))] = (short)lane;
         const int nr = __popcll(rbal);
         int nc = 0;
@@ -371,7 +380,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n, Lp
         LP_STAMP(t_e);
         LP_ACC(3, t_d, t_e);
         LP_ACC(5, t_a, t_a + 1);       // pivot count
-        const double wn = -T[m * stride + n];
+        const double wn = -T[mc * stride + n];
         if (wn < w - 1e-12) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
@@ -392,8 +401,8 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, Lp
                                    int lane) {
     for (int q = lane; q < n; q += WAVE) S.rowr[q] = 0.0;
     __syncthreads();
-    if (lane < m && S.basis[lane] >= 0 && S.basis[lane] < n) {
-        double v = T[lane * stride + n];
+    if (lane <= m && S.basis[lane] >= 0 && S.basis[lane] < n) {     // rows incl. the budget row; generators only
+        double v = T[lane * stride + n + 1];
         S.rowr[S.basis[lane]] = v > 0.0 ? v : 0.0;
     }
     __syncthreads();
@@ -435,14 +444,15 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, Lp
 // Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
 // price it into the cost row.  The tableau then continues from the basis reached so far (warm start).
 template <bool IN_LDS, typename TP>
-__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n, LpScratch& S, int lane) {
+__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, LpScratch& S, int lane) {
+    const int n = n_gen + 1;
     for (int i = m_act; i < m; ++i) {
         const bool neg = T[i * stride + n] < 0.0;                  // uniform
         wave_sync<IN_LDS>();
         for (int q = lane; q <= n; q += WAVE) {
             double v = T[i * stride + q];
             if (neg) { v = -v; T[i * stride + q] = v; }
-            T[m * stride + q] -= v;
+            T[(m + 1) * stride + q] -= v;
         }
         if (lane == 0) S.basis[i] = n + i;
     }
@@ -472,9 +482,9 @@ __device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_ca
     if (n_free == 0) return true;
     lp_row_map(S, free_mask, lane);
     const int m = 3 * n_free, n = 4 * n_if;
-    int stride = n + 1;
+    int stride = n + 2;
     if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
-    const int64_t cells = (int64_t)(m + 1) * stride;
+    const int64_t cells = (int64_t)(m + 2) * stride;
     double w;
     if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
         lp_build(tab_lds, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
@@ -533,9 +543,9 @@ __device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap,
     const uint32_t all = n_blocks >= 32 ? 0xffffffffu : ((1u << n_blocks) - 1u);
     lp_row_map(S, all, lane);
     const int m = 3 * n_blocks, n = 4 * n_if;
-    int stride = n + 1;
+    int stride = n + 2;
     if ((stride & 1) == 0) stride += 1;
-    const int64_t cells = (int64_t)(m + 1) * stride;
+    const int64_t cells = (int64_t)(m + 2) * stride;
     if (cells <= LP_TAB_LDS) {
         rbe_both_in<true>(tab_lds, stride, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density,
                           lane, st_frozen, st_free, error);

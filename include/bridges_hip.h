@@ -128,7 +128,7 @@ typedef struct {
     const float* reward_map;       /* [64,64] */
     /* --- scratch --- */
     double* lp_ws;             /* [E, lp_ws_stride] simplex tableau overflow */
-    int64_t lp_ws_stride;      /* >= (3K+1)*(4*MAX_IF+1) */
+    int64_t lp_ws_stride;      /* >= 9*MAX_IF + (3K+2)*(4*MAX_IF+3) */
     uint64_t* stats;           /* [8] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps */
 } bridges_env_buffers;
 
@@ -203,7 +203,7 @@ int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* strea
  * is_static)
  * -> stable [n] u8, info [n,8] f64 (phase-1 objective, n_interfaces, pivots, error, shader cycles spent in
  *    interface detection, shader cycles spent in the LP, 0, 0).
- * lp_ws: [n, lp_ws_stride] doubles, lp_ws_stride >= 9*MAX_INTERFACES + (3K+1)*(4*MAX_INTERFACES+2). */
+ * lp_ws: [n, lp_ws_stride] doubles, lp_ws_stride >= 9*MAX_INTERFACES + (3K+2)*(4*MAX_INTERFACES+3). */
 int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose,
                       const double* verts, const int32_t* shape_id, const int32_t* n_blocks,
                       const uint32_t* fixed_mask, double mu, double density, double floor_half_width,

@@ -74,7 +74,7 @@ typedef struct {
     int32_t needs_reset, n_cand, n_valid;
     orc_cand* cand;
     float* f32;           /* optional [a_max+1][64][64] f32 rasters (what the reference surfaces to the networks) */
-    double* tab;          /* simplex tableau (3K+1) x (4*MAXIF+2) */
+    double* tab;          /* simplex tableau (3K+2) x (4*MAXIF+3) */
     long total_pivots;
 } orc_env;
 
@@ -192,52 +192,62 @@ static void append_interfaces(orc_env* e, int nbn) {
     }
 }
 
-/* ---- phase-1 simplex: exists x >= 0 with M x = w ?  (oracle/rbe.py; same rules as the device kernel) ---- */
+/* ---- phase-1 simplex: exists x >= 0 with M x = w and sum(x) <= S_MAX ?  (oracle/rbe.py; same rules as the device
+ * kernel).  Tableau layout: rows [0, m) equilibrium, row m the force budget  sum_j x_j + s = S_MAX, row m+1 the
+ * phase-1 cost; columns [0, n) cone generators, column n the budget slack s, column n+1 the right-hand side. ---- */
 #define FEAS_TOL 1e-5
 #define EPS_COST 1e-9
 #define TAU 1e-5
 #define TIE 1e-9
 #define STALL 40
 #define PERTURB 1e-8
-static double art_sum(const double* T, int stride, int m_act, int n, const int* basis) {
+#define S_MAX 1e4
+static double art_sum(const double* T, int stride, int m_act, int nn, const int* basis) {
     double s = 0.0;
-    for (int i = 0; i < m_act; ++i) if (basis[i] >= n) { double r = T[i * stride + n]; s += r > 0 ? r : 0; }
+    for (int i = 0; i < m_act; ++i) if (basis[i] >= nn) { double r = T[i * stride + nn]; s += r > 0 ? r : 0; }
     return s;
 }
-static double phase1(double* T, int stride, int m, int m_act, int n, int* basis, int init, long* pivots) {
-    if (init) for (int i = 0; i < m; ++i) basis[i] = i < m_act ? n + i : -1;
+/* m equilibrium rows are stored (rows >= m_act passive), the budget row m is always enforced; nn = n + 1 columns */
+static double phase1(double* T, int stride, int m, int m_act, int nn, int* basis, int init, long* pivots) {
+    const int cost = m + 1;
+    if (init) { for (int i = 0; i < m; ++i) basis[i] = i < m_act ? nn + i : -1; basis[m] = nn - 1; }
     int stall = 0, bland = 0, guard = 0;
-    double w = art_sum(T, stride, m_act, n, basis);
+    double w = art_sum(T, stride, m_act, nn, basis);
     while (w > FEAS_TOL) {
         int jin = -1;
-        if (bland) { for (int j = 0; j < n; ++j) if (T[m * stride + j] < -EPS_COST) { jin = j; break; } }
-        else { double best = -EPS_COST; for (int j = 0; j < n; ++j) if (T[m * stride + j] < best) { best = T[m * stride + j]; jin = j; } }
+        if (bland) { for (int j = 0; j < nn; ++j) if (T[cost * stride + j] < -EPS_COST) { jin = j; break; } }
+        else { double best = -EPS_COST; for (int j = 0; j < nn; ++j) if (T[cost * stride + j] < best) { best = T[cost * stride + j]; jin = j; } }
         if (jin < 0) break;
         double rmin = 1e300;
-        for (int i = 0; i < m_act; ++i) { double a = T[i * stride + jin]; if (a > TAU) { double r = T[i * stride + n]; r = (r > 0 ? r : 0) / a; if (r < rmin) rmin = r; } }
-        if (rmin >= 1e300) { T[m * stride + jin] = 0.0; continue; }
+        for (int i = 0; i <= m; ++i) {
+            if (i >= m_act && i != m) continue;
+            double a = T[i * stride + jin];
+            if (a > TAU) { double r = T[i * stride + nn]; r = (r > 0 ? r : 0) / a; if (r < rmin) rmin = r; }
+        }
+        if (rmin >= 1e300) { T[cost * stride + jin] = 0.0; continue; }
         int r = -1; double cbest = -1e300; int vbest = 0x7fffffff;
-        for (int i = 0; i < m_act; ++i) {
+        for (int i = 0; i <= m; ++i) {
+            if (i >= m_act && i != m) continue;
             double a = T[i * stride + jin];
             if (a <= TAU) continue;
-            double rr = T[i * stride + n]; rr = (rr > 0 ? rr : 0) / a;
+            double rr = T[i * stride + nn]; rr = (rr > 0 ? rr : 0) / a;
             if (rr > rmin + TIE * (1.0 + rmin)) continue;
             if (bland) { if (basis[i] < vbest) { vbest = basis[i]; r = i; } }
             else if (a > cbest) { cbest = a; r = i; }
         }
         double piv = T[r * stride + jin];
-        for (int q = 0; q <= n; ++q) T[r * stride + q] /= piv;
+        for (int q = 0; q <= nn; ++q) T[r * stride + q] /= piv;
         T[r * stride + jin] = 1.0;
-        for (int i = 0; i <= m; ++i) {
+        for (int i = 0; i <= cost; ++i) {
             if (i == r) continue;
             double f = T[i * stride + jin];
             if (f == 0.0) continue;
-            for (int q = 0; q <= n; ++q) T[i * stride + q] -= f * T[r * stride + q];
+            for (int q = 0; q <= nn; ++q) T[i * stride + q] -= f * T[r * stride + q];
             T[i * stride + jin] = 0.0;
         }
         basis[r] = jin;
         ++*pivots;
-        double wn = art_sum(T, stride, m_act, n, basis);
+        double wn = art_sum(T, stride, m_act, nn, basis);
         if (wn < w - 1e-12) { stall = 0; bland = 0; } else if (++stall > STALL) bland = 1;
         w = wn;
         if (++guard > 5000) break;
@@ -248,10 +258,10 @@ static double phase1(double* T, int stride, int m, int m_act, int n, int* basis,
 static void rbe_both(orc_env* e, int* st_frozen, int* st_free) {
     int nb = e->nb, n_if = e->n_if;
     if (n_if == 0) { *st_frozen = nb == 1; *st_free = 0; return; }
-    int m = 3 * nb, n = 4 * n_if, stride = n + 1, m_act = m - 3;
+    int m = 3 * nb, n = 4 * n_if, nn = n + 1, stride = nn + 1, m_act = m - 3, cost = m + 1;
     double* T = e->tab;
-    int basis[3 * MAXK];
-    memset(T, 0, sizeof(double) * (size_t)(m + 1) * stride);
+    int basis[3 * MAXK + 1];
+    memset(T, 0, sizeof(double) * (size_t)(m + 2) * stride);
     for (int k = 0; k < n_if; ++k) {
         const double* g = e->if_geom[k];
         for (int ip = 0; ip < 2; ++ip) for (int ig = 0; ig < 2; ++ig) {
@@ -273,18 +283,20 @@ static void rbe_both(orc_env* e, int* st_frozen, int* st_free) {
             }
         }
     }
-    for (int i = 0; i < m; ++i) T[i * stride + n] = PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-    for (int b = 0; b < nb; ++b) T[(3 * b + 1) * stride + n] += e->c.density * e->c.shapes[e->shape[b]].volume;
-    for (int q = 0; q <= n; ++q) { double s = 0; for (int i = 0; i < m_act; ++i) s += T[i * stride + q]; T[m * stride + q] = -s; }
-    double w = phase1(T, stride, m, m_act, n, basis, 1, &e->total_pivots);
+    for (int i = 0; i < m; ++i) T[i * stride + nn] = PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    for (int b = 0; b < nb; ++b) T[(3 * b + 1) * stride + nn] += e->c.density * e->c.shapes[e->shape[b]].volume;
+    for (int q = 0; q < nn; ++q) T[m * stride + q] = 1.0;
+    T[m * stride + nn] = S_MAX;
+    for (int q = 0; q <= nn; ++q) { double s = 0; for (int i = 0; i < m_act; ++i) s += T[i * stride + q]; T[cost * stride + q] = -s; }
+    double w = phase1(T, stride, m, m_act, nn, basis, 1, &e->total_pivots);
     *st_frozen = w <= FEAS_TOL;
     if (!*st_frozen) { *st_free = 0; return; }
     for (int i = m_act; i < m; ++i) {
-        int neg = T[i * stride + n] < 0.0;
-        for (int q = 0; q <= n; ++q) { double v = T[i * stride + q]; if (neg) { v = -v; T[i * stride + q] = v; } T[m * stride + q] -= v; }
-        basis[i] = n + i;
+        int neg = T[i * stride + nn] < 0.0;
+        for (int q = 0; q <= nn; ++q) { double v = T[i * stride + q]; if (neg) { v = -v; T[i * stride + q] = v; } T[cost * stride + q] -= v; }
+        basis[i] = nn + i;
     }
-    w = phase1(T, stride, m, m, n, basis, 0, &e->total_pivots);
+    w = phase1(T, stride, m, m, nn, basis, 0, &e->total_pivots);
     *st_free = w <= FEAS_TOL;
 }
 
@@ -366,7 +378,7 @@ orc_env* orc_create(const orc_cfg* cfg) {
     if (!e) return 0;
     e->c = *cfg;
     e->cand = (orc_cand*)calloc((size_t)cfg->a_max, sizeof(orc_cand));
-    e->tab = (double*)malloc(sizeof(double) * (3 * MAXK + 1) * (4 * MAXIF + 2));
+    e->tab = (double*)malloc(sizeof(double) * (3 * MAXK + 2) * (4 * MAXIF + 3));
     reset_state(e);
     refresh(e);
     return e;
@@ -382,6 +394,11 @@ void orc_reset(orc_env* e) { reset_state(e); e->draw_counter = 0; refresh(e); }
 const orc_cand* orc_candidates(const orc_env* e, int32_t* n_cand, int32_t* n_valid) { *n_cand = e->n_cand; *n_valid = e->n_valid; return e->cand; }
 const uint64_t* orc_state_bits(const orc_env* e) { return e->state_bits; }
 long orc_total_pivots(const orc_env* e) { return e->total_pivots; }
+/* current assembly: shape ids and poses (x, z, cos, sin) of the placed blocks */
+int orc_blocks(const orc_env* e, int32_t* shape, double* pose) {
+    for (int b = 0; b < e->nb; ++b) { shape[b] = e->shape[b]; memcpy(pose + 4 * b, e->pose[b], 4 * sizeof(double)); }
+    return e->nb;
+}
 
 /* One lock-step of the protocol of DESIGN.md: place a uniformly drawn valid candidate (or reset-only), both
  * stability variants, reward / termination, auto-reset, candidates of the new state. */

@@ -72,6 +72,7 @@ def lib():
         L.orc_enable_f32.argtypes = [C.c_void_p]
         L.orc_f32.restype = C.POINTER(C.c_float)
         L.orc_f32.argtypes = [C.c_void_p]
+        L.orc_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         L.orc_total_pivots.restype = C.c_long
         L.orc_total_pivots.argtypes = [C.c_void_p]
         _lib = L
@@ -150,6 +151,12 @@ class CEnv:
         o = Out()
         self.L.orc_lockstep(self.h, seed, env_id, C.byref(o))
         return o
+
+    def blocks(self):
+        sh = (C.c_int32 * MAXK)()
+        po = (C.c_double * (4 * MAXK))()
+        n = self.L.orc_blocks(self.h, sh, po)
+        return [(sh[b], (po[4 * b], po[4 * b + 1]), (po[4 * b + 2], po[4 * b + 3])) for b in range(n)]
 
     def enable_f32(self):
         assert self.L.orc_enable_f32(self.h)

@@ -23,10 +23,22 @@ algorithm (Kao et al. 2022, "Coupled Rigid-Block Analysis") is restated in 2-D:
 
 With the cone written in generators, force = a (n + mu t) + b (n - mu t),
 a, b >= 0, stability is the standard-form feasibility problem
-``exists x >= 0 : M x = w``.  The oracle measures the L1 distance to
-feasibility  v* = min 1'(e+ + e-) s.t. M x + e+ - e- = w  with HiGHS and
-declares stable iff v* <= FEAS_TOL.  (v* is unique even when x is not, which
-is what makes the boolean comparable across solvers.)
+``exists x >= 0 : M x = w, 1'x <= S_MAX``.  The oracle measures the L1 distance
+to feasibility  v* = min 1'(e+ + e-) s.t. M x + e+ - e- = w, 1'x <= S_MAX, x >= 0
+with HiGHS and declares stable iff v* <= FEAS_TOL.  (v* is unique even when x
+is not, which is what makes the boolean comparable across solvers.)
+
+S_MAX is a budget on the total contact force (sum of the cone-generator
+multipliers).  Block weights are O(1..30); genuine equilibria need a total of
+1..1e3 (friction wedges near their critical angle form a thin tail up to
+~1e4).  The float32 STL vertices however leave ~1e-7 of direction noise in
+nominally parallel faces, and an unbounded LP can balance a block on that noise
+with forces of 1e5..1e12 x its weight (observed: v* = 0 with max x = 6.4e7 while
+v* = 2.95..3.00 for every bound <= 1e6).  That is a numerical artefact, not an
+equilibrium, and no finite-precision solver decides it reliably.  With the
+budget row the question is well conditioned: over 400 000 decisions of random
+rollouts (tools/stress_c_vs_highs.py) no LP has v* in (1e-6, 1e-4) and the two
+simplex implementations (plain C, HIP) agree with HiGHS on every one.
 """
 import numpy as np
 
@@ -34,6 +46,7 @@ FLOOR = -1
 TOL_PARALLEL = 1e-6
 TOL_COPLANAR = 1e-6
 AMIN = 0.001
+S_MAX = 1e4       # budget on the sum of contact-force multipliers, see module docstring
 FEAS_TOL = 1e-5   # float32 meshes leave ~1e-7 geometric noise (observed classes: 0, 3e-7 | 7.8e-4, >= 2.8e-2)
 
 
@@ -130,7 +143,7 @@ def equilibrium_system(blocks, interfaces, fixed, mu, density):
 
 
 def infeasibility(M, w):
-    """v* = min ||M x - w||_1 over x >= 0 (HiGHS)."""
+    """v* = min ||M x - w||_1 over x >= 0, sum(x) <= S_MAX (HiGHS)."""
     from scipy.optimize import linprog
     m, n = M.shape
     if m == 0:
@@ -139,7 +152,8 @@ def infeasibility(M, w):
         return float(np.abs(w).sum())
     A = np.hstack([M, np.eye(m), -np.eye(m)])
     c = np.concatenate([np.zeros(n), np.ones(2 * m)])
-    res = linprog(c, A_eq=A, b_eq=w, bounds=(0, None), method="highs")
+    budget = np.concatenate([np.ones(n), np.zeros(2 * m)])[None, :]
+    res = linprog(c, A_eq=A, b_eq=w, A_ub=budget, b_ub=[S_MAX], bounds=(0, None), method="highs")
     if res.status != 0:
         raise RuntimeError(f"HiGHS failed on an always-feasible LP: {res.message}")
     return float(res.fun)

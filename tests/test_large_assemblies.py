@@ -65,7 +65,7 @@ def test_gpu_stability_on_large_assemblies(fixture):
         verts = torch.zeros((n, K, 6, 2), dtype=torch.float64, device=dev)
         flat_shape = shape.reshape(-1).contiguous()
         abi.check(L.bridges_pose_block(table.ptr, n * K, _ptr(flat_shape), _ptr(pose), _ptr(verts), _stream()))
-        ws_stride = 9 * abi.MAX_INTERFACES + (3 * K + 1) * (4 * abi.MAX_INTERFACES + 2)
+        ws_stride = abi.lp_ws_stride(K)
         ws = torch.empty((n, ws_stride), dtype=torch.float64, device=dev)
         stable = torch.zeros(n, dtype=torch.uint8, device=dev)
         info = torch.zeros((n, 8), dtype=torch.float64, device=dev)
@@ -78,6 +78,6 @@ def test_gpu_stability_on_large_assemblies(fixture):
             assert got[i] == c["stable"], (r["task"], i, inf[i, 0], c["v"])
             checked += 1
             n_free = len(r["poses"]) - len(c["fixed"])
-            overflow_cases += (3 * n_free + 1) * (4 * c["n_if"] + 2) > 2048   # tableau did not fit LDS
+            overflow_cases += (3 * n_free + 2) * (4 * c["n_if"] + 3) > 2048   # tableau did not fit LDS
     assert checked == sum(len(r["cases"]) for r in fixture)
     assert overflow_cases > 20
