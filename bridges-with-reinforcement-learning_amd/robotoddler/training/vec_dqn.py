@@ -36,7 +36,7 @@ class VecDQN:
         self.explore_gen = torch.Generator(device=self.device).manual_seed(7654321 + seed * 1000 + rank)
         self.epsilon, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.step_images = torch.zeros((env.K + 1, 64, 64), dtype=torch.float32, device=self.device)
-        # scratch env used to rebuild the candidate sets of sampled next states
+        # scratch env used to rebuild the candidate sets of sampled next states (see _replay_env)
         self.replay_env = VecAssemblyGym(batch_size, env.shapes, env.obstacles, env.targets, max_steps=env.max_steps,
                                          mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
                                          ylim=env.ylim, x_discr_ground=env.x_discr_ground,
@@ -112,52 +112,87 @@ class VecDQN:
         rec, valid = R.make_records(env, snap, sel_rows)
         return rec, valid
 
-    # ------------------------------------------------------------------ one gradient step on a sampled batch
-    def train_step(self):
-        if len(self.ring) < self.B:
-            return None
-        rec = self.ring.sample(self.B, self.sample_gen)
-        renv, K = self.replay_env, self.replay_env.K
-        (nb, shape, pose, occ), (nnb, nshape, npose, nocc) = R.unpack_states(rec, K)
-        with torch.no_grad():
-            # state s: raster of its blocks; action raster = the placed block
-            renv.load_states(nb, shape, pose, occ)
-            block_f = renv.state_raster.clone().unsqueeze(1)
-            # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout
-            renv.load_states(nnb, nshape, npose, nocc)
-            next_state = renv.state_raster
-            action_f = (next_state - block_f.squeeze(1)).clamp_(0, 1).unsqueeze(1)       # s' minus s = the new block
-            idx, row_env = renv.valid_rows()
-            seg, counts = self._segments(row_env, self.B, self.device)
-            done = (rec[:, R.O_DONE] > 0.5) | (counts == 0)
-            use_sf = 'mse_block_features' in self.loss_parts
-            stable_n = rec[:, R.O_STABLE_N] > 0.5
-            if idx.numel():
-                self.target_net.eval()
-                nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
-                if use_sf and nsf is None:
-                    raise ValueError("No successor block features available from the chosen policy net.")
-                q_target, sf_target, _ = dqn_ops.td_target(
-                    seg, nq.contiguous().float(), rec[:, R.O_LIN].float(), done, self.gamma,
-                    next_sf=nsf[:, 0] if use_sf else None,
-                    action_raster=action_f.squeeze(1) if use_sf else None)
-            else:
-                q_target = rec[:, R.O_LIN].float()
-                sf_target = action_f.reshape(self.B, -1) if use_sf else None
-        binary = torch.zeros((self.B, 6), dtype=torch.float32, device=self.device)
-        binary[:, 0] = rec[:, R.O_STABLE_S].float()
+    # ------------------------------------------------------------------ gradient steps on sampled batches
+    def _replay_env(self, n_states):
+        """Scratch env that rebuilds the states / candidate sets of sampled transitions (grown on demand)."""
+        if self.replay_env.E < n_states:
+            env = self.env
+            self.replay_env = VecAssemblyGym(n_states, env.shapes, env.obstacles, env.targets, max_steps=env.max_steps,
+                                             mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
+                                             ylim=env.ylim, x_discr_ground=env.x_discr_ground,
+                                             offset_values=env.offset_values, device=self.device, a_max=env.a_max)
+        return self.replay_env
+
+    @torch.no_grad()
+    def _targets(self, rec):
+        """Inputs and TD targets of the transitions in ``rec`` (train_policy_net, successor_dqn.py:178-213).  The
+        target net is constant during one train_policy_net call (it is only updated afterwards, :704-708), so the
+        targets of all its n_steps batches can be computed in one pass: one state rebuild, one candidate refresh,
+        one target-net forward and one k_td_target launch for n_steps * batch_size transitions."""
+        n = rec.shape[0]
+        renv = self._replay_env(n)
+        K, E = renv.K, renv.E
+        if n < E:                                       # pad with copies of the first record; sliced off below
+            rec_p = torch.cat([rec, rec[:1].expand(E - n, -1)])
+        else:
+            rec_p = rec
+        (nb, shape, pose, occ), (nnb, nshape, npose, nocc) = R.unpack_states(rec_p, K)
+        # state s: raster of its blocks; action raster = the placed block
+        renv.load_states(nb, shape, pose, occ)
+        block_f = renv.state_raster.clone().unsqueeze(1)
+        # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout
+        renv.load_states(nnb, nshape, npose, nocc)
+        action_f = (renv.state_raster - block_f.squeeze(1)).clamp_(0, 1).unsqueeze(1)          # s' minus s = the new block
+        idx, row_env = renv.valid_rows()
+        seg, counts = self._segments(row_env, E, self.device)
+        done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)
+        use_sf = 'mse_block_features' in self.loss_parts
+        stable_n = rec_p[:, R.O_STABLE_N] > 0.5
+        if idx.numel():
+            self.target_net.eval()
+            nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
+            if use_sf and nsf is None:
+                raise ValueError("No successor block features available from the chosen policy net.")
+            q_target, sf_target, _ = dqn_ops.td_target(
+                seg, nq.contiguous().float(), rec_p[:, R.O_LIN].float().contiguous(), done, self.gamma,
+                next_sf=nsf[:, 0] if use_sf else None,
+                action_raster=action_f.squeeze(1) if use_sf else None)
+        else:
+            q_target = rec_p[:, R.O_LIN].float()
+            sf_target = action_f.reshape(E, -1) if use_sf else None
+        binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
+        binary[:, 0] = rec_p[:, R.O_STABLE_S].float()
+        return block_f[:n], binary[:n], action_f[:n], q_target[:n], (sf_target[:n] if use_sf else None)
+
+    def train_steps(self, n_steps):
+        """n_steps optimiser steps on n_steps independently sampled batches; returns the losses (one host sync)."""
+        if len(self.ring) < self.B or n_steps <= 0:
+            return []
+        B = self.B
+        rec = torch.cat([self.ring.sample(B, self.sample_gen) for _ in range(n_steps)])
+        block_f, binary, action_f, q_target, sf_target = self._targets(rec)
+        reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
+        obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
+        use_sf = sf_target is not None
         self.policy_net.train()
-        q, sf, _ = self.policy_net(block_f, binary, action_f, self.env.reward_features.unsqueeze(0).expand(self.B, -1, -1, -1),
-                                   self.env.obstacle_raster.unsqueeze(0).expand(self.B, -1, -1, -1))
-        loss = 0.
-        if 'mse_q_values' in self.loss_parts:
-            loss = loss + self.mse(q, q_target)
-        if use_sf:
-            loss = loss + self.mse(sf[:, 0], sf_target.view_as(sf[:, 0]))
-        self.opt.zero_grad()
-        loss.backward()
-        self.opt.step()
-        return float(loss.item())
+        losses = []
+        for i in range(n_steps):
+            sl = slice(i * B, (i + 1) * B)
+            q, sf, _ = self.policy_net(block_f[sl], binary[sl], action_f[sl], reward, obstacle)
+            loss = 0.
+            if 'mse_q_values' in self.loss_parts:
+                loss = loss + self.mse(q, q_target[sl])
+            if use_sf:
+                loss = loss + self.mse(sf[:, 0], sf_target[sl].view_as(sf[:, 0]))
+            self.opt.zero_grad()
+            loss.backward()
+            self.opt.step()
+            losses.append(loss.detach())
+        return torch.stack(losses).tolist()
+
+    def train_step(self):
+        out = self.train_steps(1)
+        return out[0] if out else None
 
     def update_target(self):
         from robotoddler.training.successor_dqn import update_target_net
@@ -170,7 +205,7 @@ class VecDQN:
         allrec = D.all_gather_records(rec, valid)
         self.ring.push(allrec)
         self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())
-        losses = [l for l in (self.train_step() for _ in range(n_train_steps)) if l is not None]
+        losses = self.train_steps(n_train_steps)
         self.update_target()
         self.epsilon = (self.epsilon - self.eps_end) * self.eps_decay + self.eps_end
         return losses, allrec

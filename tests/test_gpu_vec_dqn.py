@@ -43,15 +43,49 @@ def test_records_rebuild_the_recorded_states():
             assert torch.equal(renv.cand_pose[a:a + n], env.cand_pose[b:b + n])
 
 
-@pytest.mark.parametrize("model,loss", [("SuccessorMLP", "mse_q_values+mse_block_features"), ("ConvNet", "mse_q_values"),
-                                        ("UNet", "mse_block_features")])
-def test_vectorised_training_runs(model, loss):
+TOWER2 = ["--tower_height", "2"]
+HEX_BRIDGE = ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"]       # BASELINE.json configs[4]
+
+
+@pytest.mark.parametrize("model,loss,task", [("SuccessorMLP", "mse_q_values+mse_block_features", TOWER2),
+                                             ("ConvNet", "mse_q_values", TOWER2),
+                                             ("UNet", "mse_block_features", TOWER2),
+                                             ("UNet", "mse_q_values+mse_block_features", HEX_BRIDGE)])
+def test_vectorised_training_runs(model, loss, task):
     from robotoddler.training.successor_dqn import build_parser, main
-    hist = main(["--model", model, "--loss_function", loss, "--tower_height", "2", "--num_envs", "64", "--num_episodes", "150",
+    hist = main(["--model", model, "--loss_function", loss, *task, "--num_envs", "64", "--num_episodes", "150",
                  "--num_training_steps", "2", "--batch_size", "16", "--seed", "1", "--learning_rate", "1e-4"])
     assert hist[-1]["episodes"] >= 150
     losses = [h["avg_loss"] for h in hist if h["avg_loss"] is not None]
     assert losses and all(np.isfinite(losses))
+
+
+def test_batched_targets_equal_per_batch_targets():
+    """train_steps computes the TD targets of all its batches in one pass (the target net is constant meanwhile);
+    the result must be what batch-by-batch evaluation gives."""
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev = torch.device("cuda")
+    env = make_env(128, seed=5)
+    torch.manual_seed(3)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 10000, 16, 0.95, 0.01,
+                   "mse_q_values+mse_block_features")
+    for _ in range(8):
+        rec, valid = agent.act()
+        agent.ring.push(rec[valid])
+    recs = [agent.ring.sample(16, agent.sample_gen) for _ in range(3)]
+    whole = agent._targets(torch.cat(recs))
+    for i, r in enumerate(recs):
+        part = agent._targets(r)
+        sl = slice(16 * i, 16 * (i + 1))
+        for k in range(3):                                   # state raster, binary features, action raster: exact
+            assert torch.equal(whole[k][sl], part[k])
+        assert torch.allclose(whole[3][sl], part[3], rtol=1e-5, atol=1e-5)      # q target (GEMM batch shape differs)
+        assert torch.allclose(whole[4][sl], part[4], rtol=1e-5, atol=1e-5)      # successor-feature target
+    losses = agent.train_steps(3)
+    assert len(losses) == 3 and all(np.isfinite(losses))
 
 
 def test_single_env_reference_loop_runs():

@@ -39,7 +39,7 @@ for _ in range(a.locksteps):
     agent.env_steps += int(valid.sum().item())
     agent.ring.push(rec[valid])
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    losses = [agent.train_step() for _ in range(a.train_steps)]
+    losses = agent.train_steps(a.train_steps)
     agent.update_target()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     t_act += t2 - t1; t_train += t3 - t2
