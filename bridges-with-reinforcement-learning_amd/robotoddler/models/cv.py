@@ -89,6 +89,33 @@ class SuccessorMLP(nn.Module):
         return q_values, succ_block_features, succ_binary_features
 
 
+    @torch.no_grad()
+    def q_values_factored(self, block_features, binary_features, action_features, row_env, reward_features,
+                          obstacle_features):
+        """q of ``forward`` for n candidate rows that share per-environment inputs, without materialising the
+        [n, 4*px+f] input or the [n, 2*px+2f] output (acting needs only q):
+          * first layer: W1 [block | action | reward | obstacle | binary] = (per env: block, binary; constant: reward,
+            obstacle, bias) + (per row: action) -- a quarter of the multiply-adds, no 4-image concatenation;
+          * head: softmax over the two successor channels, channel 1 = sigmoid(psi1 - psi0), so one px-wide product with
+            the row difference of the last layer replaces the 2*px+2f-wide one.
+        Same function as ``forward(...)[0]`` up to float32 summation order.
+        block_features [E,H,W], binary_features [E,f], action_features [n,H,W], row_env [n] (env of each row),
+        reward_features / obstacle_features [H,W] (or any shape with H*W elements)."""
+        lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
+        px = self.img_size[0] * self.img_size[1]
+        E, n = block_features.shape[0], action_features.shape[0]
+        W1, b1 = lin[0].weight, lin[0].bias
+        const = W1[:, 2 * px:3 * px] @ reward_features.reshape(px) + W1[:, 3 * px:4 * px] @ obstacle_features.reshape(px) + b1
+        base = block_features.reshape(E, px) @ W1[:, :px].T + binary_features @ W1[:, 4 * px:].T + const
+        h = torch.addmm(base.index_select(0, row_env), action_features.reshape(n, px), W1[:, px:2 * px].T)
+        h = F.relu(h)
+        for layer in lin[1:-1]:
+            h = F.relu(layer(h))
+        Wo, bo = lin[-1].weight, lin[-1].bias
+        d = torch.addmm(bo[px:2 * px] - bo[:px], h, (Wo[px:2 * px] - Wo[:px]).T)
+        return (torch.sigmoid(d) * reward_features.reshape(1, px)).sum(dim=1)
+
+
 class UNet(nn.Module):
     """Three-level U-Net on the 4 stacked rasters (cv.py:138-254; the deeper levels are disabled there too)."""
 

@@ -42,6 +42,10 @@ class VecDQN:
                                          ylim=env.ylim, x_discr_ground=env.x_discr_ground,
                                          offset_values=env.offset_values, device=self.device, a_max=env.a_max)
         self.mse = torch.nn.MSELoss()
+        for g in optimizer.param_groups:                # step counter on the device: the train step is graph-captured
+            if 'capturable' in g:
+                g['capturable'] = True
+        self._graph_state, self._eager_calls = None, 0
         self.episodes_done = 0
         self.env_steps = 0
 
@@ -70,6 +74,12 @@ class VecDQN:
         return block, binary, action, reward, obstacle
 
     @staticmethod
+    def _factored(net):
+        """Acting through SuccessorMLP.q_values_factored (BRIDGES_FACTORED_ACT=0: the plain module forward)."""
+        import os
+        return hasattr(net, "q_values_factored") and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0"
+
+    @staticmethod
     def _segments(row_env, E, device):
         counts = torch.bincount(row_env, minlength=E)
         seg = torch.zeros(E + 1, dtype=torch.int32, device=device)
@@ -87,12 +97,22 @@ class VecDQN:
         sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
         if idx.numel():
             self.policy_net.eval()
-            q, _, _ = self._forward_rows(self.policy_net, env, idx, row_env, stable)
+            step_of_row = env.n_blocks[row_env].long()
+            if self._factored(self.policy_net):
+                action = env.cand_raster.index_select(0, idx)
+                binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
+                binary[:, 0] = stable.float()
+                q = self.policy_net.q_values_factored(env.state_raster, binary, action, row_env, env.reward_features,
+                                                      env.obstacle_raster)
+                # overlap of every candidate with the count image of its episode step (exact: integer-valued sums)
+                px = action.shape[1] * action.shape[2]
+                join = (action.reshape(-1, px) @ self.step_images.reshape(-1, px).T).gather(1, step_of_row[:, None])[:, 0]
+            else:
+                q, _, _ = self._forward_rows(self.policy_net, env, idx, row_env, stable)
+                join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
             nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
             _, _, arg_q = dqn_ops.td_target(seg, q.contiguous().float(), zeros, nodone, 1.0)       # segmented argmax
-            step_of_row = env.n_blocks[row_env].long()
-            join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
             _, _, arg_x = dqn_ops.td_target(seg, (-join).contiguous(), zeros, nodone, 1.0)          # segmented argmin
             explore = (torch.rand(E, generator=self.explore_gen, device=self.device) <= self.epsilon) & (not greedy)
             sel_row = torch.where(explore, arg_x.long(), arg_q.long())
@@ -164,6 +184,69 @@ class VecDQN:
         binary[:, 0] = rec_p[:, R.O_STABLE_S].float()
         return block_f[:n], binary[:n], action_f[:n], q_target[:n], (sf_target[:n] if use_sf else None)
 
+    def _loss(self, q, sf, q_target, sf_target):
+        loss = 0.
+        if 'mse_q_values' in self.loss_parts:
+            loss = loss + self.mse(q, q_target)
+        if sf_target is not None:
+            loss = loss + self.mse(sf[:, 0], sf_target.view_as(sf[:, 0]))
+        return loss
+
+    def _capture_train_graph(self, n_max, use_sf):
+        """One optimiser step (batch gather, forward, loss, backward, Adam) as a HIP graph.  The batch is gathered
+        inside the graph from the static arrays of all batches of the lock-step by a device-side step counter, so a
+        train step is exactly one graph launch (eager PyTorch needs ~60 launches of a few microseconds of work each
+        and is bound by their launch latency)."""
+        B, dev = self.B, self.device
+        px = self.env.state_raster.shape[-2:]
+        st = dict(block=torch.zeros((n_max * B, 1, *px), device=dev), binary=torch.zeros((n_max * B, 6), device=dev),
+                  action=torch.zeros((n_max * B, 1, *px), device=dev), q=torch.zeros(n_max * B, device=dev),
+                  sf=torch.zeros((n_max * B, px[0] * px[1]), device=dev) if use_sf else None,
+                  counter=torch.zeros((), dtype=torch.int64, device=dev), losses=torch.zeros(n_max, device=dev),
+                  lane=torch.arange(B, device=dev), n_max=n_max, use_sf=use_sf)
+        reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
+        obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
+
+        def body():
+            idx = st["lane"] + st["counter"] * B
+            q, sf, _ = self.policy_net(st["block"].index_select(0, idx), st["binary"].index_select(0, idx),
+                                       st["action"].index_select(0, idx), reward, obstacle)
+            loss = self._loss(q, sf, st["q"].index_select(0, idx), st["sf"].index_select(0, idx) if use_sf else None)
+            loss.backward()
+            self.opt.step()
+            st["losses"].index_copy_(0, st["counter"].view(1), loss.detach().view(1))
+            st["counter"].add_(1)
+
+        self.policy_net.train()
+        self.opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        st["graph"] = graph
+        return st
+
+    def _train_graph(self, n_steps, use_sf):
+        """The captured train step, or None while it is not available: the first calls run eagerly (they initialise the
+        optimiser state and the library workspaces a capture needs), BRIDGES_TRAIN_GRAPH=0 keeps it that way."""
+        import os
+        if os.environ.get("BRIDGES_TRAIN_GRAPH", "1") == "0":
+            return None
+        st = self._graph_state
+        if st is not None and (st["n_max"] < n_steps or st["use_sf"] != use_sf):
+            st = self._graph_state = None                     # more batches per call than captured for: capture again
+        if st is None:
+            if self._eager_calls < 2:
+                self._eager_calls += 1
+                return None
+            try:
+                st = self._graph_state = self._capture_train_graph(n_steps, use_sf)
+            except RuntimeError as e:                         # same arithmetic either way: keep training eagerly
+                import warnings
+                warnings.warn(f"train-step graph capture failed, staying eager: {e}")
+                self._eager_calls = -(1 << 30)
+                return None
+        return st
+
     def train_steps(self, n_steps):
         """n_steps optimiser steps on n_steps independently sampled batches; returns the losses (one host sync)."""
         if len(self.ring) < self.B or n_steps <= 0:
@@ -171,19 +254,26 @@ class VecDQN:
         B = self.B
         rec = torch.cat([self.ring.sample(B, self.sample_gen) for _ in range(n_steps)])
         block_f, binary, action_f, q_target, sf_target = self._targets(rec)
+        use_sf = sf_target is not None
+        st = self._train_graph(n_steps, use_sf)
+        if st is not None:
+            n = n_steps * B
+            st["block"][:n].copy_(block_f); st["binary"][:n].copy_(binary); st["action"][:n].copy_(action_f)
+            st["q"][:n].copy_(q_target)
+            if use_sf:
+                st["sf"][:n].copy_(sf_target.reshape(n, -1))
+            st["counter"].zero_()
+            for _ in range(n_steps):
+                st["graph"].replay()
+            return st["losses"][:n_steps].tolist()
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
-        use_sf = sf_target is not None
         self.policy_net.train()
         losses = []
         for i in range(n_steps):
             sl = slice(i * B, (i + 1) * B)
             q, sf, _ = self.policy_net(block_f[sl], binary[sl], action_f[sl], reward, obstacle)
-            loss = 0.
-            if 'mse_q_values' in self.loss_parts:
-                loss = loss + self.mse(q, q_target[sl])
-            if use_sf:
-                loss = loss + self.mse(sf[:, 0], sf_target[sl].view_as(sf[:, 0]))
+            loss = self._loss(q, sf, q_target[sl], sf_target[sl] if use_sf else None)
             self.opt.zero_grad()
             loss.backward()
             self.opt.step()

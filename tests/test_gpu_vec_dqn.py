@@ -88,6 +88,34 @@ def test_batched_targets_equal_per_batch_targets():
     assert len(losses) == 3 and all(np.isfinite(losses))
 
 
+@pytest.mark.parametrize("model,loss", [("SuccessorMLP", "mse_q_values+mse_block_features"), ("ConvNet", "mse_q_values")])
+def test_graph_captured_train_step_equals_eager(model, loss, monkeypatch):
+    """The HIP-graph train step (third call onwards) performs the same optimiser steps as eager PyTorch."""
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", model]))
+    dev = torch.device("cuda")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", mode)
+        env = make_env(64, seed=7)
+        torch.manual_seed(11)
+        pol, tgt = make_nets(args, dev)
+        agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 10000, 16, 0.95, 0.01, loss, seed=2)
+        losses = []
+        for it in range(6):
+            l, _ = agent.lockstep(3)
+            losses += l
+        assert (agent._graph_state is not None) == (mode == "1")
+        out[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu())
+    assert len(out["1"][0]) == len(out["0"][0]) > 6
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-4, atol=1e-6)
+    # MIOpen's convolution backward is not bit-reproducible between runs and Adam turns a rounding-level gradient
+    # difference of a near-zero gradient into a step of up to lr: the conv net gets 15 steps x lr of slack
+    atol = 1e-6 if model == "SuccessorMLP" else 15 * 1e-4
+    assert torch.allclose(out["1"][1], out["0"][1], rtol=1e-4, atol=atol)
+
+
 def test_single_env_reference_loop_runs():
     from robotoddler.training.successor_dqn import main
     hist = main(["--model", "SuccessorMLP", "--loss_function", "mse_q_values+mse_block_features", "--tower_height", "2",

@@ -15,7 +15,8 @@ ap.add_argument("--tower", type=int, default=4)
 ap.add_argument("--max_steps", type=int, default=15)
 ap.add_argument("--model", default="SuccessorMLP")
 ap.add_argument("--loss", default="mse_block_features")
-ap.add_argument("--locksteps", type=int, default=20)
+ap.add_argument("--locksteps", type=int, default=30)
+ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--train_steps", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
 a = ap.parse_args()
@@ -28,11 +29,12 @@ torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
-for i in range(3):
+for i in range(a.warmup):
     agent.lockstep(a.train_steps)
     print("warm-up lock-step", i, "done", flush=True)
 torch.cuda.synchronize(); s0 = agent.env_steps; t0 = time.perf_counter()
 t_act = t_train = 0.0
+per_step = []
 for _ in range(a.locksteps):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     rec, valid = agent.act()
@@ -43,8 +45,12 @@ for _ in range(a.locksteps):
     agent.update_target()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     t_act += t2 - t1; t_train += t3 - t2
+    per_step.append(t3 - t1)
     print("lock-step", _, round((t3 - t1) * 1e3, 1), "ms", flush=True)
 dt = time.perf_counter() - t0
-print(json.dumps(dict(config=vars(a), env_steps_per_s=(agent.env_steps - s0) / dt, ms_per_lockstep=dt / a.locksteps * 1e3,
+per_step.sort()
+median = per_step[len(per_step) // 2]
+print(json.dumps(dict(config=vars(a), env_steps_per_s=(agent.env_steps - s0) / dt,
+                      env_steps_per_s_at_median_lockstep=(agent.env_steps - s0) / a.locksteps / median, ms_median_lockstep=median * 1e3, ms_per_lockstep=dt / a.locksteps * 1e3,
                       ms_act=t_act / a.locksteps * 1e3, ms_train=t_train / a.locksteps * 1e3,
                       ms_per_train_step=t_train / a.locksteps / a.train_steps * 1e3, last_loss=losses[-1])))
