@@ -49,18 +49,21 @@ class VecDQN:
         self.episodes_done = 0
         self.env_steps = 0
 
-    ROW_BUCKET = 1024      # conv nets: MIOpen tunes per input shape, so row counts are padded to a few sizes
+    ROW_CHUNK = 2048       # rows per forward call: ONE input shape for the whole run (MIOpen tunes per shape)
 
     def _forward_rows(self, net, env, idx, row_env, stable_flag):
-        """net(...) over the candidate rows, with the row count padded to a multiple of ROW_BUCKET (the padding
-        repeats row 0 and is sliced off), so that the convolution shapes repeat from lock-step to lock-step."""
-        n = idx.numel()
-        pad = (-n) % self.ROW_BUCKET
+        """net(...) over the candidate rows in chunks of ROW_CHUNK rows; the last chunk is padded with copies of row 0
+        (sliced off again), so the convolution / GEMM shapes never change from lock-step to lock-step."""
+        n, C = idx.numel(), self.ROW_CHUNK
+        pad = (-n) % C
         if pad:
             idx = torch.cat([idx, idx[:1].expand(pad)])
             row_env = torch.cat([row_env, row_env[:1].expand(pad)])
-        q, sf, sb = net(*self._row_features(env, idx, row_env, stable_flag))
-        return q[:n], (sf[:n] if sf is not None else None), (sb[:n] if sb is not None else None)
+        outs = [net(*self._row_features(env, idx[o:o + C], row_env[o:o + C], stable_flag)) for o in range(0, n + pad, C)]
+        q = torch.cat([o[0] for o in outs])[:n]
+        sf = torch.cat([o[1] for o in outs])[:n] if outs[0][1] is not None else None
+        sb = torch.cat([o[2] for o in outs])[:n] if outs[0][2] is not None else None
+        return q, sf, sb
 
     # ------------------------------------------------------------------ features of the rows a net is fed
     def _row_features(self, env, idx, row_env, stable_flag):
@@ -202,7 +205,8 @@ class VecDQN:
         st = dict(block=torch.zeros((n_max * B, 1, *px), device=dev), binary=torch.zeros((n_max * B, 6), device=dev),
                   action=torch.zeros((n_max * B, 1, *px), device=dev), q=torch.zeros(n_max * B, device=dev),
                   sf=torch.zeros((n_max * B, px[0] * px[1]), device=dev) if use_sf else None,
-                  counter=torch.zeros((), dtype=torch.int64, device=dev), losses=torch.zeros(n_max, device=dev),
+                  counter=torch.zeros((), dtype=torch.int64, device=dev),
+                  losses=torch.zeros(n_max, device=dev),
                   lane=torch.arange(B, device=dev), n_max=n_max, use_sf=use_sf)
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
@@ -212,9 +216,9 @@ class VecDQN:
             q, sf, _ = self.policy_net(st["block"].index_select(0, idx), st["binary"].index_select(0, idx),
                                        st["action"].index_select(0, idx), reward, obstacle)
             loss = self._loss(q, sf, st["q"].index_select(0, idx), st["sf"].index_select(0, idx) if use_sf else None)
+            st["losses"].index_copy_(0, st["counter"].view(1), loss.detach().view(1))
             loss.backward()
             self.opt.step()
-            st["losses"].index_copy_(0, st["counter"].view(1), loss.detach().view(1))
             st["counter"].add_(1)
 
         self.policy_net.train()
@@ -226,10 +230,14 @@ class VecDQN:
         return st
 
     def _train_graph(self, n_steps, use_sf):
-        """The captured train step, or None while it is not available: the first calls run eagerly (they initialise the
-        optimiser state and the library workspaces a capture needs), BRIDGES_TRAIN_GRAPH=0 keeps it that way."""
+        """The captured train step, or None.  EXPERIMENTAL, opt-in with BRIDGES_TRAIN_GRAPH=1: on ROCm 7.2 the replayed
+        graph trains correctly (weights equal the eager run) but at 4096 envs x 25 steps the recorded loss values of
+        some lock-steps come back as stale memory (negative "MSE"), sensitive to host synchronisation and absent
+        under AMD_SERIALIZE_KERNEL=3 -- an ordering problem of graph launches this code cannot rule out for other
+        buffers, so eager stays the default.  The first calls always run eagerly (they initialise the optimiser state
+        and the library workspaces a capture needs)."""
         import os
-        if os.environ.get("BRIDGES_TRAIN_GRAPH", "1") == "0":
+        if os.environ.get("BRIDGES_TRAIN_GRAPH", "0") != "1":
             return None
         st = self._graph_state
         if st is not None and (st["n_max"] < n_steps or st["use_sf"] != use_sf):
@@ -321,7 +329,7 @@ def run_vectorised(args, device):
                          seed=seed * 1000003 + rank, device=device, env_id_base=rank * args['num_envs'])
     torch.manual_seed(seed)                                    # identical initial weights on every rank
     policy_net, target_net = make_nets(args, device)
-    opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'])
+    opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'], fused=True)    # one launch for all tensors
     capacity = max(args['replay_buffer_capacity'], 4 * args['num_envs'] * world)
     agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],
                    args['loss_function'], seed=seed, rank=rank)

@@ -88,9 +88,12 @@ def test_batched_targets_equal_per_batch_targets():
     assert len(losses) == 3 and all(np.isfinite(losses))
 
 
-@pytest.mark.parametrize("model,loss", [("SuccessorMLP", "mse_q_values+mse_block_features"), ("ConvNet", "mse_q_values")])
-def test_graph_captured_train_step_equals_eager(model, loss, monkeypatch):
-    """The HIP-graph train step (third call onwards) performs the same optimiser steps as eager PyTorch."""
+@pytest.mark.parametrize("model,loss,E,n_steps,locksteps", [("SuccessorMLP", "mse_q_values+mse_block_features", 64, 3, 6),
+                                                            ("ConvNet", "mse_q_values", 64, 3, 6)])
+def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, locksteps, monkeypatch):
+    """The opt-in HIP-graph train step (BRIDGES_TRAIN_GRAPH=1, third call onwards) performs the same optimiser steps
+    as eager PyTorch at this size.  (At 4096 envs x 25 steps its recorded losses are unreliable on ROCm 7.2 -- see
+    VecDQN._train_graph -- which is why it is not the default.)"""
     from robotoddler.training.successor_dqn import build_parser, make_nets
     from robotoddler.training.vec_dqn import VecDQN
     args = vars(build_parser().parse_args(["--model", model]))
@@ -98,17 +101,19 @@ def test_graph_captured_train_step_equals_eager(model, loss, monkeypatch):
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", mode)
-        env = make_env(64, seed=7)
+        env = make_env(E, seed=7, tower=4 if E > 64 else 2, max_steps=15 if E > 64 else 10)
         torch.manual_seed(11)
         pol, tgt = make_nets(args, dev)
-        agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 10000, 16, 0.95, 0.01, loss, seed=2)
+        agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True), env, 100000, 32 if E > 64 else 16,
+                       0.95, 0.01, loss, seed=2)
         losses = []
-        for it in range(6):
-            l, _ = agent.lockstep(3)
+        for it in range(locksteps):
+            l, _ = agent.lockstep(n_steps)
             losses += l
         assert (agent._graph_state is not None) == (mode == "1")
         out[mode] = (np.array(losses), torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu())
-    assert len(out["1"][0]) == len(out["0"][0]) > 6
+    assert len(out["1"][0]) == len(out["0"][0]) == n_steps * locksteps
+    assert (out["1"][0] >= 0).all()
     np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-4, atol=1e-6)
     # MIOpen's convolution backward is not bit-reproducible between runs and Adam turns a rounding-level gradient
     # difference of a near-zero gradient into a step of up to lr: the conv net gets 15 steps x lr of slack

@@ -19,6 +19,7 @@ ap.add_argument("--locksteps", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--train_steps", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--no_fused_adam", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 args = vars(build_parser().parse_args(["--model", a.model, "--loss_function", a.loss, "--learning_rate", "1e-4"]))
@@ -27,11 +28,19 @@ env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i 
                      [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev)
 torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
-opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
 for i in range(a.warmup):
     agent.lockstep(a.train_steps)
     print("warm-up lock-step", i, "done", flush=True)
+t_targets = [0.0]
+_orig_targets = agent._targets
+def _timed_targets(rec):
+    torch.cuda.synchronize(); ta = time.perf_counter()
+    out = _orig_targets(rec)
+    torch.cuda.synchronize(); t_targets[0] += time.perf_counter() - ta
+    return out
+agent._targets = _timed_targets
 torch.cuda.synchronize(); s0 = agent.env_steps; t0 = time.perf_counter()
 t_act = t_train = 0.0
 per_step = []
@@ -52,5 +61,5 @@ per_step.sort()
 median = per_step[len(per_step) // 2]
 print(json.dumps(dict(config=vars(a), env_steps_per_s=(agent.env_steps - s0) / dt,
                       env_steps_per_s_at_median_lockstep=(agent.env_steps - s0) / a.locksteps / median, ms_median_lockstep=median * 1e3, ms_per_lockstep=dt / a.locksteps * 1e3,
-                      ms_act=t_act / a.locksteps * 1e3, ms_train=t_train / a.locksteps * 1e3,
+                      ms_act=t_act / a.locksteps * 1e3, ms_targets=t_targets[0] / a.locksteps * 1e3, ms_train=t_train / a.locksteps * 1e3,
                       ms_per_train_step=t_train / a.locksteps / a.train_steps * 1e3, last_loss=losses[-1])))
