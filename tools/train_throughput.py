@@ -1,6 +1,7 @@
 """Training-in-the-loop throughput of the vectorised successor-DQN (reported separately from the simulator bench)."""
 import argparse, json, os, sys, time
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+if "--miopen_search" not in sys.argv:
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
 import torch
@@ -20,14 +21,20 @@ ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--train_steps", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--no_fused_adam", action="store_true")
+ap.add_argument("--miopen_search", action="store_true", help="let MIOpen benchmark its algorithms (one shape per run)")
+ap.add_argument("--channels_last", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if a.miopen_search:
+    torch.backends.cudnn.benchmark = True
 args = vars(build_parser().parse_args(["--model", a.model, "--loss_function", a.loss, "--learning_rate", "1e-4"]))
 H = 0.8
 env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(a.tower)],
                      [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev)
 torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
+if a.channels_last:
+    pol, tgt = pol.to(memory_format=torch.channels_last), tgt.to(memory_format=torch.channels_last)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
 for i in range(a.warmup):
