@@ -1,6 +1,6 @@
 """Large randomized parity run: the HIP lock-step environment against the plain-C oracle (oracle/c), env by env and
 step by step -- selected action, both stability booleans, reward, termination, candidate / valid counts, state raster.
-    python tools/stress_parity.py --envs 1024 --locksteps 100 [--task tower4|tower2|hexbridge|mixed]"""
+    python tools/stress_parity.py --envs 1024 --locksteps 100 [--task tower4|tower2|hexbridge|mixed|bridge_mu05]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
@@ -19,7 +19,8 @@ a = ap.parse_args()
 TASKS = dict(tower4=(bridge_setup, dict(num_stories=4), ["trapezoid"], 15, 0.8),
              tower2=(bridge_setup, dict(num_stories=2), ["trapezoid"], 10, 0.8),
              hexbridge=(horizontal_bridge_setup, dict(num_obstacles=3, trapezoid=False, hexagon=True), ["hexagon"], 15, 0.8),
-             mixed=(horizontal_bridge_setup, dict(num_obstacles=4, trapezoid=True, hexagon=True), ["trapezoid", "hexagon"], 12, 2.0))
+             mixed=(horizontal_bridge_setup, dict(num_obstacles=4, trapezoid=True, hexagon=True), ["trapezoid", "hexagon"], 12, 2.0),
+             bridge_mu05=(horizontal_bridge_setup, dict(num_obstacles=5), ["trapezoid"], 15, 0.5))
 fn, kw, names, max_steps, mu = TASKS[a.task]
 setup = fn(**kw)
 vec = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], setup["obstacles"], setup["targets"],
