@@ -334,9 +334,15 @@ def run_vectorised(args, device):
     agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],
                    args['loss_function'], seed=seed, rank=rank)
     history, t0, it = [], time.time(), 0
+    next_ckpt = args['checkpoint_every']
     while agent.episodes_done < args['num_episodes']:
         losses, rec = agent.lockstep(args['num_training_steps'])
         it += 1
+        if args.get('save_checkpoint') and rank == 0 and agent.episodes_done >= next_ckpt:     # utils.py:54-89 layout
+            from robotoddler.utils.utils import save_checkpoint
+            save_checkpoint(args['save_checkpoint'], policy_net, target_net, agent.ring, opt, agent.episodes_done,
+                            {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in args.items()})
+            next_ckpt = (agent.episodes_done // args['checkpoint_every'] + 1) * args['checkpoint_every']
         if it % 100 == 0:
             D.broadcast_module(policy_net)
             D.broadcast_module(target_net)

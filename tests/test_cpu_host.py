@@ -125,6 +125,21 @@ def test_records_roundtrip_and_ring():
     assert s.shape == (3, R.RECORD_WIDTH)
 
 
+def test_ring_checkpoint_roundtrip(tmp_path):
+    """The device ring takes ReplayBuffer's place in save_checkpoint / load_checkpoint (utils.py:54-89)."""
+    from robotoddler.training import records as R
+    ring = R.ReplayRing(7, torch.device("cpu"))
+    for start in (0, 4, 8):
+        ring.push(torch.arange(start, start + 4, dtype=torch.float64)[:, None].expand(4, R.RECORD_WIDTH).clone())
+    ring.save(str(tmp_path / "replay_buffer.pt"))
+    other = R.ReplayRing(7, torch.device("cpu"))
+    other.load(str(tmp_path / "replay_buffer.pt"))
+    assert len(other) == 7 and other.data[:7, 0].tolist() == [5.0, 6.0, 7.0, 8.0, 9.0, 10.0, 11.0]     # oldest first
+    small = R.ReplayRing(3, torch.device("cpu"))
+    small.load(str(tmp_path / "replay_buffer.pt"))
+    assert sorted(small.data[:, 0].tolist()) == [9.0, 10.0, 11.0]                                     # keeps the newest
+
+
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path[:0] = [%r, %r]

@@ -121,6 +121,19 @@ def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, lockste
     assert torch.allclose(out["1"][1], out["0"][1], rtol=1e-4, atol=atol)
 
 
+def test_vectorised_loop_writes_reference_layout_checkpoints(tmp_path):
+    import json, os
+    from robotoddler.training.successor_dqn import main
+    main(["--model", "SuccessorMLP", "--loss_function", "mse_q_values", "--tower_height", "2", "--num_envs", "64",
+          "--num_episodes", "120", "--num_training_steps", "1", "--batch_size", "8", "--seed", "0", "--learning_rate", "1e-4",
+          "--save_checkpoint", str(tmp_path), "--checkpoint_every", "50"])
+    latest = os.path.realpath(tmp_path / "latest")
+    assert sorted(os.listdir(latest)) == ["meta.json", "optimizer.pt", "policy_net.pt", "replay_buffer.pt", "target_net.pt"]
+    assert json.load(open(os.path.join(latest, "meta.json")))["episode"] >= 50
+    blob = torch.load(os.path.join(latest, "replay_buffer.pt"), weights_only=True)
+    assert blob["records"].shape[0] > 0
+
+
 def test_single_env_reference_loop_runs():
     from robotoddler.training.successor_dqn import main
     hist = main(["--model", "SuccessorMLP", "--loss_function", "mse_q_values+mse_block_features", "--tower_height", "2",
