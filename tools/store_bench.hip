@@ -76,6 +76,63 @@ template <int PARTS> __global__ __launch_bounds__(256) void kG(float* out, long 
 #pragma unroll
     for (int r = 0; r < 16 / PARTS; ++r) st<false>(p + r * 256 + lane * 4, z);
 }
+// H: non-persistent, a 256-thread block owns 4 consecutive items: every wave does the per-item prologue of G for ITS item,
+// the results meet in LDS, then the block writes the 64 KiB of its 4 items in linear order (4 KiB per store step)
+__global__ __launch_bounds__(256) void kH(float* out, long items, const int* meta) {
+    __shared__ unsigned long long bits[4][64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6; long it = (long)blockIdx.x * 4 + w;
+    int m = meta[it & 1023];
+    double acc = lane * 0.5 + m;
+    for (int i = 0; i < 300; ++i) acc = acc * 1.0000001 + 0.5;
+    bits[w][lane] = (acc > 1e300) ? ~0ull : (unsigned long long)lane;
+    __syncthreads();
+    float* p = out + (size_t)blockIdx.x * 4 * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int e = r * 1024 + threadIdx.x * 4;                 // element index inside the block's 64 KiB
+        unsigned long long b = bits[e >> 12][(e >> 6) & 63];
+        unsigned nib = (unsigned)(b >> (e & 63)) & 15u;
+        f32x4 z = {(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        st<false>(p + e, z);
+    }
+}
+// I: like D (wave per item, prologue of G) but the expansion reads its bits from LDS like H (isolates the store order)
+__global__ __launch_bounds__(256) void kI(float* out, long items, const int* meta) {
+    __shared__ unsigned long long bits[4][64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6; long it = (long)blockIdx.x * 4 + w;
+    int m = meta[it & 1023];
+    double acc = lane * 0.5 + m;
+    for (int i = 0; i < 300; ++i) acc = acc * 1.0000001 + 0.5;
+    bits[w][lane] = (acc > 1e300) ? ~0ull : (unsigned long long)lane;
+    float* p = out + (size_t)it * 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int e = r * 256 + lane * 4;
+        unsigned long long b = bits[w][(e >> 6) & 63];
+        unsigned nib = (unsigned)(b >> (e & 63)) & 15u;
+        f32x4 z = {(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        st<false>(p + e, z);
+    }
+}
+// J: expansion-only kernel: one wave per 16/PARTS KiB piece in linear order; the piece's 64/PARTS row masks come through
+// scalar loads (wave-uniform address) from a bit-packed array written by an earlier kernel
+template <int PARTS> __global__ __launch_bounds__(256) void kJ(float* out, long pieces, const unsigned long long* bits) {
+    const int lane = threadIdx.x & 63;
+    const long pc = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (pc >= pieces) return;
+    constexpr int ROWS = 64 / PARTS;                         // rows of this piece, 4 per store
+    const unsigned long long* b = bits + pc * ROWS;           // uniform
+    float* p = out + pc * (4096 / PARTS);
+    const int sub = lane >> 4, col4 = (lane & 15) * 4;
+#pragma unroll
+    for (int r = 0; r < ROWS; r += 4) {
+        unsigned long long m0 = b[r], m1 = b[r + 1], m2 = b[r + 2], m3 = b[r + 3];
+        unsigned long long m = sub == 0 ? m0 : (sub == 1 ? m1 : (sub == 2 ? m2 : m3));
+        unsigned nib = (unsigned)(m >> col4) & 15u;
+        f32x4 z = {(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        st<false>(p + (r / 4) * 256 + lane * 4, z);
+    }
+}
 template <typename F> void run(const char* name, F launch, float* buf, int items) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -112,6 +169,14 @@ int main() {
     run("G 16 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
     run("G 4 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<4>, dim3(items), dim3(256), 0, 0, buf, (long)items * 4, meta); }, buf, items);
     run("G 1 KiB + load + ALU", [&] { hipLaunchKernelGGL(kG<16>, dim3(items * 4), dim3(256), 0, 0, buf, (long)items * 16, meta); }, buf, items);
+    run("H block of 4 items, linear", [&] { hipLaunchKernelGGL(kH, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
+    run("I wave per item, LDS bits", [&] { hipLaunchKernelGGL(kI, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
+    run("D wave per item (again)", [&] { hipLaunchKernelGGL(kD<false>, dim3(items / 4), dim3(256), 0, 0, buf, items); }, buf, items);
+    unsigned long long* bitsd; CHECK(hipMalloc(&bitsd, (size_t)items * 512)); CHECK(hipMemset(bitsd, 0x11, (size_t)items * 512));
+    run("J expand 1 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<16>, dim3(items * 16 / 4), dim3(256), 0, 0, buf, (long)items * 16, bitsd); }, buf, items);
+    run("J expand 2 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<8>, dim3(items * 8 / 4), dim3(256), 0, 0, buf, (long)items * 8, bitsd); }, buf, items);
+    run("J expand 4 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<4>, dim3(items * 4 / 4), dim3(256), 0, 0, buf, (long)items * 4, bitsd); }, buf, items);
+    run("J expand 16 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, bitsd); }, buf, items);
     run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
     return 0;
 }
