@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
     ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
+    ap.add_argument("--sparse-raster-update", action="store_true",
+                    help="f32 rasters, but only the row groups that change are stored (reported as its own mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +129,8 @@ def main():
     obstacles = [(0.5, 0.0, i * H + H / 2) for i in range(args.tower_height)]
     env = VecAssemblyGymGroups(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
                                groups=args.groups, max_steps=args.max_steps, seed=args.seed * 1000003 + rank,
-                               device=dev, f32_rasters=not args.no_f32_rasters, debug=args.debug)
+                               device=dev, f32_rasters=not args.no_f32_rasters, debug=args.debug,
+                               sparse_raster_update=args.sparse_raster_update)
     lockstep = env.lockstep_random
 
     for _ in range(args.warmup):
@@ -196,6 +199,8 @@ def main():
                 "workload": "%d envs/GPU lock-step, bridge_setup(num_stories=%d), trapezoid, max_steps=%d, "
                             "uniform-random policy, %s" % (args.envs, args.tower_height, args.max_steps,
                                                            "bit-packed rasters only" if args.no_f32_rasters
+                                                           else "f32 64x64 rasters for every raw candidate, sparse row-group update"
+                                                           if args.sparse_raster_update
                                                            else "f32 64x64 rasters for every raw candidate"),
                 "envs_per_gpu": args.envs, "groups": args.groups, "tower_height": args.tower_height, "max_steps": args.max_steps,
                 "mean_raw_candidates": d["sum_cand"] / max(units, 1),

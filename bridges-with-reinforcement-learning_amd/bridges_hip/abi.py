@@ -98,6 +98,8 @@ ENV_BUFFER_FIELDS = [
     ("cand_bits", "int64", "C,64"),
     ("cand_raster", "float32", "C,64,64"),
     ("state_raster", "float32", "E,64,64"),
+    ("cand_raster_nz", "int32", "C"),
+    ("state_raster_nz", "int32", "E"),
     ("obstacle_bits", "int64", "64"),
     ("reward_map", "float32", "64,64"),
     ("lp_ws", "float64", "E,WS"),

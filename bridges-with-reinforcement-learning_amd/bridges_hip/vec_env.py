@@ -79,7 +79,8 @@ def raster_posed(table, verts, shape_ids, grid_x, grid_y, want_bits=True, want_f
 class VecAssemblyGym:
     def __init__(self, num_envs, shapes, obstacles, targets, max_steps=None, mu=0.8, density=1.0, bounds=None,
                  xlim=(-3.0, 7.0), ylim=(0.0, 10.0), x_discr_ground=None, offset_values=(0.0,), seed=0,
-                 device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64), debug=0, env_id_base=0):
+                 device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64), debug=0, env_id_base=0,
+                 sparse_raster_update=False):
         L = abi.require_gpu()
         if tuple(img_size) != (64, 64):
             raise NotImplementedError("the HIP rasteriser is built for 64x64 images (successor_dqn.py:585 default)")
@@ -117,6 +118,7 @@ class VecAssemblyGym:
         bound = len(self.groups) * (len(self.x_discr_ground) + self.K * max_faces * len(self.offset_values))
         self.a_max = int(a_max) if a_max else bound
         self.f32_rasters = bool(f32_rasters)
+        self.sparse_raster_update = bool(sparse_raster_update)
         self.grid_x = np.linspace(self.xlim[0], self.xlim[1], 64)          # rendering.py:108
         self.grid_y = np.linspace(self.ylim[1], self.ylim[0], 64)
         self._alloc()
@@ -132,6 +134,9 @@ class VecAssemblyGym:
         self.buf = {}
         for name, dt, shape in abi.ENV_BUFFER_FIELDS:
             if name in ("cand_raster", "state_raster") and not self.f32_rasters:
+                self.buf[name] = None
+                continue
+            if name in ("cand_raster_nz", "state_raster_nz") and not (self.f32_rasters and self.sparse_raster_update):
                 self.buf[name] = None
                 continue
             shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))

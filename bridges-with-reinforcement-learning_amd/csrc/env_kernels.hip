@@ -349,9 +349,36 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
 
 // ---------------------------------------------------------------------------------------------
 // f32 expansion of a 64x64 bit raster held one row per lane: 16 wave-wide float4 stores of 1 KiB.
-__device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, int lane) {
+// With nz != nullptr (sparse update) only the row groups that hold pixels now or held pixels the last time this slot
+// was written are stored -- the rest of the slot is zero already -- and *nz is replaced by the new group mask.
+__device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, int lane, int32_t* nz = nullptr) {
     const int sub = lane >> 4, col4 = (lane & 15) * 4;
     const uint64_t nonzero_rows = __ballot(rowbits != 0ull);       // most of a raster is empty rows
+    if (nz) {
+        uint64_t t = nonzero_rows | (nonzero_rows >> 1);
+        t = (t | (t >> 2)) & 0x1111111111111111ull;                // bit 4g = any of rows 4g..4g+3
+        uint32_t now = 0u;
+#pragma unroll
+        for (int g = 0; g < IMG / 4; ++g) now |= (uint32_t)((t >> (4 * g)) & 1ull) << g;
+        uint32_t need = (uint32_t)__builtin_amdgcn_readfirstlane(*nz) | now;
+        if (lane == 0) *nz = (int32_t)now;
+        while (need) {
+            const int g = __builtin_ctz(need);
+            need &= need - 1u;
+            uint32_t nib = 0u;
+            if ((now >> g) & 1u) {
+                uint64_t m = shfl_u64(rowbits, 4 * g + sub);
+                nib = (uint32_t)(m >> col4) & 0xFu;
+            }
+            float4 v;
+            v.x = (nib & 1u) ? 1.f : 0.f;
+            v.y = (nib & 2u) ? 1.f : 0.f;
+            v.z = (nib & 4u) ? 1.f : 0.f;
+            v.w = (nib & 8u) ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(img + (size_t)(4 * g + sub) * IMG + col4) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int r0 = 0; r0 < IMG; r0 += 4) {
         uint32_t nib = 0u;
@@ -493,10 +520,12 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
                 c.b.cand_lin[ci] = (float)lin;
                 c.b.cand_mask[ci] = (uint8_t)(inb && !overlap);
             }
-            if (c.b.cand_raster && !(c.debug & 4)) write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane);
+            if (c.b.cand_raster && !(c.debug & 4))
+                write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane, c.b.cand_raster_nz ? c.b.cand_raster_nz + ci : nullptr);
         } else {
             const int e = it - total;
-            write_f32_image(c.b.state_raster + (size_t)e * IMG * IMG, c.b.state_bits[(size_t)e * IMG + lane], lane);
+            write_f32_image(c.b.state_raster + (size_t)e * IMG * IMG, c.b.state_bits[(size_t)e * IMG + lane], lane,
+                            c.b.state_raster_nz ? c.b.state_raster_nz + e : nullptr);
         }
     }
 }

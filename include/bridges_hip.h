@@ -123,6 +123,10 @@ typedef struct {
     uint64_t* cand_bits;       /* [C,64] bit-packed action rasters */
     float* cand_raster;        /* [C,64,64] f32 action rasters (may be NULL: skip) */
     float* state_raster;       /* [E,64,64] f32 (may be NULL) */
+    int32_t* cand_raster_nz;   /* [C] or NULL.  Non-NULL = sparse update of cand_raster: bit g = row group g (rows 4g..4g+3)
+                                  of slot i holds non-zero pixels.  The rasteriser then writes only the groups that are
+                                  non-zero now or were non-zero before; the buffers must start zeroed with zeroed masks. */
+    int32_t* state_raster_nz;  /* [E] or NULL: the same for state_raster (both or neither) */
     /* --- task features --- */
     const uint64_t* obstacle_bits; /* [64] */
     const float* reward_map;       /* [64,64] */

@@ -18,7 +18,10 @@ Parity status
   (``notebooks/Stability Evaluation.ipynb`` cell 2: 96 rows, of which 94
   reproduce and 2 are the documented IPOPT false negatives, see
   ``tests/golden/README.md``), plus the ``AssemblyEnv.ipynb`` /
-  ``CRA_Assembly.ipynb`` known answers.
+  ``CRA_Assembly.ipynb`` known answers.  The predicate carries a budget on
+  the total contact force (``oracle/rbe.py``: S_MAX) so that equilibria which
+  exist only through float32 mesh noise are rejected the same way by every
+  solver; none of the recorded rows is affected by it.
 * Geometry (placement, AABB, distances): PINNED by the float prints in
   ``AssemblyEnv.ipynb`` cells 24-25 (``distance_to_targets``).
 * Rasters, action masks, linear rewards of a full rollout: the reference holds

@@ -130,6 +130,30 @@ def test_tower_lockstep_parity(tower_height, max_steps):
     assert st["env_steps"] == n
 
 
+def test_sparse_raster_update_gives_the_same_images():
+    """sparse_raster_update stores only the row groups of a slot that hold pixels now or held pixels before; the f32
+    images must be what the full rewrite produces, lock-step after lock-step (slots are re-used by other candidates)."""
+    from bridges_hip.vec_env import VecAssemblyGym
+    E, seed = 96, 5
+    full, oracles = make_pair(dict(num_stories=4), bridge_setup, E, 15, seed, ["trapezoid"])
+    sparse = VecAssemblyGym(E, full.shapes, full.obstacles, full.targets, max_steps=15, seed=seed, sparse_raster_update=True)
+    assert sparse.cand_raster_nz is not None and full.cand_raster_nz is None
+    n = run_lockstep_parity(sparse, oracles, seed, n_lock=9)          # f32 images against the oracle at lock-steps 0 and 8
+    assert n > E * 4
+    for _ in range(9):                                                # same seed, same policy stream: same trajectory
+        full.select_random()
+        full.step()
+    for it in range(40):
+        total = int(full.cand_offset[E])
+        assert total == int(sparse.cand_offset[E])
+        assert torch.equal(full.cand_raster[:total], sparse.cand_raster[:total]), it
+        assert torch.equal(full.state_raster, sparse.state_raster), it
+        assert torch.equal(full.cand_mask[:total], sparse.cand_mask[:total])
+        for env in (full, sparse):
+            env.select_random()
+            env.step()
+
+
 def test_hexagon_bridge_lockstep_parity():
     E, seed = 32, 11
     from oracle.shapes import get_shape
