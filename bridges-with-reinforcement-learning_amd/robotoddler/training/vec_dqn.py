@@ -207,7 +207,7 @@ class VecDQN:
                   sf=torch.zeros((n_max * B, px[0] * px[1]), device=dev) if use_sf else None,
                   counter=torch.zeros((), dtype=torch.int64, device=dev),
                   losses=torch.zeros(n_max, device=dev),
-                  lane=torch.arange(B, device=dev), n_max=n_max, use_sf=use_sf)
+                  lane=torch.arange(B, device=dev), iota=torch.arange(n_max, device=dev), n_max=n_max, use_sf=use_sf)
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
 
@@ -215,8 +215,16 @@ class VecDQN:
             idx = st["lane"] + st["counter"] * B
             q, sf, _ = self.policy_net(st["block"].index_select(0, idx), st["binary"].index_select(0, idx),
                                        st["action"].index_select(0, idx), reward, obstacle)
-            loss = self._loss(q, sf, st["q"].index_select(0, idx), st["sf"].index_select(0, idx) if use_sf else None)
-            st["losses"].index_copy_(0, st["counter"].view(1), loss.detach().view(1))
+            # same losses as _loss, but the 131 072-element mean is reduced row-wise and then over the 32 rows: the
+            # multi-workgroup (semaphore) reduction nn.MSELoss launches for it returned garbage on some replays
+            # (negative "MSE", ROCm 7.2 + torch 2.10; eager never) while every single-workgroup reduction was right.
+            # The value is logged through a one-hot of the step counter (pure elementwise arithmetic).
+            loss = 0.
+            if 'mse_q_values' in self.loss_parts:
+                loss = loss + ((q - st["q"].index_select(0, idx)) ** 2).mean()
+            if use_sf:
+                loss = loss + ((sf[:, 0].reshape(B, -1) - st["sf"].index_select(0, idx)) ** 2).mean(dim=1).mean()
+            st["losses"].add_((st["iota"] == st["counter"]).to(torch.float32) * loss.detach())
             loss.backward()
             self.opt.step()
             st["counter"].add_(1)
@@ -230,14 +238,15 @@ class VecDQN:
         return st
 
     def _train_graph(self, n_steps, use_sf):
-        """The captured train step, or None.  EXPERIMENTAL, opt-in with BRIDGES_TRAIN_GRAPH=1: on ROCm 7.2 the replayed
-        graph trains correctly (weights equal the eager run) but at 4096 envs x 25 steps the recorded loss values of
-        some lock-steps come back as stale memory (negative "MSE"), sensitive to host synchronisation and absent
-        under AMD_SERIALIZE_KERNEL=3 -- an ordering problem of graph launches this code cannot rule out for other
-        buffers, so eager stays the default.  The first calls always run eagerly (they initialise the optimiser state
-        and the library workspaces a capture needs)."""
+        """The captured train step, or None (eager).  Default: on for SuccessorMLP, whose step has no multi-workgroup
+        reduction left in it (see _capture_train_graph) and is verified against the eager run at the bench size
+        (tests/test_gpu_vec_dqn.py); off for the conv nets, whose MIOpen / bias-gradient kernels were not audited for
+        that problem and which are convolution-bound anyway.  BRIDGES_TRAIN_GRAPH=0/1 overrides.  The first calls
+        always run eagerly (they initialise the optimiser state and the library workspaces a capture needs)."""
         import os
-        if os.environ.get("BRIDGES_TRAIN_GRAPH", "0") != "1":
+        from robotoddler.models.cv import SuccessorMLP
+        default = "1" if isinstance(self.policy_net, SuccessorMLP) else "0"
+        if os.environ.get("BRIDGES_TRAIN_GRAPH", default) != "1":
             return None
         st = self._graph_state
         if st is not None and (st["n_max"] < n_steps or st["use_sf"] != use_sf):
@@ -271,6 +280,7 @@ class VecDQN:
             if use_sf:
                 st["sf"][:n].copy_(sf_target.reshape(n, -1))
             st["counter"].zero_()
+            st["losses"].zero_()
             for _ in range(n_steps):
                 st["graph"].replay()
             return st["losses"][:n_steps].tolist()
