@@ -119,6 +119,30 @@ def bits_to_f32(bits):
     return img
 
 
+def bits_linear(bits, wt, bits_row=None, base=None, base_row=None):
+    """out[r] = base[base_row[r]] + sum of the rows of ``wt`` ([4096, d], pixel-major) selected by the set pixels of the
+    bit-packed raster ``bits[bits_row[r]]`` ([*,64] int64): a linear layer applied to flattened binary images without
+    expanding them (bridges_bits_linear).  Returns [n, d] float32."""
+    L = abi.require_gpu()
+    bits = bits.reshape(-1, 64)
+    assert bits.is_contiguous() and bits.dtype == torch.int64
+    wt = wt.to(torch.float32).contiguous()
+    assert wt.shape[0] == 4096 and wt.shape[1] % 4 == 0, "wt must be [4096, d] with d % 4 == 0"
+    d = wt.shape[1]
+    n = bits_row.numel() if bits_row is not None else bits.shape[0]
+    if bits_row is not None:
+        bits_row = bits_row.to(torch.int64).contiguous()
+    if base is not None:
+        base = base.to(torch.float32).reshape(-1, d).contiguous()
+        if base_row is not None:
+            base_row = base_row.to(torch.int64).contiguous()
+            assert base_row.numel() == n
+    out = torch.empty((n, d), dtype=torch.float32, device=bits.device)
+    abi.check(L.bridges_bits_linear(n, _ptr(bits), _ptr(bits_row), _ptr(wt), d, _ptr(base), _ptr(base_row), _ptr(out),
+                                    _stream()), "bridges_bits_linear")
+    return out
+
+
 def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
     """is_stable_rbe (stability.py:49-71) of ONE assembly.  Returns (stable: bool, info: dict)."""
     L = abi.require_gpu()

@@ -412,4 +412,15 @@ int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* n
     return BRIDGES_OK;
 }
 
+int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* wt, int32_t d,
+                        const float* base, const int64_t* base_row, float* out, void* stream) {
+    if (n_rows < 0 || d <= 0 || (d & 3) || !bits || !wt || !out) return fail_arg("bridges_bits_linear");
+    if ((((uintptr_t)wt) | ((uintptr_t)out) | ((uintptr_t)base)) & 15) return fail_arg("bits_linear: rows must be 16-byte aligned");
+    if (n_rows == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_bits_linear, dim3(grid_for_waves(n_rows)), dim3(256), 0, (hipStream_t)stream, n_rows, bits,
+                       bits_row, wt, d, base, base_row, out);
+    LAUNCH_CHECK("k_bits_linear");
+    return BRIDGES_OK;
+}
+
 }  // extern "C"

@@ -76,4 +76,47 @@ __global__ __launch_bounds__(256) void k_td_target(int n_trans, const int32_t* _
     }
 }
 
+// K8: first layer of an MLP that consumes flattened binary 64x64 rasters, fed with the bit-packed rasters themselves
+// (cv.py:95-97 concatenates block / action / reward / obstacle images and multiplies by W1; a block covers ~35 of the
+// 4096 pixels, so the product with its raster is the sum of ~35 rows of the transposed weight slice):
+//   out[r, :] = base[base_row[r], :] + sum over set pixels p of bits[bits_row[r]] (ascending p) of wt[p, :]
+// One wave per output row, 16 B per lane; wt (4 MiB for d = 256) stays in L2.
+__global__ __launch_bounds__(256) void k_bits_linear(int n_rows, const uint64_t* __restrict__ bits,
+                                                     const int64_t* __restrict__ bits_row, const float* __restrict__ wt,
+                                                     int d, const float* __restrict__ base,
+                                                     const int64_t* __restrict__ base_row, float* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int rv = wave; rv < n_rows; rv += nwaves) {
+        const int r = __builtin_amdgcn_readfirstlane(rv);
+        const int64_t src = bits_row ? bits_row[r] : (int64_t)r;
+        const uint64_t mine = bits[(size_t)src * IMG + lane];               // image row `lane`
+        const uint64_t rows_nz = __ballot(mine != 0ull);
+        const float* b = base ? base + (size_t)(base_row ? base_row[r] : 0) * d : nullptr;
+        for (int c0 = 0; c0 < d; c0 += 4 * WAVE) {
+            const int col = c0 + 4 * lane;
+            const bool act = col < d;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b && act) acc = *reinterpret_cast<const float4*>(b + col);
+            uint64_t rem = rows_nz;
+            while (rem) {
+                const int rr = __builtin_ctzll(rem);
+                rem &= rem - 1ull;
+                uint64_t m = shfl_u64(mine, rr);                             // uniform: the mask of image row rr
+                const float* w = wt + (size_t)rr * IMG * d + col;
+                while (m) {
+                    const int cc = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    if (act) {
+                        const float4 v = *reinterpret_cast<const float4*>(w + (size_t)cc * d);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                }
+            }
+            if (act) *reinterpret_cast<float4*>(out + (size_t)r * d + col) = acc;
+        }
+    }
+}
+
 }  // namespace bridges

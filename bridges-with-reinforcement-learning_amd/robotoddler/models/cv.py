@@ -101,14 +101,33 @@ class SuccessorMLP(nn.Module):
         Same function as ``forward(...)[0]`` up to float32 summation order.
         block_features [E,H,W], binary_features [E,f], action_features [n,H,W], row_env [n] (env of each row),
         reward_features / obstacle_features [H,W] (or any shape with H*W elements)."""
-        lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
         E, n = block_features.shape[0], action_features.shape[0]
-        W1, b1 = lin[0].weight, lin[0].bias
-        const = W1[:, 2 * px:3 * px] @ reward_features.reshape(px) + W1[:, 3 * px:4 * px] @ obstacle_features.reshape(px) + b1
-        base = block_features.reshape(E, px) @ W1[:, :px].T + binary_features @ W1[:, 4 * px:].T + const
+        W1 = self.first_layer().weight
+        base = block_features.reshape(E, px) @ W1[:, :px].T + self.first_layer_env_terms(binary_features, reward_features,
+                                                                                         obstacle_features)
         h = torch.addmm(base.index_select(0, row_env), action_features.reshape(n, px), W1[:, px:2 * px].T)
-        h = F.relu(h)
+        return self.q_from_first_layer(h, reward_features)
+
+    def first_layer(self):
+        return next(m for m in self.mlp.layers if isinstance(m, nn.Linear))
+
+    @torch.no_grad()
+    def first_layer_env_terms(self, binary_features, reward_features, obstacle_features):
+        """[E, hidden] part of the first layer that does not depend on the block / action images: binary features,
+        reward map, obstacle raster and the bias."""
+        px = self.img_size[0] * self.img_size[1]
+        lin = self.first_layer()
+        W1 = lin.weight
+        const = W1[:, 2 * px:3 * px] @ reward_features.reshape(px) + W1[:, 3 * px:4 * px] @ obstacle_features.reshape(px) + lin.bias
+        return binary_features @ W1[:, 4 * px:].T + const
+
+    @torch.no_grad()
+    def q_from_first_layer(self, h_pre, reward_features):
+        """q from the pre-activation of the first layer ([n, hidden]): the remaining layers and the factored head."""
+        lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
+        px = self.img_size[0] * self.img_size[1]
+        h = F.relu(h_pre)
         for layer in lin[1:-1]:
             h = F.relu(layer(h))
         Wo, bo = lin[-1].weight, lin[-1].bias

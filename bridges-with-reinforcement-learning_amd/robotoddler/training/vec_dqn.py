@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-from bridges_hip import dqn_ops
+from bridges_hip import dqn_ops, ops
 from bridges_hip.shapes import load_urdf
 from bridges_hip.vec_env import VecAssemblyGym
 from robotoddler.training import distributed as D
@@ -78,9 +78,16 @@ class VecDQN:
 
     @staticmethod
     def _factored(net):
-        """Acting through SuccessorMLP.q_values_factored (BRIDGES_FACTORED_ACT=0: the plain module forward)."""
+        """Acting through the factored SuccessorMLP forward on bit-packed rasters (BRIDGES_FACTORED_ACT=0: the plain
+        module forward on f32 rasters)."""
         import os
-        return hasattr(net, "q_values_factored") and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0"
+        return hasattr(net, "q_from_first_layer") and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0"
+
+    @classmethod
+    def acting_needs_f32_rasters(cls, net):
+        """False when acting reads only the bit-packed rasters of the rollout env: it can then be created with
+        f32_rasters=False and its rasteriser skips the 16 KiB-per-candidate expansion."""
+        return not cls._factored(net)
 
     @staticmethod
     def _segments(row_env, E, device):
@@ -102,15 +109,25 @@ class VecDQN:
             self.policy_net.eval()
             step_of_row = env.n_blocks[row_env].long()
             if self._factored(self.policy_net):
-                action = env.cand_raster.index_select(0, idx)
+                # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice
+                # is the sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
+                net, px = self.policy_net, 64 * 64
                 binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
                 binary[:, 0] = stable.float()
-                q = self.policy_net.q_values_factored(env.state_raster, binary, action, row_env, env.reward_features,
-                                                      env.obstacle_raster)
+                W1 = net.first_layer().weight
+                base = ops.bits_linear(env.state_bits, W1[:, :px].T,
+                                       base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
+                                       base_row=torch.arange(E, device=self.device))
+                h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
+                q = net.q_from_first_layer(h_pre, env.reward_features)
                 # overlap of every candidate with the count image of its episode step (exact: integer-valued sums)
-                px = action.shape[1] * action.shape[2]
-                join = (action.reshape(-1, px) @ self.step_images.reshape(-1, px).T).gather(1, step_of_row[:, None])[:, 0]
+                ks = self.step_images.shape[0]
+                counts_t = torch.zeros((px, (ks + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+                counts_t[:, :ks] = self.step_images.reshape(ks, px).T
+                join = ops.bits_linear(env.cand_bits, counts_t, bits_row=idx).gather(1, step_of_row[:, None])[:, 0]
             else:
+                if env.cand_raster is None:
+                    raise ValueError("this Q-network acts on f32 rasters: create the rollout env with f32_rasters=True")
                 q, _, _ = self._forward_rows(self.policy_net, env, idx, row_env, stable)
                 join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
@@ -124,7 +141,7 @@ class VecDQN:
             ex = explore & has
             if ex.any():
                 rows = sel_row[ex]
-                self.step_images.index_add_(0, step_of_row[rows], env.cand_raster[idx[rows]])
+                self.step_images.index_add_(0, step_of_row[rows], ops.bits_to_f32(env.cand_bits[idx[rows]]))
             sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
         else:
             sel_compact = torch.zeros(E, dtype=torch.long, device=self.device)
@@ -201,7 +218,7 @@ class VecDQN:
         train step is exactly one graph launch (eager PyTorch needs ~60 launches of a few microseconds of work each
         and is bound by their launch latency)."""
         B, dev = self.B, self.device
-        px = self.env.state_raster.shape[-2:]
+        px = (64, 64)
         st = dict(block=torch.zeros((n_max * B, 1, *px), device=dev), binary=torch.zeros((n_max * B, 6), device=dev),
                   action=torch.zeros((n_max * B, 1, *px), device=dev), q=torch.zeros(n_max * B, device=dev),
                   sf=torch.zeros((n_max * B, px[0] * px[1]), device=dev) if use_sf else None,
@@ -335,10 +352,11 @@ def run_vectorised(args, device):
         targets = [(n * sq + 2.5 * sq, 0, sq / 2)]
         obstacles = [(i * sq, 0, sq / 2) for i in range(1, n + 1)]
     seed = args['seed'] or 0
-    env = VecAssemblyGym(args['num_envs'], geoms, obstacles, targets, max_steps=args['max_steps'],
-                         seed=seed * 1000003 + rank, device=device, env_id_base=rank * args['num_envs'])
     torch.manual_seed(seed)                                    # identical initial weights on every rank
     policy_net, target_net = make_nets(args, device)
+    env = VecAssemblyGym(args['num_envs'], geoms, obstacles, targets, max_steps=args['max_steps'],
+                         seed=seed * 1000003 + rank, device=device, env_id_base=rank * args['num_envs'],
+                         f32_rasters=VecDQN.acting_needs_f32_rasters(policy_net))
     opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'], fused=True)    # one launch for all tensors
     capacity = max(args['replay_buffer_capacity'], 4 * args['num_envs'] * world)
     agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],

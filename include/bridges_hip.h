@@ -202,6 +202,14 @@ int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* ver
 int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream);
 /* bit raster -> f32 image. */
 int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream);
+/* K8: linear layer over flattened binary 64x64 rasters, fed with the bit-packed rasters (replaces the product of
+ * SuccessorMLP's first layer with the action / block image, robotoddler/models/cv.py:95-97):
+ *   out[r, :] = (base ? base[base_row ? base_row[r] : 0, :] : 0) + sum_{p set in bits[bits_row ? bits_row[r] : r]} wt[p, :]
+ * bits [*,64] u64 (row y of an image = one word, bit x = pixel (y, x), flattened pixel p = 64*y + x);
+ * wt [4096, d] f32 = the transposed weight slice; base [*, d]; out [n_rows, d]; d % 4 == 0; pixels are added in
+ * ascending p, so the result is deterministic. */
+int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* wt, int32_t d,
+                        const float* base, const int64_t* base_row, float* out, void* stream);
 /* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
  * padded block lists.  verts [n,K,6,2], shape_id [n,K], n_blocks [n], fixed_mask [n] (bit b = block b
  * is_static)

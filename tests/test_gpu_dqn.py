@@ -161,3 +161,31 @@ def test_update_target_net_per_tensor_path_equals_flat_path():
     for k in ref:
         assert torch.equal(b.state_dict()[k].cpu(), ref[k]), k
         assert torch.equal(b2.state_dict()[k].cpu(), ref[k]), k
+
+
+@pytest.mark.parametrize("d", [16, 256, 516])
+def test_bits_linear_matches_the_dense_product(d):
+    """bridges_bits_linear: a linear layer over flattened binary rasters fed with the bit-packed rasters equals
+    expand-to-f32 @ W (f32 summation order aside), with per-row base rows and an index into the raster array."""
+    from bridges_hip import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(d)
+    n_img, n, nb = 50, 333, 7
+    dense = (torch.rand((n_img, 64, 64), generator=g) < 0.02)
+    dense[3] = False                                                  # an empty raster
+    dense[4] = True                                                   # a full one
+    weights = (1 << torch.arange(63, dtype=torch.int64))
+    bits = (dense[:, :, :63].to(torch.int64) * weights).sum(dim=2)
+    bits = torch.where(dense[:, :, 63], bits | torch.tensor(-(1 << 63), dtype=torch.int64), bits)      # bit 63 = sign bit
+    wt = torch.randn((4096, d), generator=g)
+    base = torch.randn((nb, d), generator=g)
+    bits_row = torch.randint(0, n_img, (n,), generator=g)
+    base_row = torch.randint(0, nb, (n,), generator=g)
+    got = ops.bits_linear(bits.to(dev), wt.to(dev), bits_row=bits_row.to(dev), base=base.to(dev), base_row=base_row.to(dev))
+    want = dense[bits_row].reshape(n, 4096).double() @ wt.double() + base[base_row].double()
+    assert got.shape == (n, d)
+    assert torch.allclose(got.cpu().double(), want, rtol=1e-5, atol=1e-4), float((got.cpu().double() - want).abs().max())
+    # integer-valued weights (the exploration count images): exact
+    cnt = torch.randint(0, 5, (4096, 16), generator=g).float()
+    got = ops.bits_linear(bits.to(dev), cnt.to(dev))
+    assert torch.equal(got.cpu(), dense.reshape(n_img, 4096).float() @ cnt)

@@ -60,6 +60,40 @@ def test_vectorised_training_runs(model, loss, task):
     assert losses and all(np.isfinite(losses))
 
 
+def test_bit_packed_acting_forward_equals_the_dense_factored_forward(monkeypatch):
+    """SuccessorMLP acting: first layer from the bit-packed rasters (bridges_bits_linear) vs the torch-only factored
+    forward on the f32 rasters vs the plain module forward, on the candidates of a running env."""
+    from bridges_hip import ops
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev = torch.device("cuda")
+    env = make_env(256, seed=9, tower=4, max_steps=15)
+    for _ in range(5):
+        env.select_random()
+        env.step()
+    torch.manual_seed(3)
+    net, _ = make_nets(args, dev)
+    net.eval()
+    E, px = env.E, 4096
+    idx, row_env = env.valid_rows()
+    binary = torch.zeros((E, 6), device=dev)
+    binary[:, 0] = (torch.arange(E, device=dev) % 2).float()
+    with torch.no_grad():
+        W1 = net.first_layer().weight
+        base = ops.bits_linear(env.state_bits, W1[:, :px].T, base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
+                               base_row=torch.arange(E, device=dev))
+        q_bits = net.q_from_first_layer(ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env),
+                                        env.reward_features)
+        action = env.cand_raster.index_select(0, idx)
+        q_fact = net.q_values_factored(env.state_raster, binary, action, row_env, env.reward_features, env.obstacle_raster)
+        n = idx.numel()
+        q_full = net(env.state_raster[row_env].unsqueeze(1), binary[row_env], action.unsqueeze(1),
+                     env.reward_features.unsqueeze(0).expand(n, -1, -1, -1), env.obstacle_raster.unsqueeze(0).expand(n, -1, -1, -1))[0]
+    assert n > 1000
+    assert torch.allclose(q_bits, q_fact, rtol=1e-5, atol=1e-5), float((q_bits - q_fact).abs().max())
+    assert torch.allclose(q_bits, q_full, rtol=1e-5, atol=1e-5), float((q_bits - q_full).abs().max())
+
+
 def test_batched_targets_equal_per_batch_targets():
     """train_steps computes the TD targets of all its batches in one pass (the target net is constant meanwhile);
     the result must be what batch-by-batch evaluation gives."""

@@ -29,12 +29,13 @@ if a.miopen_search:
     torch.backends.cudnn.benchmark = True
 args = vars(build_parser().parse_args(["--model", a.model, "--loss_function", a.loss, "--learning_rate", "1e-4"]))
 H = 0.8
-env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(a.tower)],
-                     [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev)
 torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
 if a.channels_last:
     pol, tgt = pol.to(memory_format=torch.channels_last), tgt.to(memory_format=torch.channels_last)
+env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(a.tower)],
+                     [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev,
+                     f32_rasters=VecDQN.acting_needs_f32_rasters(pol))
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
 for i in range(a.warmup):
