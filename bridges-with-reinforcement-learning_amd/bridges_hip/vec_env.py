@@ -289,6 +289,16 @@ class VecAssemblyGym:
         self.buf["n_cand"].copy_(torch.clamp(n_cand, max=self.a_max).to(torch.int32))
         self.refresh()
 
+    def prefix_state_bits(self, n_prefix):
+        """Bit raster of the first n_prefix[e] blocks of every env as loaded by the last load_states call (int32/int64
+        [E]): the state a transition started from, when the env holds the state it led to."""
+        bits, _, _ = self._keep
+        start = torch.arange(self.E, dtype=torch.int32, device=self.device) * self.K
+        ranges = torch.stack([start, start + n_prefix.to(torch.int32)], dim=1).contiguous()
+        out = torch.empty((self.E, 64), dtype=torch.int64, device=self.device)
+        abi.check(self.L.bridges_bits_or(self.E, _ptr(ranges), _ptr(bits), _ptr(out), _stream()), "bridges_bits_or")
+        return out
+
     def candidate_stability(self, chunk=8192):
         """is_action_stable_rbe (assembly_gym/utils/stability.py:122-130 of the reference) for EVERY valid candidate
         of every env in one batch: the candidate block is appended to its env's assembly (the last placed block

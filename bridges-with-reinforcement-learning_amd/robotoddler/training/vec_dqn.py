@@ -177,12 +177,12 @@ class VecDQN:
         else:
             rec_p = rec
         (nb, shape, pose, occ), (nnb, nshape, npose, nocc) = R.unpack_states(rec_p, K)
-        # state s: raster of its blocks; action raster = the placed block
-        renv.load_states(nb, shape, pose, occ)
-        block_f = renv.state_raster.clone().unsqueeze(1)
-        # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout
+        # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout; s is the
+        # prefix of its block list, so its raster comes out of the same per-block bit rasters
         renv.load_states(nnb, nshape, npose, nocc)
-        action_f = (renv.state_raster - block_f.squeeze(1)).clamp_(0, 1).unsqueeze(1)          # s' minus s = the new block
+        bits_s = renv.prefix_state_bits(nb)
+        block_f = ops.bits_to_f32(bits_s).unsqueeze(1)
+        action_f = ops.bits_to_f32(renv.state_bits & ~bits_s).unsqueeze(1)                     # s' minus s = the new block
         idx, row_env = renv.valid_rows()
         seg, counts = self._segments(row_env, E, self.device)
         done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)

@@ -31,6 +31,7 @@ def test_records_rebuild_the_recorded_states():
         renv.load_states(nb, shape, pose, occ)
         assert torch.equal(renv.state_bits[valid], state_bits_before[valid])
         renv.load_states(nnb, nshape, npose, nocc)
+        assert torch.equal(renv.prefix_state_bits(nb)[valid], state_bits_before[valid])       # s is a prefix of s'
         cont = valid & ~env.step_flags[:, 5].bool()                 # not done: env now holds s' with its candidates
         assert cont.any()
         assert torch.equal(renv.state_bits[cont], env.state_bits[cont])
