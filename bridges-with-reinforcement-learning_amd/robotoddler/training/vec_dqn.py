@@ -10,8 +10,14 @@ Semantics follow rollout_episode / train_policy_net / update_target_net of the r
 * the TD target is the elementwise  lin_reward + gamma * q'  (the single-env reference path trains on a [B,B]
   broadcast of it because its lin_reward is [B,1]; that quirk is reproduced only in the single-env loop);
 * "done" of a transition = terminated | truncated | no next action (successor_dqn.py:393, 409-411).
+
+How a lock-step is spent: acting through the factored SuccessorMLP forward whose first layer reads
+the bit-packed rasters (bridges_bits_linear); the TD / successor-feature targets of ALL optimiser steps of the lock-step
+in one pass (the target net is constant meanwhile); the optimiser steps themselves as replays of one HIP graph.
 """
+import os
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -80,7 +86,6 @@ class VecDQN:
     def _factored(net):
         """Acting through the factored SuccessorMLP forward on bit-packed rasters (BRIDGES_FACTORED_ACT=0: the plain
         module forward on f32 rasters)."""
-        import os
         return hasattr(net, "q_from_first_layer") and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0"
 
     @classmethod
@@ -260,7 +265,6 @@ class VecDQN:
         (tests/test_gpu_vec_dqn.py); off for the conv nets, whose MIOpen / bias-gradient kernels were not audited for
         that problem and which are convolution-bound anyway.  BRIDGES_TRAIN_GRAPH=0/1 overrides.  The first calls
         always run eagerly (they initialise the optimiser state and the library workspaces a capture needs)."""
-        import os
         from robotoddler.models.cv import SuccessorMLP
         default = "1" if isinstance(self.policy_net, SuccessorMLP) else "0"
         if os.environ.get("BRIDGES_TRAIN_GRAPH", default) != "1":
@@ -275,7 +279,6 @@ class VecDQN:
             try:
                 st = self._graph_state = self._capture_train_graph(n_steps, use_sf)
             except RuntimeError as e:                         # same arithmetic either way: keep training eagerly
-                import warnings
                 warnings.warn(f"train-step graph capture failed, staying eager: {e}")
                 self._eager_calls = -(1 << 30)
                 return None
@@ -338,7 +341,6 @@ class VecDQN:
 
 def run_vectorised(args, device):
     from robotoddler.training.successor_dqn import make_nets
-    import os
     backend = os.environ.get("BRIDGES_DIST_BACKEND")          # 'gloo' = rehearsal with several ranks on one card
     rank, world = D.init(backend=backend, device=device)
     names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[args['shapes']]
