@@ -32,7 +32,7 @@ from assembly_gym.utils.rendering import render_blocks_2d_bits                  
 from bridges_hip import dqn_ops, ops                                                      # noqa: E402
 from robotoddler.models.cv import ConvNet, Policy, SuccessorMLP                           # noqa: E402
 from robotoddler.utils.actions import filter_actions, generate_actions                    # noqa: E402
-from robotoddler.utils.replay_memory import ReplayBuffer                                  # noqa: E402
+from robotoddler.utils.replay_memory import PrioritizedReplayBuffer, ReplayBuffer          # noqa: E402
 from robotoddler.utils.utils import (convolve_with_gaussian, init_weights, parse_img_size,   # noqa: E402
                                      save_checkpoint)
 
@@ -333,6 +333,8 @@ def build_parser():
     p.add_argument("--replay_buffer_capacity", type=int, default=2000, help="Replay buffer capacity.")
     p.add_argument("--wandb", type=bool, default=False, help="Use wandb logging.")
     p.add_argument("--num_envs", type=int, default=1, help="Environments advanced in lock-step on the GPU.")
+    p.add_argument("--prioritized_replay", action='store_true',
+                   help="Sample transitions in proportion to |td_error| + 1e-5 (PrioritizedReplayBuffer, replay_memory.py:45-93).")
     p.add_argument("--shapes", choices=['trapezoid', 'hexagon', 'both'], default='trapezoid')
     return p
 
@@ -397,7 +399,11 @@ def main(argv=None):
     xlim, ylim = (-3, 7), (0., 10)
     gamma = args['gamma']
     policy_net, target_net = make_nets(args, device)
-    replay_buffer = ReplayBuffer(capacity=args['replay_buffer_capacity'])
+    if args['prioritized_replay']:
+        replay_buffer = PrioritizedReplayBuffer(capacity=args['replay_buffer_capacity'], gamma=gamma, policy_net=policy_net,
+                                                target_net=target_net, device=device)
+    else:
+        replay_buffer = ReplayBuffer(capacity=args['replay_buffer_capacity'])
     eps_greedy = EpsilonGreedy(eps_start=0.5, gamma=0.999, eps_end=0.05, episode=0, max_steps=args['max_steps'], device=device)
     greedy = lambda q, *a, **k: torch.argmax(q)
     setup_fct = make_setup_fct(args)

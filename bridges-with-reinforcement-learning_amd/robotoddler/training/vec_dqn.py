@@ -31,11 +31,12 @@ from robotoddler.training import records as R
 
 class VecDQN:
     def __init__(self, policy_net, target_net, optimizer, env, replay_capacity, batch_size, gamma, tau, loss_function,
-                 seed=0, rank=0, eps_start=0.5, eps_end=0.05, eps_decay=0.999):
+                 seed=0, rank=0, eps_start=0.5, eps_end=0.05, eps_decay=0.999, prioritized=False):
         self.policy_net, self.target_net, self.opt, self.env = policy_net, target_net, optimizer, env
         self.device = env.device
         self.B, self.gamma, self.tau = batch_size, gamma, tau
         self.loss_parts = loss_function.split('+')
+        self.prioritized = bool(prioritized)      # PrioritizedReplayBuffer semantics (replay_memory.py:45-93)
         self.ring = R.ReplayRing(replay_capacity, self.device)
         # replay sampling must be identical on every rank (replicated rings) -> shared seed; exploration differs
         self.sample_gen = torch.Generator(device=self.device).manual_seed(1234567 + seed)
@@ -101,39 +102,67 @@ class VecDQN:
         seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return seg, counts
 
+    @staticmethod
+    def _stable_flags(env):
+        """'stable' binary feature of the current state of every env (a freshly reset env is stable)."""
+        fresh = env.n_blocks == 0
+        return torch.where(fresh, torch.ones_like(fresh), env.step_flags[:, 1].bool())
+
+    @torch.no_grad()
+    def _policy_q(self, env, idx, row_env, stable):
+        """q of the policy net for the candidate rows ``idx`` of ``env``."""
+        self.policy_net.eval()
+        if not self._factored(self.policy_net):
+            if env.cand_raster is None:
+                raise ValueError("this Q-network acts on f32 rasters: create the rollout env with f32_rasters=True")
+            return self._forward_rows(self.policy_net, env, idx, row_env, stable)[0]
+        # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice is the
+        # sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
+        net, px, E = self.policy_net, 64 * 64, env.E
+        binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
+        binary[:, 0] = stable.float()
+        W1 = net.first_layer().weight
+        base = ops.bits_linear(env.state_bits, W1[:, :px].T,
+                               base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
+                               base_row=torch.arange(E, device=self.device))
+        h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
+        return net.q_from_first_layer(h_pre, env.reward_features)
+
+    @torch.no_grad()
+    def td_errors(self, rec):
+        """td_error of the transitions just recorded (successor_dqn.py:413-426): |q(s,a) - (reward + 0.95 max_a' q(s',a'))|
+        with the policy net as it is now, next value 0 when done; the env holds s' (or a fresh state when done)."""
+        env, E = self.env, self.env.E
+        done = rec[:, R.O_DONE] > 0.5
+        idx, row_env = env.valid_rows()
+        next_q = torch.zeros(E, dtype=torch.float32, device=self.device)
+        if idx.numel():
+            q = self._policy_q(env, idx, row_env, self._stable_flags(env))
+            seg, counts = self._segments(row_env, E, self.device)
+            zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
+            next_q, _, _ = dqn_ops.td_target(seg, q.contiguous().float(), zeros, done | (counts == 0), 1.0)   # segmented max
+        expected = rec[:, R.O_REWARD].float() + 0.95 * next_q                      # hard-coded 0.95 (successor_dqn.py:425)
+        return (self._q_sel - expected).abs()
+
     # ------------------------------------------------------------------ one lock-step of acting
     @torch.no_grad()
     def act(self, greedy=False):
         env, E = self.env, self.env.E
         idx, row_env = env.valid_rows()
-        fresh = env.n_blocks == 0
-        stable = torch.where(fresh, torch.ones_like(fresh), env.step_flags[:, 1].bool())
+        stable = self._stable_flags(env)
         seg, counts = self._segments(row_env, E, self.device)
         sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
+        self._q_sel = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
-            self.policy_net.eval()
             step_of_row = env.n_blocks[row_env].long()
+            q = self._policy_q(env, idx, row_env, stable)
             if self._factored(self.policy_net):
-                # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice
-                # is the sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
-                net, px = self.policy_net, 64 * 64
-                binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
-                binary[:, 0] = stable.float()
-                W1 = net.first_layer().weight
-                base = ops.bits_linear(env.state_bits, W1[:, :px].T,
-                                       base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
-                                       base_row=torch.arange(E, device=self.device))
-                h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
-                q = net.q_from_first_layer(h_pre, env.reward_features)
                 # overlap of every candidate with the count image of its episode step (exact: integer-valued sums)
-                ks = self.step_images.shape[0]
+                px, ks = 64 * 64, self.step_images.shape[0]
                 counts_t = torch.zeros((px, (ks + 3) // 4 * 4), dtype=torch.float32, device=self.device)
                 counts_t[:, :ks] = self.step_images.reshape(ks, px).T
                 join = ops.bits_linear(env.cand_bits, counts_t, bits_row=idx).gather(1, step_of_row[:, None])[:, 0]
             else:
-                if env.cand_raster is None:
-                    raise ValueError("this Q-network acts on f32 rasters: create the rollout env with f32_rasters=True")
-                q, _, _ = self._forward_rows(self.policy_net, env, idx, row_env, stable)
                 join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
             nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
@@ -148,6 +177,7 @@ class VecDQN:
                 rows = sel_row[ex]
                 self.step_images.index_add_(0, step_of_row[rows], ops.bits_to_f32(env.cand_bits[idx[rows]]))
             sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
+            self._q_sel = torch.where(has, q.float()[sel_row.clamp(max=idx.numel() - 1)], self._q_sel)
         else:
             sel_compact = torch.zeros(E, dtype=torch.long, device=self.device)
         sel_index = (sel_compact - env.cand_offset[:E].long()).clamp(min=0).to(torch.int32)
@@ -289,7 +319,7 @@ class VecDQN:
         if len(self.ring) < self.B or n_steps <= 0:
             return []
         B = self.B
-        rec = torch.cat([self.ring.sample(B, self.sample_gen) for _ in range(n_steps)])
+        rec = torch.cat([self.ring.sample(B, self.sample_gen, self.prioritized) for _ in range(n_steps)])
         block_f, binary, action_f, q_target, sf_target = self._targets(rec)
         use_sf = sf_target is not None
         st = self._train_graph(n_steps, use_sf)
@@ -329,6 +359,8 @@ class VecDQN:
     # ------------------------------------------------------------------ driver
     def lockstep(self, n_train_steps):
         rec, valid = self.act()
+        if self.prioritized:
+            rec[:, R.O_TD] = self.td_errors(rec).to(rec.dtype)
         self.env_steps += int(valid.sum().item())
         allrec = D.all_gather_records(rec, valid)
         self.ring.push(allrec)
@@ -362,7 +394,7 @@ def run_vectorised(args, device):
     opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'], fused=True)    # one launch for all tensors
     capacity = max(args['replay_buffer_capacity'], 4 * args['num_envs'] * world)
     agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],
-                   args['loss_function'], seed=seed, rank=rank)
+                   args['loss_function'], seed=seed, rank=rank, prioritized=args.get('prioritized_replay', False))
     history, t0, it = [], time.time(), 0
     next_ckpt = args['checkpoint_every']
     while agent.episodes_done < args['num_episodes']:

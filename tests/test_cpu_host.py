@@ -125,6 +125,23 @@ def test_records_roundtrip_and_ring():
     assert s.shape == (3, R.RECORD_WIDTH)
 
 
+def test_ring_prioritized_sampling_follows_td_error():
+    """PrioritizedReplayBuffer.sample (replay_memory.py:70-86): probability proportional to td_error + 1e-5."""
+    from robotoddler.training import records as R
+    ring = R.ReplayRing(16, torch.device("cpu"))
+    rec = torch.zeros((10, R.RECORD_WIDTH), dtype=torch.float64)
+    rec[:, 0] = torch.arange(10)
+    rec[3, R.O_TD], rec[7, R.O_TD] = 3.0, 1.0
+    ring.push(rec)
+    g = torch.Generator().manual_seed(0)
+    s = ring.sample(4000, g, prioritized=True)[:, 0]
+    counts = torch.bincount(s.long(), minlength=10).double()
+    assert counts[[0, 1, 2, 4, 5, 6, 8, 9]].sum() <= 2                       # eight rows share 8e-5 / 4.00008 of the mass
+    assert abs(counts[3] / 4000 - 0.75) < 0.03 and abs(counts[7] / 4000 - 0.25) < 0.03
+    u = ring.sample(4000, g)[:, 0]
+    assert torch.bincount(u.long(), minlength=10).min() > 300                # uniform stays uniform
+
+
 def test_ring_checkpoint_roundtrip(tmp_path):
     """The device ring takes ReplayBuffer's place in save_checkpoint / load_checkpoint (utils.py:54-89)."""
     from robotoddler.training import records as R

@@ -51,7 +51,8 @@ HEX_BRIDGE = ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"
 @pytest.mark.parametrize("model,loss,task", [("SuccessorMLP", "mse_q_values+mse_block_features", TOWER2),
                                              ("ConvNet", "mse_q_values", TOWER2),
                                              ("UNet", "mse_block_features", TOWER2),
-                                             ("UNet", "mse_q_values+mse_block_features", HEX_BRIDGE)])
+                                             ("UNet", "mse_q_values+mse_block_features", HEX_BRIDGE),
+                                             ("SuccessorMLP", "mse_q_values", TOWER2 + ["--prioritized_replay"])])
 def test_vectorised_training_runs(model, loss, task):
     from robotoddler.training.successor_dqn import build_parser, main
     hist = main(["--model", model, "--loss_function", loss, *task, "--num_envs", "64", "--num_episodes", "150",
@@ -93,6 +94,50 @@ def test_bit_packed_acting_forward_equals_the_dense_factored_forward(monkeypatch
     assert n > 1000
     assert torch.allclose(q_bits, q_fact, rtol=1e-5, atol=1e-5), float((q_bits - q_fact).abs().max())
     assert torch.allclose(q_bits, q_full, rtol=1e-5, atol=1e-5), float((q_bits - q_full).abs().max())
+
+
+@pytest.mark.parametrize("model", ["SuccessorMLP", "ConvNet"])
+def test_rollout_td_error_follows_the_reference(model):
+    """td_error of a transition (successor_dqn.py:413-426) = |q(s,a) - (reward + 0.95 * max_a' q(s',a'))|, next value 0
+    when done, both q from the policy net; recomputed here with the plain module forward, env by env."""
+    from robotoddler.training import records as R
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", model]))
+    dev = torch.device("cuda")
+    env = make_env(48, seed=13)
+    torch.manual_seed(4)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 4096, 8, 0.95, 0.01, "mse_q_values",
+                   prioritized=True)
+    agent.epsilon = 0.0                                              # greedy: q(s,a) is the maximum of the state's rows
+
+    def rows_q():
+        idx, row_env = env.valid_rows()
+        stable = agent._stable_flags(env)
+        with torch.no_grad():
+            pol.eval()
+            q = agent._forward_rows(pol, env, idx, row_env, stable)[0].float()
+        return [q[row_env == e] for e in range(env.E)]
+
+    checked = 0
+    for it in range(6):
+        q_before = rows_q()
+        rec, valid = agent.act()
+        td = agent.td_errors(rec)
+        q_after = rows_q()
+        for e in torch.nonzero(valid).squeeze(1).tolist():
+            done = bool(rec[e, R.O_DONE] > 0.5)
+            nxt = 0.0 if done or q_after[e].numel() == 0 else float(q_after[e].max())
+            want = abs(float(q_before[e].max()) - (float(rec[e, R.O_REWARD]) + 0.95 * nxt))
+            assert abs(float(td[e]) - want) <= 1e-5 + 1e-5 * abs(want), (it, e, float(td[e]), want)
+            checked += 1
+        agent.ring.push(rec[valid])
+    assert checked > 100
+    rec[:, R.O_TD] = td.to(rec.dtype)
+    agent.ring.push(rec[valid])
+    assert float(agent.ring.data[:len(agent.ring), R.O_TD].max()) > 0
+    assert len(agent.train_steps(2)) == 2                            # prioritised sampling feeds the optimiser steps
 
 
 def test_batched_targets_equal_per_batch_targets():
