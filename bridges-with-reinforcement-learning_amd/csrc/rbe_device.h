@@ -39,7 +39,9 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
 #define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
                               // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
-#define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (8 KiB); larger tableaux live in lp_ws
+#ifndef LP_TAB_LDS
+#define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (16 KiB); larger tableaux live in lp_ws
+#endif
 #define MAXFACES (1 + MAXK * MAXV)            // floor + K blocks
 #define LP_MAX_COLS (4 * MAXIF)
 #define LP_MAX_CHUNKS ((LP_MAX_COLS + 2 + WAVE - 1) / WAVE)
