@@ -51,6 +51,30 @@ def test_stability_table_through_the_api(golden_dir):
     assert diffs == KNOWN_DEVIATIONS
 
 
+def test_structure_harness_reproduces_the_recorded_table(golden_dir, tmp_path):
+    """assembly_gym.utils.test_suite (the reference's regression harness over assembly_gym.utils.structures): its
+    structure.json files carry the recorded RBE column and the hand labels of the stored table."""
+    from assembly_gym.utils import test_suite
+    table = _load(golden_dir, "stability_table.json")
+    got = {}
+    for mu in (0.8, 2.0):
+        for path in test_suite.run(str(tmp_path / f"mu{mu}"), mu=mu):
+            data = json.load(open(path))
+            (mid, meth), = data["methods"].items()
+            assert meth["name"] == "rbe"
+            for t in data["tests"].values():
+                key = (data["structure"]["name"], json.dumps(data["structure"]["kwargs"], sort_keys=True), mu, t["step"])
+                got[key] = (t[mid]["is_stable"], t["is_stable"])
+    assert len(got) == len(table) == 96
+    diffs = set()
+    for row in table:
+        rbe, expected = got[(row["structure"], json.dumps(row["kwargs"], sort_keys=True), row["mu"], row["step"])]
+        assert expected == row["expected"], row                  # the hand labels (structures.py) as rules
+        if rbe != row["rbe"]:
+            diffs.add((row["structure"], row["kwargs"].get("freeze_last"), row["mu"], row["step"]))
+    assert diffs == KNOWN_DEVIATIONS
+
+
 def test_notebook_bridge_episode_through_gym_step(golden_dir):
     from assembly_gym.envs.assembly_env import AssemblyEnv
     from assembly_gym.envs.gym_env import Action, AssemblyGym, horizontal_bridge_setup, sparse_reward
