@@ -204,6 +204,26 @@ def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, lockste
     assert torch.allclose(out["1"][1], out["0"][1], rtol=1e-4, atol=atol), diff
 
 
+def test_graph_is_recaptured_when_a_call_brings_more_batches(monkeypatch):
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", "1")
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev = torch.device("cuda")
+    env = make_env(64, seed=21)
+    torch.manual_seed(1)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True), env, 10000, 16, 0.95, 0.01, "mse_block_features")
+    for _ in range(4):
+        agent.lockstep(2)
+    first = agent._graph_state
+    assert first is not None and first["n_max"] == 2
+    losses = agent.train_steps(5)                                    # more batches than the captured arrays hold
+    assert agent._graph_state is not first and agent._graph_state["n_max"] == 5
+    assert len(losses) == 5 and all(np.isfinite(losses)) and min(losses) >= 0
+    assert len(agent.train_steps(1)) == 1                            # fewer batches re-use the graph
+
+
 def test_vectorised_loop_writes_reference_layout_checkpoints(tmp_path):
     import json, os
     from robotoddler.training.successor_dqn import main
