@@ -111,14 +111,18 @@ class VecDQN:
     @torch.no_grad()
     def _policy_q(self, env, idx, row_env, stable):
         """q of the policy net for the candidate rows ``idx`` of ``env``."""
-        self.policy_net.eval()
-        if not self._factored(self.policy_net):
+        return self._net_q(self.policy_net, env, idx, row_env, stable)
+
+    @torch.no_grad()
+    def _net_q(self, net, env, idx, row_env, stable):
+        net.eval()
+        if not self._factored(net):
             if env.cand_raster is None:
                 raise ValueError("this Q-network acts on f32 rasters: create the rollout env with f32_rasters=True")
-            return self._forward_rows(self.policy_net, env, idx, row_env, stable)[0]
+            return self._forward_rows(net, env, idx, row_env, stable)[0]
         # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice is the
         # sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
-        net, px, E = self.policy_net, 64 * 64, env.E
+        px, E = 64 * 64, env.E
         binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
         binary[:, 0] = stable.float()
         W1 = net.first_layer().weight
@@ -223,13 +227,25 @@ class VecDQN:
         done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)
         use_sf = 'mse_block_features' in self.loss_parts
         stable_n = rec_p[:, R.O_STABLE_N] > 0.5
-        if idx.numel():
-            self.target_net.eval()
+        lin = rec_p[:, R.O_LIN].float().contiguous()
+        if idx.numel() and self._factored(self.target_net):
+            # q of every next candidate through the factored forward on the bit-packed rasters; the 8204-wide output
+            # (successor features) is only needed for the arg-max row of each transition
+            nq = self._net_q(self.target_net, renv, idx, row_env, stable_n).contiguous().float()
+            q_target, _, arg = dqn_ops.td_target(seg, nq, lin, done, self.gamma)
+            sf_target = None
+            if use_sf:
+                best = arg.long().clamp_(0, idx.numel() - 1)                       # empty segments are 'done': row unused
+                nsf = self._forward_rows(self.target_net, renv, idx[best], row_env[best], stable_n)[1]
+                one_each = torch.arange(E + 1, dtype=torch.int32, device=self.device)
+                _, sf_target, _ = dqn_ops.td_target(one_each, nq[best].contiguous(), lin, done, self.gamma,
+                                                    next_sf=nsf[:, 0], action_raster=action_f.squeeze(1))
+        elif idx.numel():
             nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
             if use_sf and nsf is None:
                 raise ValueError("No successor block features available from the chosen policy net.")
             q_target, sf_target, _ = dqn_ops.td_target(
-                seg, nq.contiguous().float(), rec_p[:, R.O_LIN].float().contiguous(), done, self.gamma,
+                seg, nq.contiguous().float(), lin, done, self.gamma,
                 next_sf=nsf[:, 0] if use_sf else None,
                 action_raster=action_f.squeeze(1) if use_sf else None)
         else:
