@@ -237,11 +237,12 @@ def test_vectorised_loop_writes_reference_layout_checkpoints(tmp_path):
     assert blob["records"].shape[0] > 0
 
 
-def test_single_env_reference_loop_runs():
+@pytest.mark.parametrize("extra", [[], ["--prioritized_replay"]])
+def test_single_env_reference_loop_runs(extra):
     from robotoddler.training.successor_dqn import main
     hist = main(["--model", "SuccessorMLP", "--loss_function", "mse_q_values+mse_block_features", "--tower_height", "2",
                  "--num_episodes", "6", "--num_training_steps", "2", "--batch_size", "4", "--seed", "0",
-                 "--learning_rate", "1e-4"])
+                 "--learning_rate", "1e-4", *extra])
     assert len(hist) == 6 and all(h["num_steps"] >= 1 for h in hist)
 
 
