@@ -143,6 +143,18 @@ def bits_linear(bits, wt, bits_row=None, base=None, base_row=None):
     return out
 
 
+def sigmoid_dot(d, w):
+    """out[r] = sum_j w[j] * sigmoid(d[r, j]) in one pass over ``d`` ([n, k] float32, k % 4 == 0; bridges_sigmoid_dot)."""
+    L = abi.require_gpu()
+    assert d.dtype == torch.float32 and d.dim() == 2 and d.stride(1) == 1
+    w = w.to(torch.float32).reshape(-1).contiguous()
+    n, k = d.shape
+    assert w.numel() == k
+    out = torch.empty(n, dtype=torch.float32, device=d.device)
+    abi.check(L.bridges_sigmoid_dot(n, _ptr(d), d.stride(0), _ptr(w), k, _ptr(out), _stream()), "bridges_sigmoid_dot")
+    return out
+
+
 def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
     """is_stable_rbe (stability.py:49-71) of ONE assembly.  Returns (stable: bool, info: dict)."""
     L = abi.require_gpu()

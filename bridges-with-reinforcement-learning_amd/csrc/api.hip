@@ -423,4 +423,15 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
+int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, const float* w, int32_t k, float* out,
+                        void* stream) {
+    if (n_rows < 0 || k <= 0 || (k & 3) || (row_stride & 3) || !d || !w || !out) return fail_arg("bridges_sigmoid_dot");
+    if ((((uintptr_t)d) | ((uintptr_t)w)) & 15) return fail_arg("sigmoid_dot: rows must be 16-byte aligned");
+    if (n_rows == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_sigmoid_dot, dim3(grid_for_waves(n_rows)), dim3(256), 0, (hipStream_t)stream, n_rows, d, row_stride,
+                       w, k, out);
+    LAUNCH_CHECK("k_sigmoid_dot");
+    return BRIDGES_OK;
+}
+
 }  // extern "C"

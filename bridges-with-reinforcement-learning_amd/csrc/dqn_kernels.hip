@@ -119,4 +119,28 @@ __global__ __launch_bounds__(256) void k_bits_linear(int n_rows, const uint64_t*
     }
 }
 
+// Head of the factored acting forward: q[r] = sum_j w[j] * sigmoid(d[r, j])  (cv.py:101-104: softmax over the two successor
+// channels, channel 1, times the reward map, summed over the image) in ONE pass over d instead of sigmoid / mul / sum
+// passes.  One wave per row, 16 B per lane per trip; lane partial sums in f32, the 64 partials added in f64.
+__global__ __launch_bounds__(256) void k_sigmoid_dot(int n_rows, const float* __restrict__ d, int64_t row_stride,
+                                                     const float* __restrict__ w, int k, float* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int r = wave; r < n_rows; r += nwaves) {
+        const float* row = d + (size_t)r * row_stride;
+        float acc = 0.f;
+        for (int j = 4 * lane; j < k; j += 4 * WAVE) {
+            const float4 x = *reinterpret_cast<const float4*>(row + j);
+            const float4 ww = *reinterpret_cast<const float4*>(w + j);
+            acc += ww.x / (1.f + __expf(-x.x));
+            acc += ww.y / (1.f + __expf(-x.y));
+            acc += ww.z / (1.f + __expf(-x.z));
+            acc += ww.w / (1.f + __expf(-x.w));
+        }
+        const double total = wave_sum_d((double)acc);
+        if (lane == 0) out[r] = (float)total;
+    }
+}
+
 }  // namespace bridges

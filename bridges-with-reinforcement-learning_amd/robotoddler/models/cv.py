@@ -123,8 +123,9 @@ class SuccessorMLP(nn.Module):
         return binary_features @ W1[:, 4 * px:].T + const
 
     @torch.no_grad()
-    def q_from_first_layer(self, h_pre, reward_features):
-        """q from the pre-activation of the first layer ([n, hidden]): the remaining layers and the factored head."""
+    def q_from_first_layer(self, h_pre, reward_features, head=None):
+        """q from the pre-activation of the first layer ([n, hidden]): the remaining layers and the factored head.
+        ``head(d, w) -> sum_j w[j] * sigmoid(d[:, j])`` may be supplied as a fused operator."""
         lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
         h = F.relu(h_pre)
@@ -132,6 +133,8 @@ class SuccessorMLP(nn.Module):
             h = F.relu(layer(h))
         Wo, bo = lin[-1].weight, lin[-1].bias
         d = torch.addmm(bo[px:2 * px] - bo[:px], h, (Wo[px:2 * px] - Wo[:px]).T)
+        if head is not None:
+            return head(d, reward_features.reshape(px))
         return (torch.sigmoid(d) * reward_features.reshape(1, px)).sum(dim=1)
 
 

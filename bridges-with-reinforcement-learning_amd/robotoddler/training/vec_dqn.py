@@ -130,7 +130,7 @@ class VecDQN:
                                base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
                                base_row=torch.arange(E, device=self.device))
         h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
-        return net.q_from_first_layer(h_pre, env.reward_features)
+        return net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot)
 
     @torch.no_grad()
     def td_errors(self, rec):

@@ -210,6 +210,10 @@ int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* strea
  * ascending p, so the result is deterministic. */
 int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* wt, int32_t d,
                         const float* base, const int64_t* base_row, float* out, void* stream);
+/* out[r] = sum_j w[j] * sigmoid(d[r * row_stride + j]), j < k: the q head of SuccessorMLP's factored forward
+ * (q = sum(softmax(psi)[:, 1] * reward_map), cv.py:101-104, with psi1 - psi0 = d) in one pass.  k % 4 == 0. */
+int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, const float* w, int32_t k, float* out,
+                        void* stream);
 /* K2+K3: is_stable_rbe (stability.py:49-71) for n independent assemblies given as
  * padded block lists.  verts [n,K,6,2], shape_id [n,K], n_blocks [n], fixed_mask [n] (bit b = block b
  * is_static)

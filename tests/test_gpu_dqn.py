@@ -189,3 +189,17 @@ def test_bits_linear_matches_the_dense_product(d):
     cnt = torch.randint(0, 5, (4096, 16), generator=g).float()
     got = ops.bits_linear(bits.to(dev), cnt.to(dev))
     assert torch.equal(got.cpu(), dense.reshape(n_img, 4096).float() @ cnt)
+
+
+def test_sigmoid_dot_matches_torch():
+    """bridges_sigmoid_dot: sum_j w[j] * sigmoid(d[r, j]) in one pass (the q head of the factored SuccessorMLP forward)."""
+    from bridges_hip import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    d = (torch.randn((777, 4096), generator=g) * 3).to(dev)
+    w = (torch.rand(4096, generator=g) * 0.02).to(dev)
+    got = ops.sigmoid_dot(d, w)
+    want = (torch.sigmoid(d.double()) * w.double()).sum(dim=1)
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5), float((got.double() - want).abs().max())
+    view = torch.randn((50, 8192), generator=g).to(dev)[:, 4096:]             # row stride != k
+    assert torch.allclose(ops.sigmoid_dot(view, w).double(), (torch.sigmoid(view.double()) * w.double()).sum(dim=1), rtol=1e-5, atol=1e-5)
