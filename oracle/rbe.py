@@ -37,7 +37,7 @@ with forces of 1e5..1e12 x its weight (observed: v* = 0 with max x = 6.4e7 while
 v* = 2.95..3.00 for every bound <= 1e6).  That is a numerical artefact, not an
 equilibrium, and no finite-precision solver decides it reliably.  With the
 budget row the question is well conditioned: over 400 000 decisions of random
-rollouts (tools/stress_c_vs_highs.py) no LP has v* in (1e-6, 1e-4) and the two
+rollouts (tests/stress/stress_c_vs_highs.py) no LP has v* in (1e-6, 1e-4) and the two
 simplex implementations (plain C, HIP) agree with HiGHS on every one.
 """
 import numpy as np

@@ -73,7 +73,7 @@ for name, fn, kw, shapes, mu, n_env in TASKS:
                 out.append(rec)
             if not g.stable:
                 break
-# regression cases found by tools/stress_parity.py are kept across regenerations
+# regression cases found by tests/stress/stress_parity.py are kept across regenerations
 path = os.path.join(HERE, "large_assemblies.json")
 if os.path.exists(path):
     out += [r for r in json.load(open(path)) if r["task"].startswith("regression_")]

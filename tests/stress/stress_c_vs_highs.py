@@ -1,7 +1,7 @@
 """CPU-only adjudication run: the plain-C oracle's two stability booleans of every env-step against HiGHS (numpy
 oracle) on the same assemblies.  The C oracle shares its simplex rules with the device kernel (different arithmetic
 details), so this measures how often those rules disagree with an exact LP solver.
-    python tools/stress_c_vs_highs.py --steps 2000 --envs 8 --procs 8"""
+    python tests/stress/stress_c_vs_highs.py --steps 2000 --envs 8 --procs 8"""
 import argparse
 import ctypes as C
 import multiprocessing as mp
@@ -9,7 +9,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 TASKS = ["tower4", "hexbridge", "mixed", "tower2", "bridge_mu05"]
 

@@ -1,8 +1,8 @@
 """Large randomized parity run: the HIP lock-step environment against the plain-C oracle (oracle/c), env by env and
 step by step -- selected action, both stability booleans, reward, termination, candidate / valid counts, state raster.
-    python tools/stress_parity.py --envs 1024 --locksteps 100 [--task tower4|tower2|hexbridge|mixed|bridge_mu05]"""
+    python tests/stress/stress_parity.py --envs 1024 --locksteps 100 [--task tower4|tower2|hexbridge|mixed|bridge_mu05]"""
 import argparse, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
 import numpy as np, torch
 from oracle.c_env import CEnv

@@ -225,7 +225,7 @@ def test_stress_parity_against_the_c_oracle(task):
     stability booleans, rewards, termination, candidate / valid counts."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--envs", "256", "--locksteps", "40",
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress", "stress_parity.py"), "--envs", "256", "--locksteps", "40",
                           "--task", task, "--seed", "29"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout
