@@ -12,12 +12,12 @@ from bridges_hip import ops
 
 
 def sparse_reward(gym_env, obs, info):                                   # gym_env.py:11-22
-    if gym_env.assembly_env.state_info['collision'] or not gym_env.assembly_env.state_info['stable']:
+    """-1 for a collapsed / colliding assembly; otherwise the number of targets reached, minus one while any is left."""
+    state = gym_env.assembly_env.state_info
+    if state['collision'] or not state['stable']:
         return -1
-    num_targets_reached = len(obs['targets_reached'])
-    if not gym_env.all_targets_reached():
-        return -1 + num_targets_reached
-    return num_targets_reached
+    reached = len(obs['targets_reached'])
+    return reached if gym_env.all_targets_reached() else reached - 1
 
 
 def _shapes(trapezoid, hexagon):
@@ -79,26 +79,20 @@ class AssemblyGym:
 
     def __init__(self, reward_fct, shapes=None, obstacles=None, targets=None, render_mode=None, assembly_env=None,
                  restrict_2d=False, max_steps=None):
-        self.blocks, self.shapes, self.obstacles, self.targets = [], [], [], []
-        self.reward_fct = reward_fct
-        self.render_mode = render_mode
-        self.restrict_2d = restrict_2d
-        self.observation_space = None
-        self.action_space = None
-        self.action_history = None
-        self.block_graph = None
-        self.max_steps = max_steps
         if not restrict_2d:
             raise NotImplementedError          # gym_env.py:131-133: only the 2-D mode exists
-        if assembly_env is None:
-            assembly_env = AssemblyEnv(render=render_mode == 'human')
-        self.assembly_env = assembly_env
+        self.blocks, self.shapes, self.obstacles, self.targets = [], [], [], []
+        self.reward_fct, self.render_mode, self.restrict_2d, self.max_steps = reward_fct, render_mode, restrict_2d, max_steps
+        self.observation_space = self.action_space = None       # gymnasium attributes, unused like in the reference
+        self.action_history = self.block_graph = None
+        self.assembly_env = assembly_env if assembly_env is not None else AssemblyEnv(render=render_mode == 'human')
         self.reset(shapes, obstacles, targets)
 
     def terminated(self, assembly_env):
-        terminated = not assembly_env.state_info['stable'] or assembly_env.state_info['collision'] or self.all_targets_reached()
-        truncated = self.max_steps and len(self.blocks) >= self.max_steps
-        return terminated, truncated
+        """(terminated, truncated); truncated is None / 0 when max_steps is unset (gym_env.py:141-145)."""
+        state = assembly_env.state_info
+        failed = state['collision'] or not state['stable']
+        return failed or self.all_targets_reached(), self.max_steps and len(self.blocks) >= self.max_steps
 
     @property
     def num_targets(self):
@@ -114,10 +108,10 @@ class AssemblyGym:
         return [min(distance_box_point(b.bounding_box, t) for b in self.assembly_env.blocks) for t in self.targets]
 
     def _update_targets(self, new_block):
-        for target in list(self.targets_remaining):
-            if new_block.bounding_box.contains_point(target):
-                self.targets_reached.append(target)
-                self.targets_remaining.remove(target)
+        still_open = []
+        for t in self.targets_remaining:           # a target counts as reached once a block's bounding box holds it
+            (self.targets_reached if new_block.bounding_box.contains_point(t) else still_open).append(t)
+        self.targets_remaining = still_open
 
     def all_targets_reached(self):
         return len(self.targets_remaining) == 0
@@ -164,30 +158,21 @@ class AssemblyGym:
         if len(self.assembly_env.blocks) > 1 and self.assembly_env.blocks[-2].is_static:
             self.assembly_env.unfreeze_block(len(self.assembly_env.blocks) - 2)
         action.frozen = True                   # gym_env.py:238: the last block is always frozen
-        if action.frozen:
-            self.assembly_env.freeze_block(len(self.assembly_env.blocks) - 1)
+        self.assembly_env.freeze_block(new_block_index)
         self._update_targets(new_block)
         self.assembly_env._update_state_info()
-        terminated, truncated = self.terminated(self.assembly_env)
-        info = self._get_info()
-        observation = self._get_obs()
-        reward = self.reward_fct(self, observation, info)
-        return observation, reward, terminated, truncated, info
+        done = self.terminated(self.assembly_env)
+        obs, info = self._get_obs(), self._get_info()
+        return (obs, self.reward_fct(self, obs, info), *done, info)
 
     def reset(self, shapes=None, obstacles=None, targets=None, blocks=None):
         self.assembly_env.reset()
-        self.action_history = []
-        self.blocks = []
-        self.block_graph = {(-1, 0): []}
-        self.targets_reached = []
-        if shapes is not None:
-            self.shapes = shapes
-        if obstacles is not None:
-            self.obstacles = obstacles
-        if targets is not None:
-            self.targets = targets
-        if blocks is not None:
-            self.blocks = blocks
+        self.action_history, self.targets_reached = [], []
+        self.block_graph = {(-1, 0): []}                        # (block, face) -> what is attached there; floor = (-1, 0)
+        self.blocks = blocks if blocks is not None else []
+        for name, value in (("shapes", shapes), ("obstacles", obstacles), ("targets", targets)):
+            if value is not None:
+                setattr(self, name, value)
         self.targets_remaining = list(self.targets)
         small_cube = Shape(urdf_file='shapes/cube06.urdf')
         for b in self.blocks:
