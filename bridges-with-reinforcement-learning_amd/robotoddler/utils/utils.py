@@ -26,19 +26,17 @@ def parse_img_size(s):
 
 
 def optimizer_to(optimizer, device):
-    for state in optimizer.state.values():
-        for k, v in state.items():
-            if isinstance(v, torch.Tensor):
-                state[k] = v.to(device)
+    """Move the optimiser's per-parameter state tensors (utils.py:21-28 of the reference)."""
+    for per_param in optimizer.state.values():
+        per_param.update({name: t.to(device) for name, t in per_param.items() if isinstance(t, torch.Tensor)})
 
 
 def save_checkpoint(path, policy_net, target_net, replay_buffer, optimizer, episode, config, aim_run=None, wandb_run=None):
-    current = os.path.join(path, str(episode))
+    current = os.path.join(path, str(episode))                  # <path>/<episode>/..., utils.py:54-89 of the reference
     os.makedirs(current, exist_ok=True)
-    torch.save(policy_net.state_dict(), os.path.join(current, 'policy_net.pt'))
-    torch.save(target_net.state_dict(), os.path.join(current, 'target_net.pt'))
-    torch.save(optimizer.state_dict(), os.path.join(current, 'optimizer.pt'))
-    replay_buffer.save(os.path.join(current, 'replay_buffer.pt'))
+    for stem, holder in (("policy_net", policy_net), ("target_net", target_net), ("optimizer", optimizer)):
+        torch.save(holder.state_dict(), os.path.join(current, stem + ".pt"))
+    replay_buffer.save(os.path.join(current, "replay_buffer.pt"))
     meta = dict(episode=episode, timestamp=str(datetime.now()), config=config)
     if aim_run is not None:
         meta['aim_hash'] = aim_run.hash
