@@ -63,6 +63,7 @@ def cpu_baseline(tower_height, max_steps, seconds=10.0):
     from oracle import c_env
     c_env.lib()                                      # build once before forking
     # a one-GPU box of this pool gives the job a 16-core share whatever the affinity mask says
+    seconds = float(os.environ.get("BENCH_CPU_SECONDS", seconds))          # tests shorten the sample
     cores = int(os.environ.get("BENCH_CPU_WORKERS", max(1, min(len(os.sched_getaffinity(0)), 16))))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
