@@ -133,6 +133,25 @@ template <int PARTS> __global__ __launch_bounds__(256) void kJ(float* out, long 
         st<false>(p + (r / 4) * 256 + lane * 4, z);
     }
 }
+// K: expansion-only like J, but the piece's row masks arrive through ONE vector load (lane r < ROWS loads row r) and
+// are handed round with a cross-lane shuffle, so a wave pays one memory latency in front of its stores
+template <int PARTS> __global__ __launch_bounds__(256) void kK(float* out, long pieces, const unsigned long long* bits) {
+    const int lane = threadIdx.x & 63;
+    const long pc = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pc >= pieces) return;
+    constexpr int ROWS = 64 / PARTS;
+    const unsigned long long mine = lane < ROWS ? bits[pc * ROWS + lane] : 0ull;
+    float* p = out + pc * (4096 / PARTS);
+    const int sub = lane >> 4, col4 = (lane & 15) * 4;
+#pragma unroll
+    for (int r = 0; r < ROWS; r += 4) {
+        unsigned lo = __shfl((unsigned)mine, r + sub, 64), hi = __shfl((unsigned)(mine >> 32), r + sub, 64);
+        unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        unsigned nib = (unsigned)(m >> col4) & 15u;
+        f32x4 z = {(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        st<false>(p + (r / 4) * 256 + lane * 4, z);
+    }
+}
 template <typename F> void run(const char* name, F launch, float* buf, int items) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -177,6 +196,10 @@ int main() {
     run("J expand 2 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<8>, dim3(items * 8 / 4), dim3(256), 0, 0, buf, (long)items * 8, bitsd); }, buf, items);
     run("J expand 4 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<4>, dim3(items * 4 / 4), dim3(256), 0, 0, buf, (long)items * 4, bitsd); }, buf, items);
     run("J expand 16 KiB (s_load bits)", [&] { hipLaunchKernelGGL(kJ<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, bitsd); }, buf, items);
+    run("K expand 2 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<8>, dim3(items * 8 / 4), dim3(256), 0, 0, buf, (long)items * 8, bitsd); }, buf, items);
+    run("K expand 4 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<4>, dim3(items * 4 / 4), dim3(256), 0, 0, buf, (long)items * 4, bitsd); }, buf, items);
+    run("K expand 8 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<2>, dim3(items * 2 / 4), dim3(256), 0, 0, buf, (long)items * 2, bitsd); }, buf, items);
+    run("K expand 16 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, bitsd); }, buf, items);
     run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
     return 0;
 }
