@@ -152,6 +152,23 @@ template <int PARTS> __global__ __launch_bounds__(256) void kK(float* out, long 
         st<false>(p + (r / 4) * 256 + lane * 4, z);
     }
 }
+// L: "zeros first": the wave stores its whole 16 KiB image as zeros before it knows anything (pure stores), then does the
+// dependent load + ALU prologue of G and overwrites only the ~3 KiB of row groups that hold pixels
+__global__ __launch_bounds__(256) void kL(float* out, long items, const int* meta, int dirty_groups) {
+    int lane = threadIdx.x & 63; long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (it >= items) return;
+    float* p = out + it * 4096;
+    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st<false>(p + r * 256 + lane * 4, zero);
+    int m = meta[it & 1023];
+    double acc = lane * 0.5 + m;
+    for (int i = 0; i < 300; ++i) acc = acc * 1.0000001 + 0.5;
+    f32x4 z = {0.f, 1.f, (float)(acc > 1e300), (float)lane};
+    __builtin_amdgcn_s_waitcnt(0);                              // the zero stores of this wave are complete (vmcnt = 0)
+    int g0 = (int)((it * 7) & 15);
+    for (int g = 0; g < dirty_groups; ++g) st<false>(p + ((g0 + g) & 15) * 256 + lane * 4, z);
+}
 template <typename F> void run(const char* name, F launch, float* buf, int items) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -200,6 +217,9 @@ int main() {
     run("K expand 4 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<4>, dim3(items * 4 / 4), dim3(256), 0, 0, buf, (long)items * 4, bitsd); }, buf, items);
     run("K expand 8 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<2>, dim3(items * 2 / 4), dim3(256), 0, 0, buf, (long)items * 2, bitsd); }, buf, items);
     run("K expand 16 KiB (vector load)", [&] { hipLaunchKernelGGL(kK<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, bitsd); }, buf, items);
+    run("L zeros first + 3 dirty groups", [&] { hipLaunchKernelGGL(kL, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta, 3); }, buf, items);
+    run("L zeros first + 0 dirty groups", [&] { hipLaunchKernelGGL(kL, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta, 0); }, buf, items);
+    run("G 16 KiB + load + ALU (again)", [&] { hipLaunchKernelGGL(kG<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
     run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
     return 0;
 }
