@@ -169,6 +169,19 @@ __global__ __launch_bounds__(256) void kL(float* out, long items, const int* met
     int g0 = (int)((it * 7) & 15);
     for (int g = 0; g < dirty_groups; ++g) st<false>(p + ((g0 + g) & 15) * 256 + lane * 4, z);
 }
+// M: like G (dependent load + ALU, then 16/PARTS KiB of stores) with the ALU chain a parameter: models PARTS waves per
+// image that each redo the (short) half-plane tests of the block's row window and store only their own rows
+template <int PARTS> __global__ __launch_bounds__(256) void kM(float* out, long pieces, const int* meta, int alu) {
+    int lane = threadIdx.x & 63; long pc = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pc >= pieces) return;
+    int m = meta[(pc / PARTS) & 1023];
+    double acc = lane * 0.5 + m;
+    for (int i = 0; i < alu; ++i) acc = acc * 1.0000001 + 0.5;
+    f32x4 z = {0.f, 0.f, (float)(acc > 1e300), (float)lane};
+    float* p = out + pc * (4096 / PARTS);
+#pragma unroll
+    for (int r = 0; r < 16 / PARTS; ++r) st<false>(p + r * 256 + lane * 4, z);
+}
 template <typename F> void run(const char* name, F launch, float* buf, int items) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch();
@@ -220,6 +233,15 @@ int main() {
     run("L zeros first + 3 dirty groups", [&] { hipLaunchKernelGGL(kL, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta, 3); }, buf, items);
     run("L zeros first + 0 dirty groups", [&] { hipLaunchKernelGGL(kL, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta, 0); }, buf, items);
     run("G 16 KiB + load + ALU (again)", [&] { hipLaunchKernelGGL(kG<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta); }, buf, items);
+    for (int alu : {0, 60, 150}) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "M 4 KiB + load + %d FMA", alu);
+        run(nm, [&] { hipLaunchKernelGGL(kM<4>, dim3(items), dim3(256), 0, 0, buf, (long)items * 4, meta, alu); }, buf, items);
+        snprintf(nm, sizeof(nm), "M 2 KiB + load + %d FMA", alu);
+        run(nm, [&] { hipLaunchKernelGGL(kM<8>, dim3(items * 2), dim3(256), 0, 0, buf, (long)items * 8, meta, alu); }, buf, items);
+        snprintf(nm, sizeof(nm), "M 16 KiB + load + %d FMA", alu);
+        run(nm, [&] { hipLaunchKernelGGL(kM<1>, dim3(items / 4), dim3(256), 0, 0, buf, (long)items, meta, alu); }, buf, items);
+    }
     run("E linear fill full grid", [&] { hipLaunchKernelGGL(kE<false>, dim3(items * 4), dim3(256), 0, 0, buf, items); }, buf, items);
     return 0;
 }
