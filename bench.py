@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--tower_height", type=int, default=4)
     ap.add_argument("--max_steps", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, one HIP stream each")
+    ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
     ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
@@ -232,7 +232,7 @@ def main():
                 for name, kw in (("sparse_raster_update", dict(f32_rasters=True, sparse_raster_update=True)),
                                  ("bit_packed_rasters_only", dict(f32_rasters=False))):
                     e2 = VecAssemblyGymGroups(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
-                                              groups=args.groups, max_steps=args.max_steps, seed=args.seed * 1000003 + rank,
+                                              groups=3, max_steps=args.max_steps, seed=args.seed * 1000003 + rank,
                                               device=dev, **kw)
                     for _ in range(args.warmup):
                         e2.lockstep_random()
