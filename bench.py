@@ -8,15 +8,25 @@ candidates -> (A+1) 64x64 f32 rasters -> bounds/overlap mask -> linear reward  (
 `value` counts real environment steps (reset-only lock-steps of an env are not counted).
 
   python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (a
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` child,
+before anything touches the GPU) and passes the child's output through; launched under torchrun
+by someone else it is simply one of the ranks.
 
 Envs are independent: each rank owns E envs (weak scaling), there is no data-path collective;
 the only communication is the barrier / max-reduce of the timing contract.
+
+Side numbers (never part of `value`) ride in the same JSON line under `other_modes`, each measured in
+a child process of its own: the two cheaper raster modes, the candidate-stability mask
+(`is_action_stable_rbe` over every valid candidate, LPs/s), BASELINE.json's config-5 simulator
+workload (hexagon, bridge span) and training in the loop for configs[1] and configs[2].
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +37,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_FILE = os.path.join("profiles", "r01_pmc_k_raster.json")
 
 
 def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4):
@@ -41,12 +52,37 @@ def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4):
             + 100 * E)                     # stability I/O
 
 
+def task_of(args):
+    """(shape names, obstacles, targets, label) of the synthetic task: --bridge_length N -> horizontal_bridge_setup
+    (gym_env.py:25-43), else --tower_height N -> bridge_setup(H=.8, num_stories=N) (gym_env.py:46-61)."""
+    names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[args.shapes]
+    if args.bridge_length:
+        sq, n = 0.6, args.bridge_length
+        targets = [(n * sq + 2.5 * sq, 0.0, sq / 2)]
+        obstacles = [(i * sq, 0.0, sq / 2) for i in range(1, n + 1)]
+        label = "horizontal_bridge_setup(num_obstacles=%d)" % n
+    else:
+        H, n = 0.8, args.tower_height
+        targets = [(0.5, 0.0, n * H + H / 2)]
+        obstacles = [(0.5, 0.0, i * H + H / 2) for i in range(n)]
+        label = "bridge_setup(num_stories=%d)" % n
+    return names, obstacles, targets, label
+
+
 # ------------------------------------------------------------------------- CPU baseline (oracle)
-def _cpu_worker(args):
-    seed, env_id, seconds, tower_height, max_steps = args
+def _oracle_setup(args):
+    from oracle.env import bridge_setup, horizontal_bridge_setup
+    trap, hexa = args.shapes in ("trapezoid", "both"), args.shapes in ("hexagon", "both")
+    if args.bridge_length:
+        return horizontal_bridge_setup(num_obstacles=args.bridge_length, trapezoid=trap, hexagon=hexa)
+    return bridge_setup(num_stories=args.tower_height, trapezoid=trap, hexagon=hexa)
+
+
+def _cpu_worker(job):
+    seed, env_id, seconds, setup, max_steps = job
     from oracle.c_env import CEnv
-    from oracle.env import OracleGym, bridge_setup
-    ce = CEnv(OracleGym(**bridge_setup(num_stories=tower_height), max_steps=max_steps))
+    from oracle.env import OracleGym
+    ce = CEnv(OracleGym(**setup, max_steps=max_steps))
     ce.enable_f32()                                  # same unit of work: f32 rasters for every raw candidate
     ce.run(seed, env_id, 200)                        # warm-up
     n, chunk = 0, 2000
@@ -56,61 +92,172 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(tower_height, max_steps, seconds=10.0):
+def _numpy_highs_worker(job):
+    """The numpy + HiGHS restatement (oracle/env.py) itself, one process: the same lock-step protocol, rasters of
+    every raw candidate, LPs by scipy.optimize.linprog."""
+    seed, min_steps, seconds, setup, max_steps = job
+    from oracle.env import OracleGym, OracleLockstep, policy_draw
+    o = OracleLockstep(OracleGym(**setup, max_steps=max_steps))
+    n, ctr = 0, [0]
+
+    def pick(nv):
+        r = policy_draw(seed, 0, ctr[0]) % nv
+        ctr[0] += 1
+        return r
+    t0 = time.perf_counter()
+    while n < min_steps or time.perf_counter() - t0 < seconds:
+        n += 1 if o.lockstep(pick)["valid_step"] else 0
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(args, seconds=10.0):
     """The plain-C restatement of the path (oracle/c, tested bit for bit against the numpy + HiGHS oracle), one
-    environment per process on every host core."""
+    environment per process on every host core (the headline `value`), then alone on one core, then the numpy +
+    HiGHS oracle on one core (SURVEY.md §8d asks for all three)."""
     import multiprocessing as mp
     from oracle import c_env
     c_env.lib()                                      # build once before forking
+    setup = _oracle_setup(args)
     # a one-GPU box of this pool gives the job a 16-core share whatever the affinity mask says
     seconds = float(os.environ.get("BENCH_CPU_SECONDS", seconds))          # tests shorten the sample
     cores = int(os.environ.get("BENCH_CPU_WORKERS", max(1, min(len(os.sched_getaffinity(0)), 16))))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(0, i, seconds, tower_height, max_steps) for i in range(cores)])
-    steps = sum(r[0] for r in res)
-    wall = max(r[1] for r in res)
+        res = pool.map(_cpu_worker, [(0, i, seconds, setup, args.max_steps) for i in range(cores)])
+        steps = sum(r[0] for r in res)
+        wall = max(r[1] for r in res)
+        one = pool.map(_cpu_worker, [(0, 0, max(1.0, seconds / 2), setup, args.max_steps)])[0]
+        nh = pool.map(_numpy_highs_worker, [(0, int(os.environ.get("BENCH_NUMPY_STEPS", 200)), max(1.0, seconds / 2),
+                                             setup, args.max_steps)])[0]
     return dict(value=steps / wall, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"{cores} processes x {seconds:.0f} s of tower_height={tower_height} random-policy lock-steps "
+                sample=f"{cores} processes x {seconds:.0f} s of {task_of(args)[3]} random-policy lock-steps "
                        f"({steps} env-steps) with oracle/c/oracle_env.c (scalar C, -O2, float64, own simplex, "
-                       f"bit + f32 rasters); the numpy/HiGHS oracle it mirrors runs ~30 env-steps/s per core")
+                       f"bit + f32 rasters)",
+                one_core=dict(value=one[0] / one[1], unit="env-steps/s", cores=1, kind="port",
+                              sample=f"the same C port, 1 process alone, {one[1]:.1f} s ({one[0]} env-steps)"),
+                numpy_highs=dict(value=nh[0] / nh[1], unit="env-steps/s", cores=1, kind="port",
+                                 sample=f"oracle/env.py (numpy float64 + scipy HiGHS LPs), 1 process, {nh[1]:.1f} s "
+                                        f"({nh[0]} env-steps)"))
+
+
+# ------------------------------------------------------------------------- self-launch for --gpus N
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: start N ranks ourselves.  Runs before torch is imported, so this
+    parent never touches the GPU; the ranks are children and the parent exits with their code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------- side modes (child processes)
+def _child_json(cmd, timeout, env=None):
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if res.returncode != 0 or not line:
+        return None, (res.stderr or "no output")[-300:]
+    return json.loads(line[-1]), None
+
+
+def side_modes(args):
+    """Each in a process of its own (as if started by hand): how HIP maps the streams of a SECOND set of groups onto
+    hardware queues inside one process moved the latency-bound modes by +-30 %."""
+    me = os.path.abspath(__file__)
+    base = [sys.executable, me, "--no-cpu-baseline", "--no-other-modes", "--envs", str(args.envs), "--steps", str(args.steps),
+            "--warmup", str(args.warmup), "--seed", str(args.seed)]
+    task = ["--tower_height", str(args.tower_height), "--max_steps", str(args.max_steps), "--shapes", args.shapes]
+    if args.bridge_length:
+        task += ["--bridge_length", str(args.bridge_length)]
+    out = {}
+
+    def sim(name, extra):
+        try:
+            sub, err = _child_json(base + extra, 600)
+            if sub is None:
+                out[name] = {"error": err}
+                return
+            out[name] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+                         "groups": sub["config"].get("groups"), "workload": sub["config"]["workload"]}
+            for k in ("roofline", "candidate_stability"):
+                if k in sub:
+                    out[name][k] = sub[k]
+        except Exception as exc:
+            out[name] = {"error": repr(exc)[:300]}
+
+    sim("sparse_raster_update", task + ["--sparse-raster-update", "--groups", "3"])
+    sim("bit_packed_rasters_only", task + ["--no-f32-rasters", "--groups", "3"])
+    sim("candidate_stability", task + ["--mode", "candidate-stability"])
+    # BASELINE.json configs[4]'s simulator workload: hexagon blocks, bridge-span task, max_steps=15
+    sim("config5_hexagon_bridge", ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15", "--groups", str(args.groups)])
+    if os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
+        tool = os.path.join(ROOT, "tools", "train_throughput.py")
+        for name, extra in (("train_config3_successor_mlp", ["--envs", "4096", "--tower", "4", "--max_steps", "15", "--model",
+                                                             "SuccessorMLP", "--loss", "mse_block_features"]),
+                            ("train_config2_convnet", ["--envs", "1024", "--tower", "2", "--max_steps", "10", "--model",
+                                                       "ConvNet", "--loss", "mse_q_values"])):
+            try:
+                sub, err = _child_json([sys.executable, tool, "--locksteps", os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12"),
+                                        "--warmup", "6", *extra], 900)
+                if sub is None:
+                    out[name] = {"error": err}
+                    continue
+                out[name] = {"value": sub["env_steps_per_s"], "unit": "env-steps/s (acting + replay + 25 optimiser steps per lock-step)",
+                             "ms_per_lockstep": sub["ms_per_lockstep"], "ms_act": sub["ms_act"], "ms_targets": sub["ms_targets"],
+                             "ms_per_train_step": sub["ms_per_train_step"], "config": sub["config"]}
+            except Exception as exc:
+                out[name] = {"error": repr(exc)[:300]}
+    return out
 
 
 # ------------------------------------------------------------------------- main
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--tower_height", type=int, default=4)
+    ap.add_argument("--bridge_length", type=int, default=0, help="> 0: horizontal_bridge_setup(num_obstacles=N) instead of the tower")
+    ap.add_argument("--shapes", choices=["trapezoid", "hexagon", "both"], default="trapezoid")
     ap.add_argument("--max_steps", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, one HIP stream each")
+    ap.add_argument("--mode", choices=["sim", "candidate-stability"], default="sim",
+                    help="candidate-stability: every lock-step also decides is_action_stable_rbe for every valid candidate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
     ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
-    ap.add_argument("--no-other-modes", action="store_true", help="skip the short runs of the two other raster modes")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the child runs of the side modes")
     ap.add_argument("--sparse-raster-update", action="store_true",
                     help="f32 rasters, but only the row groups that change are stored (reported as its own mode)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.tower_height, args.max_steps)      # before the GPU is initialised (fork pool)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "sim":
+        cpu = cpu_baseline(args)                       # before the GPU is initialised (fork pool)
 
     import torch
     import torch.distributed as dist
     from bridges_hip.shapes import load_urdf
-    from bridges_hip.vec_env import VecAssemblyGymGroups
+    from bridges_hip.vec_env import VecAssemblyGym, VecAssemblyGymGroups
 
     # one process per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share one card to rehearse the N>1 code path
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -118,22 +265,42 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        ranks_seen = dist.get_world_size()
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    H = 0.8                                                     # gym_env.py:46 bridge_setup(H=.8, num_stories=N)
-    targets = [(0.5, 0.0, args.tower_height * H + H / 2)]
-    obstacles = [(0.5, 0.0, i * H + H / 2) for i in range(args.tower_height)]
-    env = VecAssemblyGymGroups(args.envs, [load_urdf("shapes/trapezoid.urdf")], obstacles, targets,
-                               groups=args.groups, max_steps=args.max_steps, seed=args.seed * 1000003 + rank,
-                               device=dev, f32_rasters=not args.no_f32_rasters, debug=args.debug,
-                               sparse_raster_update=args.sparse_raster_update)
-    lockstep = env.lockstep_random
+    names, obstacles, targets, task_label = task_of(args)
+    geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
+    V = sum(g.num_faces_2d for g in geoms) / len(geoms)
+    kw = dict(max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev, f32_rasters=not args.no_f32_rasters,
+              debug=args.debug, sparse_raster_update=args.sparse_raster_update)
+    cand_mode = args.mode == "candidate-stability"
+    if cand_mode:
+        env = VecAssemblyGym(args.envs, geoms, obstacles, targets, env_id_base=0, **kw)
+        cand_ev, cand_count = [], []
+
+        def lockstep():
+            env.select_random()
+            env.step()
+            if len(cand_ev) < 4096:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                n_dec = env.candidate_stability_mask()
+                b.record()
+                cand_ev.append((a, b))
+                cand_count.append(n_dec)
+            else:
+                env.candidate_stability_mask()
+        env.sync = lambda: None
+    else:
+        env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, **kw)
+        lockstep = env.lockstep_random
 
     for _ in range(args.warmup):
         lockstep()
@@ -146,6 +313,9 @@ def main():
         torch.cuda.synchronize()
 
     sync()
+    if cand_mode:
+        cand_ev.clear()
+        cand_count.clear()
     s0 = env.read_stats()
     if not args.no_kernel_timing:
         env.timing_begin(args.steps)
@@ -175,20 +345,29 @@ def main():
         # HBM traffic per launch: measured/algorithmic ratio of the committed PMC passes (profiles/), applied to
         # this run's launch size -- PMC counters cannot be collected inside an un-profiled bench run
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_raster.json")))
-            # counters were taken at 4096 envs in one group; scale to this run's launch size
+            pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
             traffic_ratio = pm["hbm_bytes_per_launch"] / pm["algorithmic_bytes_per_launch"]
         except Exception:
             traffic_ratio = None
-        alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units)
+        alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units, V)
         per_launch = alg / max(n_launch, 1)
         avg_ms = raster_ms / max(n_launch, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        raster_mode = ("bit-packed rasters only" if args.no_f32_rasters
+                       else "f32 64x64 rasters for every raw candidate, sparse row-group update" if args.sparse_raster_update
+                       else "f32 64x64 rasters for every raw candidate")
+        if cand_mode:
+            raster_mode += ", is_action_stable_rbe for every valid candidate"
+        if args.bridge_length:
+            metric = "env-steps/sec (vectorised assembly_gym, %s, %s)" % (task_label, args.shapes)
+        else:
+            metric = "env-steps/sec (vectorised assembly_gym, tower_height=%d)" % args.tower_height
         out = {
-            "metric": "env-steps/sec (vectorised assembly_gym, tower_height=%d)" % args.tower_height,
+            "metric": metric,
             "value": steps_all / dt_all,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_all / args.steps * 1e3,
@@ -198,56 +377,52 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%d envs/GPU lock-step, bridge_setup(num_stories=%d), trapezoid, max_steps=%d, "
-                            "uniform-random policy, %s" % (args.envs, args.tower_height, args.max_steps,
-                                                           "bit-packed rasters only" if args.no_f32_rasters
-                                                           else "f32 64x64 rasters for every raw candidate, sparse row-group update"
-                                                           if args.sparse_raster_update
-                                                           else "f32 64x64 rasters for every raw candidate"),
-                "envs_per_gpu": args.envs, "groups": args.groups, "tower_height": args.tower_height, "max_steps": args.max_steps,
+                "workload": "%d envs/GPU lock-step, %s, %s, max_steps=%d, uniform-random policy, %s"
+                            % (args.envs, task_label, args.shapes, args.max_steps, raster_mode),
+                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups, "tower_height": args.tower_height,
+                "bridge_length": args.bridge_length, "shapes": args.shapes, "max_steps": args.max_steps,
                 "mean_raw_candidates": d["sum_cand"] / max(units, 1),
                 "mean_valid_candidates": d["sum_valid"] / max(units, 1),
                 "mean_blocks": d["sum_blocks"] / max(units, 1),
                 "env_step_fraction": env_steps / max(units, 1),
                 "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
+                "debug": args.debug, "dist_backend": backend if world > 1 else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_raster",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (traffic_ratio * per_launch) if traffic_ratio else None,
+                "traffic_source": "static ratio (HBM bytes / algorithmic bytes of the committed PMC passes, %s) applied to this "
+                                  "run's algorithmic bytes per launch; not measured in this run" % PMC_FILE,
                 "avg_launch_ms": avg_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_launch,
                 "whole_step_GBps": alg / dt / 1e9,
             },
         }
+        if cand_mode:
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in cand_ev)
+            n_dec = int(sum(int(c) for c in cand_count))
+            total = env.total_candidates()
+            cst = env.cand_stable[:total][env.cand_mask[:total].bool()]
+            out["candidate_stability"] = {
+                "decisions": n_dec, "decisions_per_s": n_dec / (ms * 1e-3) if ms > 0 else 0.0, "unit": "LPs/s",
+                "ms_per_lockstep": ms / max(len(cand_ev), 1), "decisions_per_lockstep": n_dec / max(len(cand_ev), 1),
+                "last_lockstep": {"stable": int((cst == 1).sum()), "unstable": int((cst == 0).sum()), "errors": int((cst == 2).sum()),
+                                  "queued_large_tableaux": int(env.cand_counters[0])}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if world == 1 and not (args.no_other_modes or args.no_f32_rasters or args.sparse_raster_update or args.debug):
-            # the two other raster modes of the same workload, for orientation only: never part of `value`.  Each runs
-            # in its own child process (as if started by hand): how HIP maps the streams of a SECOND set of groups onto
-            # hardware queues inside one process moved these latency-bound modes by +-30 %
+        plain = not (args.no_f32_rasters or args.sparse_raster_update or args.debug or cand_mode or args.bridge_length
+                     or args.shapes != "trapezoid")
+        if world == 1 and plain and not args.no_other_modes:
             try:
                 del env, lockstep
                 torch.cuda.empty_cache()
-                import subprocess
-                out["other_modes"] = {}
-                for name, flag in (("sparse_raster_update", "--sparse-raster-update"),
-                                   ("bit_packed_rasters_only", "--no-f32-rasters")):
-                    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-modes", flag,
-                           "--groups", "3", "--envs", str(args.envs), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                           "--tower_height", str(args.tower_height), "--max_steps", str(args.max_steps), "--seed", str(args.seed)]
-                    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                    line = [l for l in res.stdout.splitlines() if l.startswith("{")]
-                    if res.returncode != 0 or not line:
-                        out["other_modes"][name] = {"error": (res.stderr or "no output")[-200:]}
-                        continue
-                    sub = json.loads(line[-1])
-                    out["other_modes"][name] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
-                                                "groups": sub["config"]["groups"]}
+                out["other_modes"] = side_modes(args)
             except Exception as exc:                     # the headline line must survive whatever happens here
                 out["other_modes"] = {"error": repr(exc)[:200]}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

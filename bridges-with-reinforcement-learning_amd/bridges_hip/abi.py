@@ -106,13 +106,21 @@ ENV_BUFFER_FIELDS = [
 ]
 
 
+# buffers that follow lp_ws_stride / stats in bridges_env_buffers
+ENV_BUFFER_FIELDS_TAIL = [
+    ("cand_stable", "uint8", "C"),
+    ("cand_queue", "int32", "C"),
+    ("cand_counters", "int32", "4"),
+]
+
+
 class EnvBuffers(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS] + [
-        ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)]
+        ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)] + [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS_TAIL]
 
 
 # put lp_ws_stride right after lp_ws as in the header (fields above are already in header order)
-assert [f[0] for f in EnvBuffers._fields_][-3:] == ["lp_ws", "lp_ws_stride", "stats"]
+assert [f[0] for f in EnvBuffers._fields_][-6:-3] == ["lp_ws", "lp_ws_stride", "stats"]
 
 _lib = None
 
@@ -138,6 +146,7 @@ def lib():
         "bridges_env_select_random": [vp, vp],
         "bridges_env_lockstep_random": [vp, vp],
         "bridges_env_refresh": [vp, vp],
+        "bridges_env_candidate_stability": [vp, vp],
         "bridges_gate_create": [C.POINTER(vp)],
         "bridges_gate_destroy": [vp],
         "bridges_env_set_gate": [vp, vp],
@@ -170,6 +179,7 @@ def lib():
 EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
+    "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
     "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability",

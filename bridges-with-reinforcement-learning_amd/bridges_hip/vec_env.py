@@ -106,7 +106,7 @@ class VecAssemblyGym:
         self.x_discr_ground = [float(v) for v in x_discr_ground]
         self.offset_values = [float(v) for v in offset_values]
         self.seed = int(seed)
-        self.debug = int(debug) | int(os.environ.get("BRIDGES_DEBUG", "0"))     # experiments only
+        self.debug = int(debug)                     # kernel timing experiments only (bench.py --debug echoes it in its line)
         self.env_id_base = int(env_id_base)
         # the task's shape table = the env's shapes + cube06 for obstacles/targets (gym_env.py:277)
         self.cube06 = load_urdf("shapes/cube06.urdf")
@@ -141,9 +141,13 @@ class VecAssemblyGym:
                 continue
             shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))
             self.buf[name] = torch.zeros(shp, dtype=getattr(torch, dt), device=self.device)
+        for name, dt, shape in abi.ENV_BUFFER_FIELDS_TAIL:
+            shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))
+            self.buf[name] = torch.zeros(shp, dtype=getattr(torch, dt), device=self.device)
         self.stats = torch.zeros(8, dtype=torch.int64, device=self.device)
         for k, v in self.buf.items():
             setattr(self, k, v)
+        self._contacts_current = True
 
     def _task_features(self):
         """get_task_features (successor_dqn.py:67-85): obstacle raster and the Gaussian-blurred target raster,
@@ -218,6 +222,8 @@ class VecAssemblyGym:
             setattr(b, name, self.buf[name].data_ptr() if self.buf[name] is not None else None)
         b.lp_ws_stride = self.ws_stride
         b.stats = self.stats.data_ptr()
+        for name, _, _ in abi.ENV_BUFFER_FIELDS_TAIL:
+            setattr(b, name, self.buf[name].data_ptr())
         self._env = C.c_void_p()
         abi.check(self.L.bridges_env_create(C.byref(t), C.byref(b), C.byref(self._env)), "bridges_env_create")
 
@@ -231,6 +237,7 @@ class VecAssemblyGym:
     # ------------------------------------------------------------------ lock-step API
     def reset(self):
         abi.check(self.L.bridges_env_reset(self._env, _stream()), "bridges_env_reset")
+        self._contacts_current = True
 
     def select_random(self):
         """Synthetic uniform-random policy over each env's valid candidates -> sel_index."""
@@ -264,6 +271,7 @@ class VecAssemblyGym:
         self.buf["blk_occ"].copy_(blk_occ)
         self.buf["needs_reset"].zero_()
         self.buf["n_if"].zero_()                      # interfaces are only needed by step(); replay states never step
+        self._contacts_current = False
         flat_shape = self.buf["blk_shape"].reshape(E * K)
         abi.check(self.L.bridges_pose_block(self.table.ptr, E * K, _ptr(flat_shape), _ptr(self.buf["blk_pose"]),
                                             _ptr(self.buf["blk_verts"]), _stream()), "bridges_pose_block")
@@ -299,44 +307,24 @@ class VecAssemblyGym:
         abi.check(self.L.bridges_bits_or(self.E, _ptr(ranges), _ptr(bits), _ptr(out), _stream()), "bridges_bits_or")
         return out
 
-    def candidate_stability(self, chunk=8192):
-        """is_action_stable_rbe (assembly_gym/utils/stability.py:122-130 of the reference) for EVERY valid candidate
-        of every env in one batch: the candidate block is appended to its env's assembly (the last placed block
-        stays frozen, gym_env.py:238-240) and the HIP contact + simplex kernel decides.  Returns (rows, stable):
-        compact candidate indices and a bool per row."""
-        idx, row_env = self.valid_rows()
-        n = idx.numel()
-        K16 = abi.MAX_BLOCKS
-        out = torch.zeros(n, dtype=torch.bool, device=self.device)
-        if n == 0:
-            return idx, out
-        ws_stride = abi.lp_ws_stride(K16)
-        if getattr(self, "_stab_ws", None) is None:
-            self._stab_ws = torch.empty((chunk, ws_stride), dtype=torch.float64, device=self.device)
-        for lo in range(0, n, chunk):
-            ii, ee = idx[lo:lo + chunk], row_env[lo:lo + chunk]
-            m = ii.numel()
-            nb = self.buf["n_blocks"][ee].long()
-            pose = torch.zeros((m, K16, 4), dtype=torch.float64, device=self.device)
-            verts = torch.zeros((m, K16, 6, 2), dtype=torch.float64, device=self.device)
-            shape = torch.zeros((m, K16), dtype=torch.int32, device=self.device)
-            pose[:, :self.K] = self.buf["blk_pose"][ee]
-            verts[:, :self.K] = self.buf["blk_verts"][ee]
-            shape[:, :self.K] = self.buf["blk_shape"][ee]
-            r = torch.arange(m, device=self.device)
-            pose[r, nb] = self.buf["cand_pose"][ii]
-            verts[r, nb] = self.buf["cand_verts"][ii]
-            shape[r, nb] = self.buf["cand_desc"][ii, 2]
-            nblocks = (nb + 1).to(torch.int32)
-            fixed = torch.where(nb > 0, torch.ones_like(nb) << (nb - 1).clamp(min=0), torch.zeros_like(nb)).to(torch.int32)
-            stable = torch.zeros(m, dtype=torch.uint8, device=self.device)
-            info = torch.zeros((m, 8), dtype=torch.float64, device=self.device)
-            t = self._create_args
-            abi.check(self.L.bridges_stability(self.table.ptr, m, K16, _ptr(pose), _ptr(verts), _ptr(shape), _ptr(nblocks),
-                                               _ptr(fixed), self.mu, self.density, t[0], t[1], _ptr(stable), _ptr(info),
-                                               _ptr(self._stab_ws), ws_stride, _stream()), "bridges_stability")
-            out[lo:lo + m] = stable.bool() & (info[:, 3] == 0)
-        return idx, out
+    def candidate_stability_mask(self):
+        """is_action_stable_rbe (assembly_gym/utils/stability.py:122-130 of the reference) for EVERY valid candidate of
+        every env, fused on the device (bridges_env_candidate_stability): one wave per candidate appends the candidate
+        block to its env's persistent contact list in LDS (the last placed block stays frozen, gym_env.py:238-240) and
+        solves the feasibility LP.  Fills ``cand_stable`` (uint8 [C]: 1 stable, 0 unstable / masked-out, 2 solver
+        error) without any host synchronisation; returns the number of decisions as a device scalar."""
+        if not self._contacts_current:
+            raise abi.BridgesHipError("candidate stability needs the persistent contact lists of states reached through "
+                                      "reset()/step(); this env was overwritten by load_states()")
+        abi.check(self.L.bridges_env_candidate_stability(self._env, _stream()), "bridges_env_candidate_stability")
+        return self.buf["n_valid"].sum()
+
+    def candidate_stability(self):
+        """-> (rows, stable): compact indices of the valid candidates and a bool per row (errors count as unstable,
+        stability.py:68 + gym_env.py:182)."""
+        self.candidate_stability_mask()
+        idx, _ = self.valid_rows()
+        return idx, self.buf["cand_stable"][idx] == 1
 
     def valid_rows(self):
         """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed."""

@@ -248,6 +248,27 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
+#define CS_TAB_SMALL 640
+#define CS_COLS_SMALL 92
+int bridges_env_candidate_stability(bridges_env* env, void* stream) {
+    if (!env) return fail_arg("null env");
+    const DevCtx& c = env->ctx;
+    if (!c.b.cand_stable || !c.b.cand_queue || !c.b.cand_counters) return fail_arg("cand_stable / cand_queue / cand_counters not given");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(c.b.cand_counters, 0, 2 * sizeof(int32_t), s));
+    // one wave per raw candidate (masked-out ones leave at once); grid from the last known candidate count, grid-stride beyond
+    long long est = (long long)(*(volatile int32_t*)env->h_total);
+    if (est < c.E) est = c.E;
+    est += est / 32 + 64;
+    if (est > env->max_blocks) est = env->max_blocks;
+    hipLaunchKernelGGL((k_candidate_stability<CS_TAB_SMALL, CS_COLS_SMALL, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
+    LAUNCH_CHECK("k_candidate_stability");
+    const int drain = c.E < 512 ? c.E : 512;          // one lp_ws slot per workgroup
+    hipLaunchKernelGGL((k_candidate_stability<LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
+    LAUNCH_CHECK("k_candidate_stability (queue)");
+    return BRIDGES_OK;
+}
+
 int bridges_env_select_random(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");
     hipLaunchKernelGGL(k_select, dim3(env->ctx.E), dim3(WAVE), 0, (hipStream_t)stream, env->ctx, 1);

@@ -142,13 +142,15 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     bool err = false;
     bool st_frozen = true, st_free = true;
     if (!(c.debug & 1))
-        rbe_both(tab, ws, c.b.lp_ws_stride, S, n_if, if_body, if_geom, nb + 1, pose, shape_id, shapes, c.mu, c.density,
-                 lane, &st_frozen, &st_free, &err);
+        rbe_both(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), c.mu,
+                 c.density, lane, &st_frozen, &st_free, &err);
 
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
     const bool all_reached = left == 0;
     const bool terminated = !st_frozen || all_reached;
-    const bool truncated = c.max_steps > 0 && (nb + 1) >= c.max_steps;
+    // gym_env.py:143; a state that fills its K block slots is truncated as well (without a step limit the reference
+    // would go on; the arrays here cannot), so slot nb == K is never written
+    const bool truncated = (c.max_steps > 0 && (nb + 1) >= c.max_steps) || (nb + 1) >= K;
     const bool done = terminated || truncated;
     float reward = !st_frozen ? -1.f : (all_reached ? (float)n_reached : (float)(-1 + n_reached));
     const float base = c.b.cand_lin[ci];
@@ -572,6 +574,132 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
                 c.b.step_flags[(size_t)e * 8 + F_NO_ACTIONS] = 1;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// is_action_stable_rbe (assembly_gym/assembly_gym/utils/stability.py:122-130) for every valid candidate of every env:
+// the candidate block is appended to the assembly (free), the boundary conditions of the placed blocks stay (the last
+// placed block is frozen, gym_env.py:238-240) and the RBE feasibility LP decides.  One wave per candidate.  Nothing is
+// rebuilt: the env's persistent contact list (k_step) is read in place, only the face pairs between the candidate and
+// the older bodies are tested (same pair order as append_interfaces, so the LP is column for column the one k_step
+// would build after placing the candidate) and kept in LDS; the candidate's pose / vertices / frames come from the
+// candidate arrays k_enumerate wrote.  Result: cand_stable[ci] = 1 stable, 0 unstable (or masked-out candidate),
+// 2 = solver error / interface overflow (counts as unstable, stability.py:68 + gym_env.py:182).
+//
+// Two launches share the code.  QUEUE == false: grid over all raw candidates, a small LDS tableau (high occupancy);
+// a candidate whose tableau does not fit is appended to cand_queue (one atomic per such candidate, they are rare).
+// QUEUE == true: a small persistent grid drains that queue with the full-size LDS tableau and the env workspace
+// lp_ws (one slot per workgroup) behind it; every wave leaves when the queue head passes the count.
+#define CS_NEW_IF 16
+template <int TAB, int MAXCOLS, bool QUEUE>
+__global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
+    __shared__ __attribute__((aligned(16))) double tab[TAB];
+    __shared__ LpScratchT<MAXCOLS> S;
+    __shared__ double new_geom[CS_NEW_IF * 8];
+    __shared__ int32_t new_body[CS_NEW_IF * 2];
+    const int lane = threadIdx.x;
+    const int K = c.K;
+    const bridges_shape* shapes = c.tt->shapes;
+    const int total = c.b.cand_offset[c.E];
+    int32_t* cnt = c.b.cand_counters;                 // [0] queue length, [1] queue head
+    const int qlen = QUEUE ? cnt[0] : 0;
+    for (int item = blockIdx.x;; item += gridDim.x) {
+        int ci;
+        if constexpr (QUEUE) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&cnt[1], 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= qlen) return;
+            ci = c.b.cand_queue[i];
+        } else {
+            if (item >= total) return;
+            ci = item;
+            if (!c.b.cand_mask[ci]) {
+                if (lane == 0) c.b.cand_stable[ci] = 0;
+                continue;
+            }
+        }
+        __syncthreads();                               // LDS lists of the previous item are dead
+        const int e = c.b.cand_env[ci];
+        const int nb = c.b.n_blocks[e];                // index the candidate would take
+        const int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
+        const double* pose = c.b.blk_pose + (size_t)e * K * 4;
+        const double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+        const int csh = c.b.cand_desc[(size_t)ci * 4 + 2];
+        const bridges_shape& shn = shapes[csh];
+        const double* cverts = c.b.cand_verts + (size_t)ci * MAXV * 2;
+        const double* cframes = c.b.cand_frames + (size_t)ci * MAXV * 4;
+        const int n_if0 = c.b.n_if[e];
+        // ---- interfaces candidate <-> floor and blocks < nb ----
+        const int totalp = (1 + nb * MAXV) * MAXV;
+        int n_new = 0;
+        for (int p0 = 0; p0 < totalp; p0 += WAVE) {
+            const int p = p0 + lane;
+            bool hit = false;
+            double g[8];
+            int bodyA = -1;
+            if (p < totalp) {
+                const int qa = p / MAXV, fn = p % MAXV;
+                if (fn < shn.nv) {
+                    const int ia = shn.fa[fn], ib = shn.fb[fn];
+                    const double aBx = cverts[2 * ia], aBz = cverts[2 * ia + 1], bBx = cverts[2 * ib], bBz = cverts[2 * ib + 1];
+                    const double cBx = cframes[4 * fn], cBz = cframes[4 * fn + 1], nBx = cframes[4 * fn + 2], nBz = cframes[4 * fn + 3];
+                    if (qa == 0) {
+                        hit = face_pair_contact_v(-c.floor_hw, 0.0, c.floor_hw, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, aBx, aBz, bBx,
+                                                  bBz, cBx, cBz, nBx, nBz, fmin(c.floor_depth, shn.depth), g);
+                    } else {
+                        bodyA = (qa - 1) / MAXV;
+                        const int f = (qa - 1) % MAXV;
+                        const bridges_shape& sa = shapes[shape_id[bodyA]];
+                        if (f < sa.nv) {
+                            const double* v = verts + (size_t)bodyA * MAXV * 2;
+                            const double ax = v[2 * sa.fa[f]], az = v[2 * sa.fa[f] + 1], bx = v[2 * sa.fb[f]], bz = v[2 * sa.fb[f] + 1];
+                            const Frame2 fr = edge_frame(ax, az, bx, bz);
+                            hit = face_pair_contact_v(ax, az, bx, bz, fr.cx, fr.cz, fr.tx, fr.tz, fr.nx, fr.nz, aBx, aBz, bBx, bBz,
+                                                      cBx, cBz, nBx, nBz, fmin(sa.depth, shn.depth), g);
+                        }
+                    }
+                }
+            }
+            const uint64_t bal = __ballot(hit);
+            const int idx = n_new + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && idx < CS_NEW_IF) {
+                new_body[2 * idx] = bodyA;
+                new_body[2 * idx + 1] = nb;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) new_geom[8 * idx + k] = g[k];
+            }
+            n_new += __popcll(bal);
+        }
+        __syncthreads();
+        uint8_t res;
+        if (n_new > CS_NEW_IF || n_if0 + n_new > MAXIF) {
+            res = 2;                                   // contact list overflow (k_step would flag the same placement)
+        } else {
+            AsmView A;
+            A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
+            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh;
+            A.n_if = n_if0 + n_new; A.n_if0 = n_if0;
+            A.if_body0 = c.b.if_body + (size_t)e * MAXIF * 2; A.if_geom0 = c.b.if_geom + (size_t)e * MAXIF * 8;
+            A.if_body1 = new_body; A.if_geom1 = new_geom;
+            const uint32_t fixed = nb > 0 ? (1u << (nb - 1)) : 0u;
+            bool err = false, too_big = false;
+            double w = 0.0;
+            int piv = 0;
+            double* ws = QUEUE ? c.b.lp_ws + (size_t)blockIdx.x * c.b.lp_ws_stride : nullptr;
+            const bool st = rbe_stable(tab, TAB, MAXCOLS, ws, QUEUE ? c.b.lp_ws_stride : (int64_t)0, S, A, fixed, c.mu, c.density,
+                                       lane, &w, &piv, &err, &too_big);
+            if (too_big) {
+                if constexpr (!QUEUE) {
+                    if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;
+                    continue;                          // decided by the second launch
+                }
+                err = true;
+            }
+            res = err ? 2 : (st ? 1 : 0);
+        }
+        if (lane == 0) c.b.cand_stable[ci] = res;
     }
 }
 

@@ -195,8 +195,10 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     double w = 0.0;
     int piv = 0;
     const long long t1 = clock64();
-    bool st = rbe_stable(tab, tab_ws, tab_cap, S, n_if, if_body, if_geom, nb, fm,
-                         pose, shape_id, shapes, mu, density, lane, &w, &piv, &err);
+    bool too_big = false;
+    bool st = rbe_stable(tab, LP_TAB_LDS, LP_MAX_COLS, tab_ws, tab_cap, S, env_view(nb, pose, shape_id, shapes, n_if, if_body, if_geom),
+                         fm, mu, density, lane, &w, &piv, &err, &too_big);
+    err = err || too_big;
     if (lane == 0) {
         stable[e] = (uint8_t)(st && !bad_mask);
         const long long t2 = clock64();

@@ -73,17 +73,20 @@ __device__ inline void stage_faces(FaceLds& F, int q_begin, int q_end, const dou
     }
 }
 
-// oracle/rbe.py face_pair_contact, same operation order.
-__device__ __forceinline__ bool face_pair_contact(const FaceLds& F, int qa, int qb, double depth, double* out8) {
-    double dotn = F.nx[qa] * F.nx[qb] + F.nz[qa] * F.nz[qb];
+// oracle/rbe.py face_pair_contact, same operation order.  Face A: end points a, b, centre c, tangent t, normal n;
+// face B: end points, centre, normal.
+__device__ __forceinline__ bool face_pair_contact_v(double aAx, double aAz, double bAx, double bAz, double cAx, double cAz,
+                                                    double tAx, double tAz, double nAx, double nAz, double aBx, double aBz,
+                                                    double bBx, double bBz, double cBx, double cBz, double nBx, double nBz,
+                                                    double depth, double* out8) {
+    double dotn = nAx * nBx + nAz * nBz;
     if (dotn > -1.0 + RBE_TOL_PARALLEL) return false;
-    double cAx = F.cx[qa], cAz = F.cz[qa], tAx = F.tx[qa], tAz = F.tz[qa], nAx = F.nx[qa], nAz = F.nz[qa];
-    double gap = (F.cx[qb] - cAx) * nAx + (F.cz[qb] - cAz) * nAz;
+    double gap = (cBx - cAx) * nAx + (cBz - cAz) * nAz;
     if (fabs(gap) > RBE_TOL_COPLANAR) return false;
-    double a0 = (F.ax[qa] - cAx) * tAx + (F.az[qa] - cAz) * tAz;
-    double a1 = (F.bx[qa] - cAx) * tAx + (F.bz[qa] - cAz) * tAz;
-    double b0 = (F.ax[qb] - cAx) * tAx + (F.az[qb] - cAz) * tAz;
-    double b1 = (F.bx[qb] - cAx) * tAx + (F.bz[qb] - cAz) * tAz;
+    double a0 = (aAx - cAx) * tAx + (aAz - cAz) * tAz;
+    double a1 = (bAx - cAx) * tAx + (bAz - cAz) * tAz;
+    double b0 = (aBx - cAx) * tAx + (aBz - cAz) * tAz;
+    double b1 = (bBx - cAx) * tAx + (bBz - cAz) * tAz;
     double lo = fmax(fmin(a0, a1), fmin(b0, b1));
     double hi = fmin(fmax(a0, a1), fmax(b0, b1));
     if ((hi - lo) * depth < RBE_AMIN) return false;
@@ -91,6 +94,12 @@ __device__ __forceinline__ bool face_pair_contact(const FaceLds& F, int qa, int 
     out8[2] = cAx + hi * tAx; out8[3] = cAz + hi * tAz;
     out8[4] = nAx; out8[5] = nAz; out8[6] = tAx; out8[7] = tAz;
     return true;
+}
+
+__device__ __forceinline__ bool face_pair_contact(const FaceLds& F, int qa, int qb, double depth, double* out8) {
+    return face_pair_contact_v(F.ax[qa], F.az[qa], F.bx[qa], F.bz[qa], F.cx[qa], F.cz[qa], F.tx[qa], F.tz[qa], F.nx[qa],
+                               F.nz[qa], F.ax[qb], F.az[qb], F.bx[qb], F.bz[qb], F.cx[qb], F.cz[qb], F.nx[qb], F.nz[qb],
+                               depth, out8);
 }
 
 // Append the interfaces between block `nb_new` and every earlier body (floor, blocks < nb_new).
@@ -138,17 +147,50 @@ __device__ inline int append_interfaces(const FaceLds& F, int nb_new, const int3
     return n_if;
 }
 
+// What the LP reads of one assembly: the env's block arrays plus (optionally) one extra block that is not part of the
+// state (a candidate placement, index cand_b), and the contact list as the env's persistent list followed by an
+// appended part (the candidate's interfaces, held in LDS by the wave that found them).
+struct AsmView {
+    const double* pose;            // [K,4] env blocks
+    const int32_t* shape_id;       // [K]
+    const bridges_shape* shapes;
+    int n_blocks;                  // incl. the extra block
+    int cand_b;                    // index of the extra block, or -1
+    const double* cand_pose;       // [4]
+    int cand_shape;
+    int n_if, n_if0;               // interfaces in total / in the first list
+    const int32_t* if_body0;       // [n_if0,2]
+    const double* if_geom0;        // [n_if0,8]
+    const int32_t* if_body1;       // [n_if-n_if0,2]
+    const double* if_geom1;
+    __device__ __forceinline__ const double* P(int b) const { return b == cand_b ? cand_pose : pose + 4 * b; }
+    __device__ __forceinline__ const bridges_shape& S(int b) const { return shapes[b == cand_b ? cand_shape : shape_id[b]]; }
+    __device__ __forceinline__ const int32_t* ib(int k) const { return k < n_if0 ? if_body0 + 2 * k : if_body1 + 2 * (k - n_if0); }
+    __device__ __forceinline__ const double* ig(int k) const { return k < n_if0 ? if_geom0 + 8 * k : if_geom1 + 8 * (k - n_if0); }
+};
+
+__device__ __forceinline__ AsmView env_view(int n_blocks, const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
+                                            int n_if, const int32_t* if_body, const double* if_geom) {
+    AsmView A;
+    A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = n_blocks;
+    A.cand_b = -1; A.cand_pose = pose; A.cand_shape = 0;
+    A.n_if = n_if; A.n_if0 = n_if; A.if_body0 = if_body; A.if_geom0 = if_geom; A.if_body1 = if_body; A.if_geom1 = if_geom;
+    return A;
+}
+
 // Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = the force budget
 // sum_j x_j + s = LP_S_MAX, row m+1 = cost.  Columns [0, n) = cone generators, column n = the budget slack s,
 // column n+1 = right-hand side.
 // Blocks >= n_free are fixed (only the last block is ever frozen, gym_env.py:235-240).
+// Every absolute tolerance of the solve (budget, rhs perturbation, feasibility and verification thresholds) is a
+// force and is therefore scaled by `density` (the right-hand side is linear in it, the matrix does not depend on it);
+// the pivot floor LP_TAU and the reduced-cost threshold are matrix quantities and stay.  At density = 1 the products
+// are exact, i.e. the arithmetic is the one the tolerances were calibrated with.
 // The right-hand side carries a tiny deterministic perturbation (<= 2e-7 per row, far below RBE_FEAS_TOL): these
 // equilibrium systems are massively degenerate (most rhs entries are exactly 0) and the perturbation is what keeps
 // the simplex from stalling.
 template <typename TP>
-__device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n_if, const int32_t* if_body,
-                                const double* if_geom, const int* row_of /*LDS [K]*/, int n_blocks,
-                                const double* pose /*[K,4]*/, const int32_t* shape_id, const bridges_shape* shapes,
+__device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const AsmView& A, const int* row_of /*LDS [K]*/,
                                 double mu, double density, int lane) {
     const int nn = n + 1;                              // structural columns incl. the budget slack; rhs column index
     int cells = (m + 2) * stride;
@@ -156,20 +198,21 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n
     __syncthreads();
     for (int j = lane; j < n; j += WAVE) {
         int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
-        const double* g = if_geom + 8 * k;
+        const double* g = A.ig(k);
+        const int32_t* bd = A.ib(k);
         double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
         double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
         double gx = ig ? nx - mu * tx : nx + mu * tx;
         double gz = ig ? nz - mu * tz : nz + mu * tz;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            int body = if_body[2 * k + (side == 0 ? 1 : 0)];   // side 0: body B (+), side 1: body A (-)
+            int body = bd[side == 0 ? 1 : 0];                  // side 0: body B (+), side 1: body A (-)
             const int r = body >= 0 ? row_of[body] : -1;
             if (r >= 0) {
                 double sgx = side == 0 ? gx : -gx;
                 double sgz = side == 0 ? gz : -gz;
-                const bridges_shape& sh = shapes[shape_id[body]];
-                const double* P = pose + 4 * body;
+                const bridges_shape& sh = A.S(body);
+                const double* P = A.P(body);
                 double rgx, rgz;
                 rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
                 double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
@@ -180,11 +223,11 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n
         }
     }
     for (int i = lane; i < m; i += WAVE)
-        T[i * stride + nn] = LP_PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? 1.0 : LP_S_MAX;
+        T[i * stride + nn] = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? 1.0 : LP_S_MAX * density;
     __syncthreads();
-    for (int b = lane; b < n_blocks; b += WAVE)
-        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * shapes[shape_id[b]].volume;
+    for (int b = lane; b < A.n_blocks; b += WAVE)
+        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * A.S(b).volume;
     __syncthreads();
     for (int q = lane; q <= nn; q += WAVE) {         // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
         double s = 0.0;
@@ -194,14 +237,16 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, int n
     __syncthreads();
 }
 
-struct LpScratch {                 // LDS scratch of one wave's simplex
+template <int MAXCOLS>
+struct LpScratchT {                // LDS scratch of one wave's simplex (MAXCOLS = generator columns it can hold)
     double col[WAVE];              // entering column (row i in slot i, cost entry in slot m)
-    double rowr[LP_MAX_COLS + 4];  // normalised pivot row
+    double rowr[MAXCOLS + 4];      // normalised pivot row
     int basis[WAVE];
     int row_of[MAXK];              // first tableau row of block b, or -1 if the block is fixed (is_static)
     short rows_nz[WAVE];           // rows touched by the current pivot (entering column entry != 0)
-    short cols_nz[LP_MAX_COLS + 4];// columns touched by the current pivot (pivot row entry != 0)
+    short cols_nz[MAXCOLS + 4];    // columns touched by the current pivot (pivot row entry != 0)
 };
+typedef LpScratchT<LP_MAX_COLS> LpScratch;
 
 // Ordering point between the lanes of the ONE wave that owns a tableau.  LDS operations of a wave execute in
 // program order, so for an LDS tableau a compiler fence is enough; the global overflow path needs the real
@@ -244,10 +289,11 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // A pivot is one dependent chain (price -> ratio -> stage -> sweep), so its latency is what bounds the kernel:
 // reductions run on DPP, the cells of the elimination sweep are batched 4 per lane, and the running objective is
 // read from the cost row (the exact artificial sum is recomputed only to confirm a "feasible" exit).
-// Returns w = sum of the artificial basics (<= RBE_FEAS_TOL <=> stable).  All lanes return the same value.
-template <bool IN_LDS, typename TP>
-__device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, LpScratch& S, int lane, int* pivots_out,
-                                   bool* error, bool init_basis) {
+// `feas` = the feasibility threshold (RBE_FEAS_TOL x density).
+// Returns w = sum of the artificial basics (<= feas <=> stable).  All lanes return the same value.
+template <bool IN_LDS, typename TP, typename SC>
+__device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int* pivots_out,
+                                   bool* error, bool init_basis, double feas) {
     // m equilibrium rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials
     // (the others are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
     // Row m is the force-budget row (always enforced, basic variable = its slack, column n_gen), row m+1 the cost.
@@ -262,12 +308,13 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
     bool bland = false;
     const int nchunk = (n + WAVE - 1) / WAVE;
     const int ncols = n + 1;
+    const double progress = 1e-7 * feas;               // 1e-12 at density 1
     LP_PROF_DECL;
     double w = artificial_sum(T, stride, m_act, n, basis, lane);
     for (;;) {
-        if (w <= RBE_FEAS_TOL) {                                   // confirm with the exact artificial sum
+        if (w <= feas) {                                           // confirm with the exact artificial sum
             w = artificial_sum(T, stride, m_act, n, basis, lane);
-            if (w <= RBE_FEAS_TOL) break;
+            if (w <= feas) break;
         }
         LP_STAMP(t_a);
         // ---- entering column ----
@@ -383,7 +430,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         LP_ACC(3, t_d, t_e);
         LP_ACC(5, t_a, t_a + 1);       // pivot count
         const double wn = -T[mc * stride + n];
-        if (wn < w - 1e-12) { stall = 0; bland = false; }
+        if (wn < w - progress) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
         if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m_act, n, basis, lane); break; }
@@ -396,11 +443,9 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
 // Independent check of a "feasible" verdict: read the basic solution x off the tableau and evaluate the ORIGINAL
 // equilibrium rows  sum_j M_ij x_j - w_i  again from the contact list (nothing of the pivoted tableau is reused).
 // A tableau damaged by an ill-conditioned pivot cannot pass this.  Returns the L1 residual over rows < m_chk.
-template <typename TP>
-__device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, LpScratch& S, int n_if,
-                                   const int32_t* if_body, const double* if_geom, int n_blocks, const double* pose,
-                                   const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
-                                   int lane) {
+template <typename TP, typename SC>
+__device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC& S, const AsmView& A, double mu,
+                                   double density, int lane) {
     for (int q = lane; q < n; q += WAVE) S.rowr[q] = 0.0;
     __syncthreads();
     if (lane <= m && S.basis[lane] >= 0 && S.basis[lane] < n) {     // rows incl. the budget row; generators only
@@ -412,19 +457,20 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, Lp
     if (lane < m_chk) {
         // row -> (block, component): rows are 3 per free block in block order (row_of)
         int b = -1;
-        for (int k = 0; k < n_blocks; ++k) if (S.row_of[k] >= 0 && S.row_of[k] <= lane && lane < S.row_of[k] + 3) b = k;
+        for (int k = 0; k < A.n_blocks; ++k) if (S.row_of[k] >= 0 && S.row_of[k] <= lane && lane < S.row_of[k] + 3) b = k;
         const int comp = lane - S.row_of[b];
-        const bridges_shape& sh = shapes[shape_id[b]];
-        const double* P = pose + 4 * b;
+        const bridges_shape& sh = A.S(b);
+        const double* P = A.P(b);
         double rgx, rgz;
         rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
         const double gcx = P[0] + rgx, gcz = P[1] + rgz;
         double acc = 0.0;
-        for (int k = 0; k < n_if; ++k) {
-            const int bA = if_body[2 * k], bB = if_body[2 * k + 1];
+        for (int k = 0; k < A.n_if; ++k) {
+            const int32_t* bd = A.ib(k);
+            const int bA = bd[0], bB = bd[1];
             if (bA != b && bB != b) continue;
             const double sign = (bB == b) ? 1.0 : -1.0;
-            const double* g = if_geom + 8 * k;
+            const double* g = A.ig(k);
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const int ip = c4 >> 1, ig = c4 & 1;
@@ -445,8 +491,8 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, Lp
 
 // Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
 // price it into the cost row.  The tableau then continues from the basis reached so far (warm start).
-template <bool IN_LDS, typename TP>
-__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, LpScratch& S, int lane) {
+template <bool IN_LDS, typename TP, typename SC>
+__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane) {
     const int n = n_gen + 1;
     for (int i = m_act; i < m; ++i) {
         const bool neg = T[i * stride + n] < 0.0;                  // uniform
@@ -461,100 +507,104 @@ __device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int 
     wave_sync<IN_LDS>();
 }
 
-// Shared setup of a solve: row map of the free blocks, tableau placement.  Returns false on overflow.
-__device__ inline void lp_row_map(LpScratch& S, uint32_t free_mask, int lane) {
+// Shared setup of a solve: row map of the free blocks.
+template <typename SC>
+__device__ inline void lp_row_map(SC& S, uint32_t free_mask, int lane) {
     __syncthreads();
     if (lane < MAXK)
         S.row_of[lane] = ((free_mask >> lane) & 1u) ? 3 * __popc(free_mask & ((1u << lane) - 1u)) : -1;
     __syncthreads();
 }
 
-// Stability of one assembly variant.  fixed_mask bit b = block b is_static (fixed).
-__device__ inline bool rbe_stable(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
-                                  const int32_t* if_body, const double* if_geom, int n_blocks, uint32_t fixed_mask,
-                                  const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
-                                  double mu, double density, int lane, double* w_out, int* pivots_out,
-                                  bool* error) {
+// Tableau geometry of an assembly with n_free free blocks and n_if interfaces: rows m = 3 n_free (+ budget + cost),
+// generator columns n = 4 n_if, odd row stride (conflict-free column reads).
+__device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, int& stride, int64_t& cells) {
+    m = 3 * n_free;
+    n = 4 * n_if;
+    stride = n + 2;
+    if ((stride & 1) == 0) stride += 1;
+    cells = (int64_t)(m + 2) * stride;
+}
+
+// Stability of one assembly variant.  fixed_mask bit b = block b is_static (fixed).  tab_lds holds lds_cap doubles
+// and the scratch MAXCOLS generator columns; a tableau that does not fit goes to tab_ws (ws_cap doubles, may be 0).
+// *too_big is set (and false returned, without an error) when neither fits -- the caller decides what that means.
+template <typename SC>
+__device__ inline bool rbe_stable(double* tab_lds, int lds_cap, int max_cols, double* tab_ws, int64_t ws_cap, SC& S,
+                                  const AsmView& A, uint32_t fixed_mask, double mu, double density, int lane,
+                                  double* w_out, int* pivots_out, bool* error, bool* too_big) {
     *w_out = 0.0;
     *pivots_out = 0;
+    const int n_blocks = A.n_blocks;
     const uint32_t all = n_blocks >= 32 ? 0xffffffffu : ((1u << n_blocks) - 1u);
     const uint32_t free_mask = all & ~fixed_mask;
     const int n_free = __popc(free_mask);
-    if (n_if == 0) return n_free == 0;                 // stability.py:53-56
+    if (A.n_if == 0) return n_free == 0;               // stability.py:53-56
     if (n_free == 0) return true;
-    lp_row_map(S, free_mask, lane);
-    const int m = 3 * n_free, n = 4 * n_if;
-    int stride = n + 2;
-    if ((stride & 1) == 0) stride += 1;               // odd row stride: conflict-free column reads
-    const int64_t cells = (int64_t)(m + 2) * stride;
+    int m, n, stride;
+    int64_t cells;
+    lp_dims(n_free, A.n_if, m, n, stride, cells);
+    const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
     double w;
-    if (cells <= LP_TAB_LDS) {                        // LDS path: address space known at compile time (ds_read/ds_write)
-        lp_build(tab_lds, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
-        w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true);
-        if (w <= RBE_FEAS_TOL && lp_verify(tab_lds, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes,
-                                           mu, density, lane) > LP_VERIFY_TOL) { *error = true; w = 1.0; }
+    if (cells <= lds_cap && n <= max_cols) {          // LDS path: address space known at compile time (ds_read/ds_write)
+        lp_row_map(S, free_mask, lane);
+        lp_build(tab_lds, stride, m, m, n, A, S.row_of, mu, density, lane);
+        w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true, feas);
+        if (w <= feas && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; w = 1e300; }
     } else {
-        if (cells > ws_cap) { *error = true; return false; }
-        lp_build(tab_ws, stride, m, m, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
-        w = lp_phase1<false>(tab_ws, stride, m, m, n, S, lane, pivots_out, error, true);
-        if (w <= RBE_FEAS_TOL && lp_verify(tab_ws, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes,
-                                           mu, density, lane) > LP_VERIFY_TOL) { *error = true; w = 1.0; }
+        if (cells > ws_cap || n > max_cols) { *too_big = true; return false; }
+        lp_row_map(S, free_mask, lane);
+        lp_build(tab_ws, stride, m, m, n, A, S.row_of, mu, density, lane);
+        w = lp_phase1<false>(tab_ws, stride, m, m, n, S, lane, pivots_out, error, true, feas);
+        if (w <= feas && lp_verify(tab_ws, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; w = 1e300; }
     }
     *w_out = w;
-    return w <= RBE_FEAS_TOL;
+    return w <= feas;
 }
 
 // Both variants of gym_env.py:325-333 in ONE tableau.  Stage 1 solves "last block frozen" (the rows of the last
 // block are carried along passively); if it is infeasible so is the unfrozen system (a superset of its rows).
 // Otherwise stage 2 enforces the last block's three equilibrium rows and continues from the stage-1 basis.
 template <bool IN_LDS, typename TP>
-__device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S, int n_if, const int32_t* if_body,
-                                   const double* if_geom, int n_blocks, const double* pose, const int32_t* shape_id,
-                                   const bridges_shape* shapes, double mu, double density, int lane, bool* st_frozen,
-                                   bool* st_free, bool* error) {
+__device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu,
+                                   double density, int lane, bool* st_frozen, bool* st_free, bool* error) {
     const int m_act = m - 3;
-    lp_build(T, stride, m, m_act, n, n_if, if_body, if_geom, S.row_of, n_blocks, pose, shape_id, shapes, mu, density, lane);
+    const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
+    lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane);
     int piv = 0;
-    double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, true);
-    *st_frozen = w <= RBE_FEAS_TOL;
-    if (*st_frozen && m_act > 0 &&
-        lp_verify(T, stride, m, m_act, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density, lane) > LP_VERIFY_TOL) {
+    double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, true, feas);
+    *st_frozen = w <= feas;
+    if (*st_frozen && m_act > 0 && lp_verify(T, stride, m, m_act, n, S, A, mu, density, lane) > vtol) {
         *st_frozen = false;                 // the verdict does not survive the check on the original rows
         *error = true;
     }
     if (!*st_frozen) { *st_free = false; return; }
     lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane);
-    w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false);
-    *st_free = w <= RBE_FEAS_TOL;
-    if (*st_free &&
-        lp_verify(T, stride, m, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density, lane) > LP_VERIFY_TOL) {
+    w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas);
+    *st_free = w <= feas;
+    if (*st_free && lp_verify(T, stride, m, m, n, S, A, mu, density, lane) > vtol) {
         *st_free = false;
         *error = true;
     }
 }
 
-__device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, int n_if,
-                                const int32_t* if_body, const double* if_geom, int n_blocks, const double* pose,
-                                const int32_t* shape_id, const bridges_shape* shapes, double mu, double density,
-                                int lane, bool* st_frozen, bool* st_free, bool* error) {
-    if (n_if == 0) {                                   // stability.py:53-56: no edges -> stable iff no free node
-        *st_frozen = n_blocks == 1;
+__device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, const AsmView& A,
+                                double mu, double density, int lane, bool* st_frozen, bool* st_free, bool* error) {
+    if (A.n_if == 0) {                                 // stability.py:53-56: no edges -> stable iff no free node
+        *st_frozen = A.n_blocks == 1;
         *st_free = false;
         return;
     }
-    const uint32_t all = n_blocks >= 32 ? 0xffffffffu : ((1u << n_blocks) - 1u);
+    const uint32_t all = A.n_blocks >= 32 ? 0xffffffffu : ((1u << A.n_blocks) - 1u);
     lp_row_map(S, all, lane);
-    const int m = 3 * n_blocks, n = 4 * n_if;
-    int stride = n + 2;
-    if ((stride & 1) == 0) stride += 1;
-    const int64_t cells = (int64_t)(m + 2) * stride;
+    int m, n, stride;
+    int64_t cells;
+    lp_dims(A.n_blocks, A.n_if, m, n, stride, cells);
     if (cells <= LP_TAB_LDS) {
-        rbe_both_in<true>(tab_lds, stride, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density,
-                          lane, st_frozen, st_free, error);
+        rbe_both_in<true>(tab_lds, stride, m, n, S, A, mu, density, lane, st_frozen, st_free, error);
     } else {
         if (cells > ws_cap) { *error = true; *st_frozen = false; *st_free = false; return; }
-        rbe_both_in<false>(tab_ws, stride, m, n, S, n_if, if_body, if_geom, n_blocks, pose, shape_id, shapes, mu, density,
-                           lane, st_frozen, st_free, error);
+        rbe_both_in<false>(tab_ws, stride, m, n, S, A, mu, density, lane, st_frozen, st_free, error);
     }
     __syncthreads();
 }

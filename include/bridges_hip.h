@@ -134,6 +134,10 @@ typedef struct {
     double* lp_ws;             /* [E, lp_ws_stride] simplex tableau overflow */
     int64_t lp_ws_stride;      /* >= 9*MAX_IF + (3K+2)*(4*MAX_IF+3) */
     uint64_t* stats;           /* [8] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps */
+    /* --- candidate stability (bridges_env_candidate_stability; all three may be NULL if it is never called) --- */
+    uint8_t* cand_stable;      /* [C] 1 = stable, 0 = unstable or masked-out candidate, 2 = solver error / contact overflow */
+    int32_t* cand_queue;       /* [C] scratch: candidates whose tableau needs the large workspace */
+    int32_t* cand_counters;    /* [4] scratch: queue length, queue head */
 } bridges_env_buffers;
 
 typedef struct bridges_env bridges_env;
@@ -169,6 +173,11 @@ int bridges_gate_destroy(bridges_gate* gate);
 int bridges_env_set_gate(bridges_env* env, bridges_gate* gate);
 /* Candidate refresh only (used after the host edited the state). */
 int bridges_env_refresh(bridges_env* env, void* stream);
+/* is_action_stable_rbe (assembly_gym/assembly_gym/utils/stability.py:122-130) for EVERY valid candidate of every
+ * environment in one pass -> cand_stable[cand_offset[e] + a].  The candidate block is appended to the env's assembly
+ * (free; the last placed block stays frozen, gym_env.py:238-240); its contacts are found against the env's persistent
+ * contact list, which must be current (i.e. the state was reached through bridges_env_reset / bridges_env_step). */
+int bridges_env_candidate_stability(bridges_env* env, void* stream);
 
 /* --- stand-alone operators (same kernels, caller-shaped batches) ------------ */
 /* K1: create_block / align_frames_2d (gym_env.py:204-216, geometry.py:39-50).

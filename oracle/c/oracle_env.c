@@ -208,12 +208,14 @@ static double art_sum(const double* T, int stride, int m_act, int nn, const int*
     return s;
 }
 /* m equilibrium rows are stored (rows >= m_act passive), the budget row m is always enforced; nn = n + 1 columns */
-static double phase1(double* T, int stride, int m, int m_act, int nn, int* basis, int init, long* pivots) {
+/* every absolute tolerance is a force and scales with the density (the rhs is linear in it, the matrix is not) */
+static double phase1(double* T, int stride, int m, int m_act, int nn, int* basis, int init, long* pivots, double density) {
     const int cost = m + 1;
+    const double feas = FEAS_TOL * density, progress = 1e-7 * feas;
     if (init) { for (int i = 0; i < m; ++i) basis[i] = i < m_act ? nn + i : -1; basis[m] = nn - 1; }
     int stall = 0, bland = 0, guard = 0;
     double w = art_sum(T, stride, m_act, nn, basis);
-    while (w > FEAS_TOL) {
+    while (w > feas) {
         int jin = -1;
         if (bland) { for (int j = 0; j < nn; ++j) if (T[cost * stride + j] < -EPS_COST) { jin = j; break; } }
         else { double best = -EPS_COST; for (int j = 0; j < nn; ++j) if (T[cost * stride + j] < best) { best = T[cost * stride + j]; jin = j; } }
@@ -248,7 +250,7 @@ static double phase1(double* T, int stride, int m, int m_act, int nn, int* basis
         basis[r] = jin;
         ++*pivots;
         double wn = art_sum(T, stride, m_act, nn, basis);
-        if (wn < w - 1e-12) { stall = 0; bland = 0; } else if (++stall > STALL) bland = 1;
+        if (wn < w - progress) { stall = 0; bland = 0; } else if (++stall > STALL) bland = 1;
         w = wn;
         if (++guard > 5000) break;
     }
@@ -283,21 +285,80 @@ static void rbe_both(orc_env* e, int* st_frozen, int* st_free) {
             }
         }
     }
-    for (int i = 0; i < m; ++i) T[i * stride + nn] = PERTURB * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    for (int i = 0; i < m; ++i) T[i * stride + nn] = (PERTURB * e->c.density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
     for (int b = 0; b < nb; ++b) T[(3 * b + 1) * stride + nn] += e->c.density * e->c.shapes[e->shape[b]].volume;
     for (int q = 0; q < nn; ++q) T[m * stride + q] = 1.0;
-    T[m * stride + nn] = S_MAX;
+    T[m * stride + nn] = S_MAX * e->c.density;
     for (int q = 0; q <= nn; ++q) { double s = 0; for (int i = 0; i < m_act; ++i) s += T[i * stride + q]; T[cost * stride + q] = -s; }
-    double w = phase1(T, stride, m, m_act, nn, basis, 1, &e->total_pivots);
-    *st_frozen = w <= FEAS_TOL;
+    const double feas = FEAS_TOL * e->c.density;
+    double w = phase1(T, stride, m, m_act, nn, basis, 1, &e->total_pivots, e->c.density);
+    *st_frozen = w <= feas;
     if (!*st_frozen) { *st_free = 0; return; }
     for (int i = m_act; i < m; ++i) {
         int neg = T[i * stride + nn] < 0.0;
         for (int q = 0; q <= nn; ++q) { double v = T[i * stride + q]; if (neg) { v = -v; T[i * stride + q] = v; } T[cost * stride + q] -= v; }
         basis[i] = nn + i;
     }
-    w = phase1(T, stride, m, m, nn, basis, 0, &e->total_pivots);
-    *st_free = w <= FEAS_TOL;
+    w = phase1(T, stride, m, m, nn, basis, 0, &e->total_pivots, e->c.density);
+    *st_free = w <= feas;
+}
+
+/* is_stable_rbe with an arbitrary set of fixed blocks (bit b of fixed = block b is_static): one phase-1 solve over the
+ * rows of the free blocks (oracle/rbe.py equilibrium_system). */
+static int rbe_fixed(orc_env* e, uint32_t fixed) {
+    int nb = e->nb, n_if = e->n_if, row_of[MAXK], n_free = 0;
+    for (int b = 0; b < nb; ++b) row_of[b] = ((fixed >> b) & 1u) ? -1 : 3 * n_free++;
+    if (n_if == 0) return n_free == 0;
+    if (n_free == 0) return 1;
+    int m = 3 * n_free, n = 4 * n_if, nn = n + 1, stride = nn + 1, cost = m + 1;
+    double* T = e->tab;
+    int basis[3 * MAXK + 1];
+    memset(T, 0, sizeof(double) * (size_t)(m + 2) * stride);
+    for (int k = 0; k < n_if; ++k) {
+        const double* g = e->if_geom[k];
+        for (int ip = 0; ip < 2; ++ip) for (int ig = 0; ig < 2; ++ig) {
+            int j = 4 * k + 2 * ip + ig;
+            double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+            double gx = ig ? g[4] - e->c.mu * g[6] : g[4] + e->c.mu * g[6];
+            double gz = ig ? g[5] - e->c.mu * g[7] : g[5] + e->c.mu * g[7];
+            for (int side = 0; side < 2; ++side) {
+                int body = e->if_body[k][side == 0 ? 1 : 0];
+                if (body < 0 || row_of[body] < 0) continue;
+                double sgx = side == 0 ? gx : -gx, sgz = side == 0 ? gz : -gz;
+                const orc_shape* sh = &e->c.shapes[e->shape[body]];
+                double rgx, rgz;
+                rot2(sh->gx, sh->gz, e->pose[body][2], e->pose[body][3], &rgx, &rgz);
+                double rx = px - (e->pose[body][0] + rgx), rz = pz - (e->pose[body][1] + rgz);
+                T[(row_of[body] + 0) * stride + j] = sgx;
+                T[(row_of[body] + 1) * stride + j] = sgz;
+                T[(row_of[body] + 2) * stride + j] = rx * sgz - rz * sgx;
+            }
+        }
+    }
+    for (int i = 0; i < m; ++i) T[i * stride + nn] = (PERTURB * e->c.density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+    for (int b = 0; b < nb; ++b) if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += e->c.density * e->c.shapes[e->shape[b]].volume;
+    for (int q = 0; q < nn; ++q) T[m * stride + q] = 1.0;
+    T[m * stride + nn] = S_MAX * e->c.density;
+    for (int q = 0; q <= nn; ++q) { double s = 0; for (int i = 0; i < m; ++i) s += T[i * stride + q]; T[cost * stride + q] = -s; }
+    double w = phase1(T, stride, m, m, nn, basis, 1, &e->total_pivots, e->c.density);
+    return w <= FEAS_TOL * e->c.density;
+}
+
+/* is_action_stable_rbe (stability.py:122-130): candidate a appended as a free block, the last placed block stays
+ * frozen (gym_env.py:238-240); the state is restored afterwards. */
+static int action_stable(orc_env* e, int a) {
+    const orc_cand* cd = &e->cand[a];
+    int nb = e->nb, n_if = e->n_if;
+    if (nb >= MAXK) return 0;
+    e->shape[nb] = cd->sh;
+    memcpy(e->pose[nb], cd->pose, sizeof(cd->pose));
+    memcpy(e->verts[nb], cd->verts, sizeof(cd->verts));
+    e->nb = nb + 1;
+    append_interfaces(e, nb);
+    int st = rbe_fixed(e, nb > 0 ? (1u << (nb - 1)) : 0u);
+    e->nb = nb;
+    e->n_if = n_if;
+    return st;
 }
 
 /* ---- candidates of the current state (generate_actions + create_block + rasters + filter + lin) ---- */
@@ -400,6 +461,13 @@ int orc_blocks(const orc_env* e, int32_t* shape, double* pose) {
     return e->nb;
 }
 
+/* out[a] = is_action_stable_rbe of candidate a for the valid (mask) candidates of the current state, 0 otherwise. */
+int orc_candidate_stability(orc_env* e, uint8_t* out) {
+    int n = 0;
+    for (int a = 0; a < e->n_cand; ++a) { out[a] = e->cand[a].mask ? (uint8_t)action_stable(e, a) : 0; n += e->cand[a].mask; }
+    return n;
+}
+
 /* One lock-step of the protocol of DESIGN.md: place a uniformly drawn valid candidate (or reset-only), both
  * stability variants, reward / termination, auto-reset, candidates of the new state. */
 void orc_lockstep(orc_env* e, uint64_t seed, int32_t env_id, orc_out* out) {
@@ -438,7 +506,8 @@ void orc_lockstep(orc_env* e, uint64_t seed, int32_t env_id, orc_out* out) {
         long p0 = e->total_pivots;
         rbe_both(e, &sf, &su);
         int all = e->targets_left == 0;
-        int terminated = !sf || all, truncated = c->max_steps > 0 && e->nb >= c->max_steps;
+        /* a state that fills the K = (max_steps or MAXK) block slots of the device layout is truncated too */
+        int terminated = !sf || all, truncated = (c->max_steps > 0 && e->nb >= c->max_steps) || e->nb >= MAXK;
         out->valid_step = 1; out->action_index = a; out->stable_frozen = sf; out->stable_unfrozen = su;
         out->terminated = terminated; out->truncated = truncated; out->done = terminated || truncated;
         out->n_blocks = e->nb; out->n_reached = n_reached; out->lp_pivots = (int32_t)(e->total_pivots - p0);

@@ -73,6 +73,7 @@ def lib():
         L.orc_f32.restype = C.POINTER(C.c_float)
         L.orc_f32.argtypes = [C.c_void_p]
         L.orc_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        L.orc_candidate_stability.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
         L.orc_total_pivots.restype = C.c_long
         L.orc_total_pivots.argtypes = [C.c_void_p]
         _lib = L
@@ -157,6 +158,15 @@ class CEnv:
         po = (C.c_double * (4 * MAXK))()
         n = self.L.orc_blocks(self.h, sh, po)
         return [(sh[b], (po[4 * b], po[4 * b + 1]), (po[4 * b + 2], po[4 * b + 3])) for b in range(n)]
+
+    def candidate_stability(self):
+        """is_action_stable_rbe (stability.py:122-130) of every candidate of the current state: uint8 [n_cand],
+        0 for the masked-out ones."""
+        n, nv = C.c_int32(), C.c_int32()
+        self.L.orc_candidates(self.h, C.byref(n), C.byref(nv))
+        out = (C.c_uint8 * max(n.value, 1))()
+        self.L.orc_candidate_stability(self.h, out)
+        return np.frombuffer(out, dtype=np.uint8, count=n.value).copy()
 
     def enable_f32(self):
         assert self.L.orc_enable_f32(self.h)

@@ -216,8 +216,9 @@ class OracleLockstep:
     both stability variants, reward/termination, auto-reset when done) or a
     reset-only step (when the previous state had no valid candidate)."""
 
-    def __init__(self, gym):
+    def __init__(self, gym, capacity=16):
         self.gym = gym
+        self.capacity = capacity      # block slots of the device state: a state that fills them is truncated
         self.gym.reset()
         self.cand = self.gym.candidates()
         self.needs_reset = not self.cand["mask"].any()
@@ -233,6 +234,7 @@ class OracleLockstep:
             a = int(valid[pick_valid_rank(len(valid))])
             action = self.cand["actions"][a]
             stable, reward, term, trunc = g.step(action)
+            trunc = trunc or len(g.blocks) >= self.capacity
             fs, us = g.stabilities_freezing()
             base = float(self.cand["lin_reward"][a])
             lin = base if us else (np.float32(base) / np.float32(100) if fs else 0.0)   # successor_dqn.py:397-401

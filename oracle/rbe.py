@@ -46,8 +46,11 @@ FLOOR = -1
 TOL_PARALLEL = 1e-6
 TOL_COPLANAR = 1e-6
 AMIN = 0.001
-S_MAX = 1e4       # budget on the sum of contact-force multipliers, see module docstring
+S_MAX = 1e4       # budget on the sum of contact-force multipliers at density 1, see module docstring
 FEAS_TOL = 1e-5   # float32 meshes leave ~1e-7 geometric noise (observed classes: 0, 3e-7 | 7.8e-4, >= 2.8e-2)
+# Both are forces: they are multiplied by the density (the right-hand side w is linear in it, M does not depend on it),
+# so the boolean does not depend on the unit of mass -- AssemblyEnv(density=...) is a public input
+# (assembly_gym/assembly_gym/envs/assembly_env.py:164).
 
 
 def floor_body(bounds=((-3.0, -3.0, -1.0), (7.0, 7.0, 9.0))):
@@ -142,8 +145,8 @@ def equilibrium_system(blocks, interfaces, fixed, mu, density):
     return M, w
 
 
-def infeasibility(M, w):
-    """v* = min ||M x - w||_1 over x >= 0, sum(x) <= S_MAX (HiGHS)."""
+def infeasibility(M, w, s_max=S_MAX):
+    """v* = min ||M x - w||_1 over x >= 0, sum(x) <= s_max (HiGHS)."""
     from scipy.optimize import linprog
     m, n = M.shape
     if m == 0:
@@ -153,7 +156,7 @@ def infeasibility(M, w):
     A = np.hstack([M, np.eye(m), -np.eye(m)])
     c = np.concatenate([np.zeros(n), np.ones(2 * m)])
     budget = np.concatenate([np.ones(n), np.zeros(2 * m)])[None, :]
-    res = linprog(c, A_eq=A, b_eq=w, A_ub=budget, b_ub=[S_MAX], bounds=(0, None), method="highs")
+    res = linprog(c, A_eq=A, b_eq=w, A_ub=budget, b_ub=[s_max], bounds=(0, None), method="highs")
     if res.status != 0:
         raise RuntimeError(f"HiGHS failed on an always-feasible LP: {res.message}")
     return float(res.fun)
@@ -169,6 +172,6 @@ def is_stable_rbe(blocks, fixed, mu=0.8, density=1.0, bounds=((-3.0, -3.0, -1.0)
         stable = n_free == 0
         return (stable, dict(v=None, n_if=0)) if return_info else stable
     M, w = equilibrium_system(blocks, interfaces, fixed, mu, density)
-    v = infeasibility(M, w)
-    stable = v <= FEAS_TOL
+    v = infeasibility(M, w, S_MAX * density)
+    stable = v <= FEAS_TOL * density
     return (stable, dict(v=v, n_if=len(interfaces))) if return_info else stable

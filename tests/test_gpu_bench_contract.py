@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
-    env = dict(os.environ, BENCH_CPU_WORKERS="2", BENCH_CPU_SECONDS="1")
+    env = dict(os.environ, BENCH_CPU_WORKERS="2", BENCH_CPU_SECONDS="1", BENCH_NUMPY_STEPS="20", BENCH_TRAIN_MODES="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
                           "--envs", "512"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -30,4 +30,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and "sample" in c
     assert j["value"] > 1e5 and abs(j["ms_per_step"] * j["value"] / 1e3 / (512 * j["config"]["env_step_fraction"]) - 1) < 0.02
-    assert set(j["other_modes"]) == {"sparse_raster_update", "bit_packed_rasters_only"}
+    assert c["one_core"]["value"] > 0 and c["one_core"]["cores"] == 1 and c["numpy_highs"]["value"] > 0
+    assert j["ranks_seen"] == 1 and "traffic_source" in r and j["config"]["debug"] == 0
+    om = j["other_modes"]
+    assert set(om) == {"sparse_raster_update", "bit_packed_rasters_only", "candidate_stability", "config5_hexagon_bridge"}
+    for k, v in om.items():
+        assert "error" not in v, (k, v)
+        assert v["value"] > 1e4
+    cs = om["candidate_stability"]["candidate_stability"]
+    assert cs["decisions_per_s"] > 1e5 and cs["last_lockstep"]["errors"] == 0
+    assert "hexagon" in om["config5_hexagon_bridge"]["workload"]
+
+
+def test_bench_launches_its_own_ranks_for_gpus_2():
+    """`python bench.py --gpus 2` with no torchrun environment starts two ranks itself (gloo here: both share the one
+    card of the test box; on a node the same path runs RCCL) and rank 0 prints the one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+                          "--envs", "256"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == "weak"
+    assert "cpu_baseline" not in j and "other_modes" not in j          # rank 0 at N = 1 only
+    # both ranks' env-steps are in `value`: 2 x 256 envs per lock-step
+    assert abs(j["ms_per_step"] * j["value"] / 1e3 / (2 * 256 * j["config"]["env_step_fraction"]) - 1) < 0.05

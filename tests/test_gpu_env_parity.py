@@ -219,6 +219,97 @@ def test_restricted_target_faces_two_targets_no_step_limit_parity():
     assert not bool(vec.flags()["truncated"].any())
 
 
+@pytest.mark.parametrize("task,envs,locksteps", [("tower4", 96, 14), ("hexbridge", 48, 12), ("mixed", 40, 10)])
+def test_fused_candidate_stability_against_the_c_oracle(task, envs, locksteps):
+    """>= 5000 candidate placements per task decided by bridges_env_candidate_stability and by the C oracle's
+    is_action_stable_rbe: 0 mismatches, 0 solver errors."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress", "stress_candidate_stability.py"), "--envs", str(envs),
+                          "--locksteps", str(locksteps), "--task", task], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"RESULT .*: (\d+) candidate decisions compared \((\d+) unstable.*, 0 mismatches, 0 lp errors", out.stdout)
+    assert m, out.stdout[-500:]
+    assert int(m.group(1)) >= 5000 and int(m.group(2)) > 100
+
+
+def test_fused_candidate_stability_equals_the_unfused_operator_path():
+    """Second, independent GPU path at a size the CPU oracles do not reach: gathered copies of every assembly + the
+    stand-alone bridges_stability operator (interfaces re-detected from scratch) give the same booleans."""
+    from gpu_helpers import candidate_stability_unfused
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    setup = bridge_setup(num_stories=4)
+    vec = VecAssemblyGym(1024, [load_urdf("shapes/trapezoid.urdf")], setup["obstacles"], setup["targets"], max_steps=15, seed=3,
+                         f32_rasters=False)
+    n = 0
+    for it in range(8):
+        rows, stable = vec.candidate_stability()
+        rows2, stable2, err2 = candidate_stability_unfused(vec)
+        assert torch.equal(rows, rows2) and not bool(err2.any())
+        assert torch.equal(stable, stable2), it
+        assert int((vec.cand_stable[rows] == 2).sum()) == 0
+        n += rows.numel()
+        vec.select_random()
+        vec.step()
+    assert n > 50000
+
+
+@pytest.mark.parametrize("density", [0.1, 50.0])
+def test_density_scaled_tolerances_parity(density):
+    """AssemblyEnv(density=...) is a public input (assembly_env.py:164): every absolute LP tolerance scales with it,
+    so the lock-step booleans at density d agree with the oracle at density d (and, by the CPU test, with density 1)."""
+    E, seed = 24, 41
+    vec, oracles = make_pair(dict(num_stories=4), bridge_setup, E, 15, seed, ["trapezoid"], density=density)
+    n = run_lockstep_parity(vec, oracles, seed, n_lock=12)
+    assert n > E * 8
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress", "stress_candidate_stability.py"), "--envs", "32",
+                          "--locksteps", "6", "--task", "tower4", "--density", str(density)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "0 mismatches, 0 lp errors" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_state_capacity_is_a_forced_truncation_and_neighbours_stay_intact():
+    """max_steps=None -> K = 16 block slots.  A state that fills them is truncated and auto-reset (slot nb == K is
+    never written); every env's block list stays what was placed into it, bit for bit."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    # ground-only placements of a small cube, 0.8 apart: they never collide and never become unstable
+    cube = load_urdf("shapes/cube06.urdf")
+    E = 3
+    vec = VecAssemblyGym(E, [cube], [], [(50.0, 0.0, 50.0)], max_steps=None, seed=1, xlim=(-3.0, 17.0), ylim=(0.0, 20.0),
+                         x_discr_ground=np.linspace(-2.4, 16.0, 24), f32_rasters=False,
+                         bounds=((-30.0, -3.0, -1.0), (30.0, 3.0, 9.0)))
+    assert vec.K == 16
+    mirror = [[] for _ in range(E)]
+    truncations = 0
+    for it in range(40):
+        off = vec.cand_offset.cpu().numpy(); mask = vec.cand_mask.cpu().numpy(); desc = vec.cand_desc.cpu().numpy()
+        cpose = vec.cand_pose.cpu().numpy()
+        sel = []
+        for e in range(E):
+            rows = [a for a in range(off[e], off[e + 1]) if mask[a] and desc[a, 0] < 0]      # ground candidates only
+            assert rows, "no free ground slot left"
+            pick = rows[(it + e) % len(rows)]                  # envs take different slots: their block lists differ
+            sel.append(pick - off[e])
+            mirror[e].append(cpose[pick].copy())
+        vec.step(torch.tensor(sel, dtype=torch.int32))
+        fl = {k: v.cpu().numpy() for k, v in vec.flags().items()}
+        nb = vec.n_blocks.cpu().numpy()
+        pose = vec.blk_pose.cpu().numpy()
+        assert not fl["lp_error"].any() and fl["stable_frozen"].all()
+        for e in range(E):
+            if len(mirror[e]) >= 16:
+                assert fl["truncated"][e] and fl["done"][e] and nb[e] == 0
+                mirror[e] = []
+                truncations += 1
+            else:
+                assert not fl["truncated"][e] and not fl["done"][e] and nb[e] == len(mirror[e])
+                assert np.array_equal(pose[e, :nb[e]], np.array(mirror[e])), (it, e)
+    assert truncations == E * 2
+
+
 @pytest.mark.parametrize("task", ["tower4", "mixed"])
 def test_stress_parity_against_the_c_oracle(task):
     """Thousands of env-steps against the plain-C oracle (fast enough to follow): every selected action, both

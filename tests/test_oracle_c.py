@@ -73,3 +73,62 @@ def test_c_oracle_f32_rasters():
             assert np.array_equal(imgs[i], ref)
         sb = ce.state_bits()
         assert np.array_equal(imgs[len(cands)], np.array([[(b >> q) & 1 for q in range(64)] for b in sb], dtype=np.float32))
+
+
+@pytest.mark.parametrize("setup,kw,max_steps,seed", [
+    (bridge_setup, dict(num_stories=4), 15, 3),
+    (horizontal_bridge_setup, dict(num_obstacles=3, trapezoid=False, hexagon=True), 15, 11),
+    (horizontal_bridge_setup, dict(num_obstacles=2, trapezoid=True, hexagon=True), 12, 2),
+])
+def test_c_candidate_stability_equals_is_action_stable_rbe(setup, kw, max_steps, seed):
+    """is_action_stable_rbe (stability.py:122-130) for every valid candidate: the C oracle's incremental contact list +
+    own simplex against the numpy oracle's from-scratch interface search + HiGHS."""
+    checked = unstable = 0
+    for env_id in range(3):
+        gym = OracleGym(**setup(**kw), max_steps=max_steps)
+        ce = CEnv(gym)
+        L = OracleLockstep(gym)
+        ctr = [0]
+
+        def pick(nv):
+            r = policy_draw(seed, env_id, ctr[0]) % nv
+            ctr[0] += 1
+            return r
+        for it in range(10):
+            st = ce.candidate_stability()
+            assert len(st) == len(L.cand["actions"])
+            for a in np.flatnonzero(L.cand["mask"]):
+                ref = gym.is_action_stable(L.cand["actions"][a])
+                assert bool(st[a]) == ref, (env_id, it, a)
+                checked += 1
+                unstable += not ref
+            assert not st[~L.cand["mask"]].any()
+            ce.lockstep(seed, env_id)
+            L.lockstep(pick)
+    assert checked > 200 and 0 < unstable < checked
+
+
+@pytest.mark.parametrize("density", [0.1, 50.0])
+def test_stability_booleans_do_not_depend_on_the_density(density):
+    """Forces are linear in the density and every absolute LP tolerance scales with it, so the booleans of both
+    oracles at density d equal those at density 1 (AssemblyEnv(density=...), assembly_env.py:164)."""
+    seed, n = 17, 0
+    for env_id in range(3):
+        ref_gym = OracleGym(**bridge_setup(num_stories=4), max_steps=15)
+        gym = OracleGym(**bridge_setup(num_stories=4), max_steps=15, density=density)
+        ce_ref, ce = CEnv(ref_gym), CEnv(gym)
+        L = OracleLockstep(gym)
+        ctr = [0]
+
+        def pick(nv):
+            r = policy_draw(seed, env_id, ctr[0]) % nv
+            ctr[0] += 1
+            return r
+        for it in range(30):
+            a, b, ref = ce_ref.lockstep(seed, env_id), ce.lockstep(seed, env_id), L.lockstep(pick)
+            assert (a.valid_step, a.action_index, a.stable_frozen, a.stable_unfrozen, a.done) == \
+                   (b.valid_step, b.action_index, b.stable_frozen, b.stable_unfrozen, b.done), (env_id, it)
+            if ref["valid_step"]:
+                assert (bool(b.stable_frozen), bool(b.stable_unfrozen)) == (ref["stable_frozen"], ref["stable_unfrozen"])
+                n += 1
+    assert n > 60
