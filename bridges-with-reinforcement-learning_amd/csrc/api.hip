@@ -248,8 +248,7 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
-#define CS_TAB_SMALL 640
-#define CS_COLS_SMALL 92
+#define CS_RM_SMALL 18      // first launch: register tableaux of <= 6 free blocks
 int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");
     const DevCtx& c = env->ctx;
@@ -261,10 +260,10 @@ int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (est < c.E) est = c.E;
     est += est / 32 + 64;
     if (est > env->max_blocks) est = env->max_blocks;
-    hipLaunchKernelGGL((k_candidate_stability<CS_TAB_SMALL, CS_COLS_SMALL, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
+    hipLaunchKernelGGL((k_candidate_stability<CS_RM_SMALL, 8, 60, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability");
     const int drain = c.E < 512 ? c.E : 512;          // one lp_ws slot per workgroup
-    hipLaunchKernelGGL((k_candidate_stability<LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
+    hipLaunchKernelGGL((k_candidate_stability<STEP_RM, LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability (queue)");
     return BRIDGES_OK;
 }

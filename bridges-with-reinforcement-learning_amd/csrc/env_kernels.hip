@@ -12,6 +12,7 @@
 //               sum(action_features * reward_features) (successor_dqn.py:399-401)
 #include "bridges_device.h"
 #include "rbe_device.h"
+#include "rbe_reg.h"
 
 namespace bridges {
 
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+#define STEP_RM 36          // register tableau: up to 12 free blocks (3 rows each); larger assemblies take the LDS tableau
 __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     // LDS: the staged face frames are dead once the interfaces are found, so they share storage with the tableau
     __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     const int K = c.K;
     const bridges_shape* shapes = c.tt->shapes;
     uint8_t* flags = c.b.step_flags + (size_t)e * 8;
+    const long long ts0 = (c.debug & 8) ? wall_clock64() : 0;      // debug bit3: per-env phase stamps (tools/kstep_phases.py)
 
     if (c.b.needs_reset[e]) {                       // reset-only lock-step (previous state had no valid action)
         reset_env(c, e, lane);
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     }
     const int n_reached = c.n_targets - __popc(left);
 
+    const long long ts1 = (c.debug & 8) ? wall_clock64() : 0;
     // ---- contact interfaces of the new block (assembly_env.py:281-304) ----
     int32_t* if_body = c.b.if_body + (size_t)e * MAXIF * 2;
     double* if_geom = c.b.if_geom + (size_t)e * MAXIF * 8;
@@ -141,10 +145,12 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     double* ws = c.b.lp_ws + (size_t)e * c.b.lp_ws_stride;
     bool err = false;
     bool st_frozen = true, st_free = true;
+    const long long ts2 = (c.debug & 8) ? wall_clock64() : 0;
     if (!(c.debug & 1))
-        rbe_both(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), c.mu,
-                 c.density, lane, &st_frozen, &st_free, &err);
+        rbe_both_auto<STEP_RM>(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), c.mu,
+                               c.density, lane, &st_frozen, &st_free, &err);
 
+    const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
     const bool all_reached = left == 0;
     const bool terminated = !st_frozen || all_reached;
@@ -175,6 +181,11 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     }
     int nc = count_candidates(c, e, nb_after, lane);
     if (lane == 0) c.b.n_cand[e] = nc;
+    if ((c.debug & 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
+        const long long ts4 = wall_clock64();
+        ws[0] = (double)ts0; ws[1] = (double)(ts1 - ts0); ws[2] = (double)(ts2 - ts1); ws[3] = (double)(ts3 - ts2);
+        ws[4] = (double)(ts4 - ts3); ws[5] = (double)(nb + 1); ws[6] = (double)n_if; ws[7] = (double)ts4;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -587,12 +598,13 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
 // candidate arrays k_enumerate wrote.  Result: cand_stable[ci] = 1 stable, 0 unstable (or masked-out candidate),
 // 2 = solver error / interface overflow (counts as unstable, stability.py:68 + gym_env.py:182).
 //
-// Two launches share the code.  QUEUE == false: grid over all raw candidates, a small LDS tableau (high occupancy);
-// a candidate whose tableau does not fit is appended to cand_queue (one atomic per such candidate, they are rare).
-// QUEUE == true: a small persistent grid drains that queue with the full-size LDS tableau and the env workspace
-// lp_ws (one slot per workgroup) behind it; every wave leaves when the queue head passes the count.
+// Two launches share the code.  QUEUE == false: grid over all raw candidates, register tableau of RM rows only (no LDS
+// tableau: high occupancy); a candidate whose LP does not fit is appended to cand_queue (one atomic per such
+// candidate, they are rare).  QUEUE == true: a small persistent grid drains that queue with the large register
+// tableau, the full-size LDS tableau and the env workspace lp_ws (one slot per workgroup) behind it; every wave
+// leaves when the queue head passes the count.
 #define CS_NEW_IF 16
-template <int TAB, int MAXCOLS, bool QUEUE>
+template <int RM, int TAB, int MAXCOLS, bool QUEUE>
 __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
     __shared__ __attribute__((aligned(16))) double tab[TAB];
     __shared__ LpScratchT<MAXCOLS> S;
@@ -688,8 +700,8 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
             double w = 0.0;
             int piv = 0;
             double* ws = QUEUE ? c.b.lp_ws + (size_t)blockIdx.x * c.b.lp_ws_stride : nullptr;
-            const bool st = rbe_stable(tab, TAB, MAXCOLS, ws, QUEUE ? c.b.lp_ws_stride : (int64_t)0, S, A, fixed, c.mu, c.density,
-                                       lane, &w, &piv, &err, &too_big);
+            const bool st = rbe_stable_auto<RM>(tab, QUEUE ? TAB : 0, MAXCOLS, ws, QUEUE ? c.b.lp_ws_stride : (int64_t)0, S, A, fixed,
+                                                c.mu, c.density, lane, &w, &piv, &err, &too_big);
             if (too_big) {
                 if constexpr (!QUEUE) {
                     if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;

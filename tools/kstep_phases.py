@@ -1,0 +1,30 @@
+"""Where a k_step workgroup spends its time: per-env phase stamps (debug bit3, 100 MHz wall clock) of one lock-step."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
+import numpy as np, torch
+from bridges_hip.shapes import load_urdf
+from bridges_hip.vec_env import VecAssemblyGym
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+H = 0.8
+env = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0, i * H + H / 2) for i in range(4)],
+                     [(0.5, 0, 4 * H + H / 2)], max_steps=15, seed=0, debug=8, f32_rasters=False)
+for _ in range(40):
+    env.select_random(); env.step()
+for rep in range(3):
+    env.select_random(); env.step(); torch.cuda.synchronize()
+    w = env.lp_ws[:, :8].cpu().numpy()
+    ok = env.step_flags[:, 0].cpu().numpy().astype(bool)
+    w = w[ok]
+    t0, t4 = w[:, 0], w[:, 7]
+    span = (t4.max() - t0.min()) / 100.0
+    tot = (t4 - t0) / 100.0
+    print(f"rep {rep}: kernel span {span:.1f} us; per-env total us: mean {tot.mean():.1f} p50 {np.median(tot):.1f} p95 {np.percentile(tot,95):.1f} max {tot.max():.1f}; "
+          f"start spread {(t0.max()-t0.min())/100:.1f} us")
+    for name, col in (("append+targets", 1), ("interfaces", 2), ("LPs", 3), ("tail", 4)):
+        v = w[:, col] / 100.0
+        print(f"    {name:15s} mean {v.mean():6.1f}  p95 {np.percentile(v,95):6.1f}  max {v.max():6.1f} us")
+    nb = w[:, 5].astype(int)
+    for k in sorted(set(nb)):
+        sel = nb == k
+        print(f"    nb={k:2d} n={sel.sum():5d} LP us mean {w[sel,3].mean()/100:6.1f} max {w[sel,3].max()/100:6.1f}  total mean {tot[sel].mean():6.1f}")

@@ -19,7 +19,7 @@ K = env.K
 nb = env.n_blocks.clone()
 stable = torch.zeros(E, dtype=torch.uint8, device="cuda")
 info = torch.zeros((E, 8), dtype=torch.float64, device="cuda")
-ws_stride = 9 * 64 + (3 * K + 1) * (4 * 64 + 2)
+ws_stride = abi.lp_ws_stride(K)
 ws = torch.zeros((E, ws_stride), dtype=torch.float64, device="cuda")
 fixed = torch.zeros(E, dtype=torch.int32, device="cuda")
 
