@@ -17,9 +17,15 @@ MAX_INTERFACES = 64
 
 
 def lp_ws_stride(max_blocks):
-    """Doubles of simplex workspace per assembly (include/bridges_hip.h: lp_ws_stride): interface list + the largest
-    tableau, (3K equilibrium rows + budget + cost) x (4*MAX_IF generators + slack + rhs, padded to an odd stride)."""
+    """Doubles of simplex workspace per assembly of the stand-alone stability operator (bridges_stability) and per
+    slot of the candidate-stability scratch: interface list + the largest tableau, (3K equilibrium rows + budget +
+    cost) x (4*MAX_IF generators + slack + rhs, padded to an odd stride)."""
     return 9 * MAX_INTERFACES + (3 * max_blocks + 2) * (4 * MAX_INTERFACES + 3)
+
+
+# include/bridges_hip.h: BRIDGES_LP_WS_DOUBLES -- the per-env persistent tableau of the incremental simplex
+ENV_LP_WS_DOUBLES = 64 + 2 * (3 * MAX_BLOCKS + 2) * (4 * MAX_INTERFACES + 2 + 3 * MAX_BLOCKS + 1)
+CAND_WS_SLOTS = 512
 
 
 IMG = 64
@@ -111,16 +117,18 @@ ENV_BUFFER_FIELDS_TAIL = [
     ("cand_stable", "uint8", "C"),
     ("cand_queue", "int32", "C"),
     ("cand_counters", "int32", "4"),
+    ("cand_ws", "float64", "CWS,WSC"),
 ]
 
 
 class EnvBuffers(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS] + [
-        ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)] + [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS_TAIL]
+        ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)] + [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS_TAIL] + [
+        ("cand_ws_stride", C.c_int64)]
 
 
 # put lp_ws_stride right after lp_ws as in the header (fields above are already in header order)
-assert [f[0] for f in EnvBuffers._fields_][-6:-3] == ["lp_ws", "lp_ws_stride", "stats"]
+assert [f[0] for f in EnvBuffers._fields_][-8:-5] == ["lp_ws", "lp_ws_stride", "stats"]
 
 _lib = None
 

@@ -129,8 +129,10 @@ class VecAssemblyGym:
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         E, K, Cc = self.E, self.K, self.E * self.a_max
-        self.ws_stride = abi.lp_ws_stride(K)
-        dims = dict(E=E, K=K, C=Cc, E1=E + 1, IF=abi.MAX_INTERFACES, WS=self.ws_stride)
+        self.ws_stride = abi.ENV_LP_WS_DOUBLES            # per-env persistent tableau of the incremental simplex
+        self.cand_ws_stride = abi.lp_ws_stride(K)
+        dims = dict(E=E, K=K, C=Cc, E1=E + 1, IF=abi.MAX_INTERFACES, WS=self.ws_stride, CWS=abi.CAND_WS_SLOTS,
+                    WSC=self.cand_ws_stride)
         self.buf = {}
         for name, dt, shape in abi.ENV_BUFFER_FIELDS:
             if name in ("cand_raster", "state_raster") and not self.f32_rasters:
@@ -224,6 +226,7 @@ class VecAssemblyGym:
         b.stats = self.stats.data_ptr()
         for name, _, _ in abi.ENV_BUFFER_FIELDS_TAIL:
             setattr(b, name, self.buf[name].data_ptr())
+        b.cand_ws_stride = self.cand_ws_stride
         self._env = C.c_void_p()
         abi.check(self.L.bridges_env_create(C.byref(t), C.byref(b), C.byref(self._env)), "bridges_env_create")
 

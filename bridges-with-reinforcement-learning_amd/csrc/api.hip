@@ -68,7 +68,8 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (t->n_ground < 0 || t->n_ground > 32 || t->n_offsets <= 0 || t->n_offsets > 8) return fail_arg("n_ground/n_offsets");
     if (t->n_targets < 0 || t->n_targets > BRIDGES_MAX_TARGETS) return fail_arg("n_targets");
     if (t->a_max <= 0) return fail_arg("a_max");
-    if (buf->lp_ws_stride < (int64_t)(3 * t->max_blocks + 2) * (4 * BRIDGES_MAX_INTERFACES + 3)) return fail_arg("lp_ws_stride");
+    if (buf->lp_ws_stride < (int64_t)BRIDGES_LP_WS_DOUBLES) return fail_arg("lp_ws_stride < BRIDGES_LP_WS_DOUBLES");
+    static_assert(BRIDGES_LP_WS_DOUBLES == WARM_WS_DOUBLES, "header and device code disagree on the persistent tableau size");
     for (int g = 0; g < t->n_groups; ++g) {
         if (t->group_shape[g] < 0 || t->group_shape[g] >= t->n_shapes) return fail_arg("group_shape");
         if (t->group_face[g] < 0 || t->group_face[g] >= t->shapes[t->group_shape[g]].nv) return fail_arg("group_face");
@@ -248,11 +249,13 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
-#define CS_RM_SMALL 18      // first launch: register tableaux of <= 6 free blocks
+#define CS_TAB_SMALL 640
+#define CS_COLS_SMALL 92
 int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");
     const DevCtx& c = env->ctx;
-    if (!c.b.cand_stable || !c.b.cand_queue || !c.b.cand_counters) return fail_arg("cand_stable / cand_queue / cand_counters not given");
+    if (!c.b.cand_stable || !c.b.cand_queue || !c.b.cand_counters || !c.b.cand_ws) return fail_arg("cand_stable / cand_queue / cand_counters / cand_ws not given");
+    if (c.b.cand_ws_stride < (int64_t)(3 * c.K + 2) * (4 * BRIDGES_MAX_INTERFACES + 3)) return fail_arg("cand_ws_stride");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(c.b.cand_counters, 0, 2 * sizeof(int32_t), s));
     // one wave per raw candidate (masked-out ones leave at once); grid from the last known candidate count, grid-stride beyond
@@ -260,10 +263,10 @@ int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (est < c.E) est = c.E;
     est += est / 32 + 64;
     if (est > env->max_blocks) est = env->max_blocks;
-    hipLaunchKernelGGL((k_candidate_stability<CS_RM_SMALL, 8, 60, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
+    hipLaunchKernelGGL((k_candidate_stability<CS_TAB_SMALL, CS_COLS_SMALL, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability");
-    const int drain = c.E < 512 ? c.E : 512;          // one lp_ws slot per workgroup
-    hipLaunchKernelGGL((k_candidate_stability<STEP_RM, LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
+    const int drain = BRIDGES_CAND_WS_SLOTS;          // one cand_ws slot per workgroup
+    hipLaunchKernelGGL((k_candidate_stability<LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability (queue)");
     return BRIDGES_OK;
 }

@@ -12,7 +12,6 @@
 //               sum(action_features * reward_features) (successor_dqn.py:399-401)
 #include "bridges_device.h"
 #include "rbe_device.h"
-#include "rbe_reg.h"
 
 namespace bridges {
 
@@ -60,7 +59,6 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-#define STEP_RM 36          // register tableau: up to 12 free blocks (3 rows each); larger assemblies take the LDS tableau
 __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     // LDS: the staged face frames are dead once the interfaces are found, so they share storage with the tableau
     __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
@@ -138,7 +136,8 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     stage_faces(F, 0, 1 + (nb + 1) * MAXV, verts, shape_id, shapes, c.floor_hw, lane);
     __syncthreads();
     bool overflow = false;
-    int n_if = append_interfaces(F, nb, shape_id, shapes, c.floor_depth, c.b.n_if[e], if_body, if_geom, lane, &overflow);
+    const int n_if_old = c.b.n_if[e];
+    int n_if = append_interfaces(F, nb, shape_id, shapes, c.floor_depth, n_if_old, if_body, if_geom, lane, &overflow);
     __syncthreads();
 
     // ---- stability with the last block frozen / nothing frozen (gym_env.py:238-245, 325-333) ----
@@ -146,9 +145,10 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     bool err = false;
     bool st_frozen = true, st_free = true;
     const long long ts2 = (c.debug & 8) ? wall_clock64() : 0;
+    bool warm_used = false;
     if (!(c.debug & 1))
-        rbe_both_auto<STEP_RM>(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), c.mu,
-                               c.density, lane, &st_frozen, &st_free, &err);
+        rbe_both(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), n_if_old,
+                 c.mu, c.density, lane, &st_frozen, &st_free, &err, &warm_used);
 
     const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
@@ -183,8 +183,9 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     if (lane == 0) c.b.n_cand[e] = nc;
     if ((c.debug & 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
         const long long ts4 = wall_clock64();
-        ws[0] = (double)ts0; ws[1] = (double)(ts1 - ts0); ws[2] = (double)(ts2 - ts1); ws[3] = (double)(ts3 - ts2);
-        ws[4] = (double)(ts4 - ts3); ws[5] = (double)(nb + 1); ws[6] = (double)n_if; ws[7] = (double)ts4;
+        double* st = ws + c.b.lp_ws_stride - 8;     // the last 8 doubles of the env's workspace are never used otherwise
+        st[0] = (double)ts0; st[1] = (double)(ts1 - ts0); st[2] = (double)(ts2 - ts1); st[3] = (double)(ts3 - ts2);
+        st[4] = (double)(ts4 - ts3); st[5] = (double)(nb + 1); st[6] = (double)n_if + (warm_used ? 0.5 : 0.0); st[7] = (double)ts4;
     }
 }
 
@@ -598,13 +599,12 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
 // candidate arrays k_enumerate wrote.  Result: cand_stable[ci] = 1 stable, 0 unstable (or masked-out candidate),
 // 2 = solver error / interface overflow (counts as unstable, stability.py:68 + gym_env.py:182).
 //
-// Two launches share the code.  QUEUE == false: grid over all raw candidates, register tableau of RM rows only (no LDS
-// tableau: high occupancy); a candidate whose LP does not fit is appended to cand_queue (one atomic per such
-// candidate, they are rare).  QUEUE == true: a small persistent grid drains that queue with the large register
-// tableau, the full-size LDS tableau and the env workspace lp_ws (one slot per workgroup) behind it; every wave
-// leaves when the queue head passes the count.
+// Two launches share the code.  QUEUE == false: grid over all raw candidates, a small LDS tableau (high occupancy);
+// a candidate whose tableau does not fit is appended to cand_queue (one atomic per such candidate, they are rare).
+// QUEUE == true: a small persistent grid drains that queue with the full-size LDS tableau and the env workspace
+// lp_ws (one slot per workgroup) behind it; every wave leaves when the queue head passes the count.
 #define CS_NEW_IF 16
-template <int RM, int TAB, int MAXCOLS, bool QUEUE>
+template <int TAB, int MAXCOLS, bool QUEUE>
 __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
     __shared__ __attribute__((aligned(16))) double tab[TAB];
     __shared__ LpScratchT<MAXCOLS> S;
@@ -699,9 +699,9 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
             bool err = false, too_big = false;
             double w = 0.0;
             int piv = 0;
-            double* ws = QUEUE ? c.b.lp_ws + (size_t)blockIdx.x * c.b.lp_ws_stride : nullptr;
-            const bool st = rbe_stable_auto<RM>(tab, QUEUE ? TAB : 0, MAXCOLS, ws, QUEUE ? c.b.lp_ws_stride : (int64_t)0, S, A, fixed,
-                                                c.mu, c.density, lane, &w, &piv, &err, &too_big);
+            double* ws = QUEUE ? c.b.cand_ws + (size_t)blockIdx.x * c.b.cand_ws_stride : nullptr;
+            const bool st = rbe_stable(tab, TAB, MAXCOLS, ws, QUEUE ? c.b.cand_ws_stride : (int64_t)0, S, A, fixed, c.mu, c.density,
+                                       lane, &w, &piv, &err, &too_big);
             if (too_big) {
                 if constexpr (!QUEUE) {
                     if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;

@@ -2,7 +2,6 @@
 // Used by the single-environment assembly_gym API, by replay re-rasterisation and by the parity tests.
 #include "bridges_device.h"
 #include "rbe_device.h"
-#include "rbe_reg.h"
 
 namespace bridges {
 
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     int piv = 0;
     const long long t1 = clock64();
     bool too_big = false;
-    bool st = rbe_stable_auto<36>(tab, LP_TAB_LDS, LP_MAX_COLS, tab_ws, tab_cap, S, env_view(nb, pose, shape_id, shapes, n_if, if_body, if_geom),
+    bool st = rbe_stable(tab, LP_TAB_LDS, LP_MAX_COLS, tab_ws, tab_cap, S, env_view(nb, pose, shape_id, shapes, n_if, if_body, if_geom),
                          fm, mu, density, lane, &w, &piv, &err, &too_big);
     err = err || too_big;
     if (lane == 0) {

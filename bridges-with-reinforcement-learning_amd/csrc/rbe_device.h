@@ -189,9 +189,13 @@ __device__ __forceinline__ AsmView env_view(int n_blocks, const double* pose, co
 // The right-hand side carries a tiny deterministic perturbation (<= 2e-7 per row, far below RBE_FEAS_TOL): these
 // equilibrium systems are massively degenerate (most rhs entries are exactly 0) and the perturbation is what keeps
 // the simplex from stalling.
+// ncarr = m adds one "carrier" column per equilibrium row behind the rhs (column nn + 1 + i = e_i at the start, i.e. the
+// explicit artificial of row i).  Row operations keep  tableau = R * [M | slack | w | I], so carrier i always holds
+// R e_i: what a column that arrives later (a new contact of a later block) must be multiplied with to enter the tableau
+// in its current coordinates (lp_warm_prepare).  Carriers are never priced.
 template <typename TP>
 __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const AsmView& A, const int* row_of /*LDS [K]*/,
-                                double mu, double density, int lane) {
+                                double mu, double density, int lane, int ncarr = 0) {
     const int nn = n + 1;                              // structural columns incl. the budget slack; rhs column index
     int cells = (m + 2) * stride;
     for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
@@ -225,6 +229,7 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
     for (int i = lane; i < m; i += WAVE)
         T[i * stride + nn] = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
     for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? 1.0 : LP_S_MAX * density;
+    for (int i = lane; i < ncarr; i += WAVE) T[i * stride + nn + 1 + i] = 1.0;
     __syncthreads();
     for (int b = lane; b < A.n_blocks; b += WAVE)
         if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * A.S(b).volume;
@@ -240,11 +245,11 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
 template <int MAXCOLS>
 struct LpScratchT {                // LDS scratch of one wave's simplex (MAXCOLS = generator columns it can hold)
     double col[WAVE];              // entering column (row i in slot i, cost entry in slot m)
-    double rowr[MAXCOLS + 4];      // normalised pivot row
+    double rowr[MAXCOLS + 4 + 3 * MAXK];   // normalised pivot row (generators, slack, rhs, carriers)
     int basis[WAVE];
     int row_of[MAXK];              // first tableau row of block b, or -1 if the block is fixed (is_static)
     short rows_nz[WAVE];           // rows touched by the current pivot (entering column entry != 0)
-    short cols_nz[MAXCOLS + 4];    // columns touched by the current pivot (pivot row entry != 0)
+    short cols_nz[MAXCOLS + 4 + 3 * MAXK]; // columns touched by the current pivot (pivot row entry != 0)
 };
 typedef LpScratchT<LP_MAX_COLS> LpScratch;
 
@@ -293,7 +298,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // Returns w = sum of the artificial basics (<= feas <=> stable).  All lanes return the same value.
 template <bool IN_LDS, typename TP, typename SC>
 __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int* pivots_out,
-                                   bool* error, bool init_basis, double feas) {
+                                   bool* error, bool init_basis, double feas, int ncarr = 0) {
     // m equilibrium rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials
     // (the others are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
     // Row m is the force-budget row (always enforced, basic variable = its slack, column n_gen), row m+1 the cost.
@@ -307,7 +312,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
     int pivots = *pivots_out, stall = 0;
     bool bland = false;
     const int nchunk = (n + WAVE - 1) / WAVE;
-    const int ncols = n + 1;
+    const int ncols = n + 1 + ncarr;                   // swept columns: structural, rhs, carriers
     const double progress = 1e-7 * feas;               // 1e-12 at density 1
     LP_PROF_DECL;
     double w = artificial_sum(T, stride, m_act, n, basis, lane);
@@ -492,12 +497,12 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
 // Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
 // price it into the cost row.  The tableau then continues from the basis reached so far (warm start).
 template <bool IN_LDS, typename TP, typename SC>
-__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane) {
+__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int ncarr = 0) {
     const int n = n_gen + 1;
     for (int i = m_act; i < m; ++i) {
         const bool neg = T[i * stride + n] < 0.0;                  // uniform
         wave_sync<IN_LDS>();
-        for (int q = lane; q <= n; q += WAVE) {
+        for (int q = lane; q <= n + ncarr; q += WAVE) {
             double v = T[i * stride + q];
             if (neg) { v = -v; T[i * stride + q] = v; }
             T[(m + 1) * stride + q] -= v;
@@ -518,10 +523,10 @@ __device__ inline void lp_row_map(SC& S, uint32_t free_mask, int lane) {
 
 // Tableau geometry of an assembly with n_free free blocks and n_if interfaces: rows m = 3 n_free (+ budget + cost),
 // generator columns n = 4 n_if, odd row stride (conflict-free column reads).
-__device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, int& stride, int64_t& cells) {
+__device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, int& stride, int64_t& cells, bool carriers = false) {
     m = 3 * n_free;
     n = 4 * n_if;
-    stride = n + 2;
+    stride = n + 2 + (carriers ? m : 0);
     if ((stride & 1) == 0) stride += 1;
     cells = (int64_t)(m + 2) * stride;
 }
@@ -562,25 +567,130 @@ __device__ inline bool rbe_stable(double* tab_lds, int lds_cap, int max_cols, do
     return w <= feas;
 }
 
-// Both variants of gym_env.py:325-333 in ONE tableau.  Stage 1 solves "last block frozen" (the rows of the last
-// block are carried along passively); if it is infeasible so is the unfrozen system (a superset of its rows).
-// Otherwise stage 2 enforces the last block's three equilibrium rows and continues from the stage-1 basis.
+// ---- persistent tableau of an environment (incremental simplex) --------------------------------------------------
+// Between two lock-steps the assembly only GROWS: one block, its contacts.  The equilibrium LP of the next step is
+// therefore the LP just solved plus three rows (the new block) and four columns per new contact, and "last block
+// frozen" of the next step enforces exactly the rows "nothing frozen" enforced in this one.  So k_step keeps the final
+// tableau of every live environment in lp_ws (header + basis + cells, two halves for tableaux that are worked on in
+// global memory) and the next step continues from it: old cells are copied over (column / row indices remapped, the
+// layout is always  generators | slack | rhs | carriers), the new columns enter as  sum_i a_i * carrier_i + slack
+// (their budget coefficient is 1), the new rows are appended untouched (no old column reaches into them), the phase-1
+// cost row is rebuilt from the rows whose artificial is still basic.  Stage 1 then needs no pivot at all when the
+// previous assembly was stable unfrozen, stage 2 about three -- instead of ~2 per row from an all-artificial start
+// (measured before: 14 pivots per step on average, 80 for 12 blocks; a pivot is ~3750 cycles whatever the size).
+// Every verdict is still re-checked against the original rows (lp_verify); a warm tableau that fails the check is
+// rebuilt from scratch (cold path) before anything is reported.
+#define WARM_HDR_DOUBLES 64                                  // header (16 int32) + basis (64 int32) + padding
+#define WARM_MAX_STRIDE (LP_MAX_COLS + 2 + 3 * MAXK + 1)
+#define WARM_HALF ((int64_t)(3 * MAXK + 2) * WARM_MAX_STRIDE)
+#define WARM_WS_DOUBLES (WARM_HDR_DOUBLES + 2 * WARM_HALF)   // bridges_env_buffers.lp_ws_stride must be >= this
+#define WARM_MAGIC 0x57A7B1E5
+
+struct WarmHdr {
+    int32_t magic, n_blocks, n_if, stride, half, m, pad_[10];
+    int32_t basis[64];
+};
+
+// Continue from the persisted tableau `src` (stride_o, m_o rows + budget, n_gen_o generators, carriers for its m_o
+// rows): fill T (stride, m = m_o + 3 rows, n_gen generators) and S.basis, rebuild the cost row for stage 1 (active
+// rows = the old ones).  A.n_blocks - 1 is the new block, interfaces >= n_gen_o / 4 are its contacts.
 template <bool IN_LDS, typename TP>
-__device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu,
-                                   double density, int lane, bool* st_frozen, bool* st_free, bool* error) {
+__device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const double* src, int stride_o, int m_o,
+                                       int n_gen_o, const int32_t* basis_o, LpScratch& S, const AsmView& A, double mu,
+                                       double density, int lane) {
+    const int n = n_gen + 1, n_o = n_gen_o + 1;                 // rhs column index (new / old)
+    const int ncols_o = n_o + 1 + m_o;
+    const int cells = (m + 2) * stride;
+    for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
+    wave_sync<IN_LDS>();
+    // old rows (equilibrium rows keep their index, the budget row moves from m_o to m), old columns remapped
+    const int cells_o = (m_o + 1) * ncols_o;
+    for (int idx = lane; idx < cells_o; idx += WAVE) {
+        const int i = idx / ncols_o, q = idx - i * ncols_o;
+        const double v = src[(size_t)i * stride_o + q];
+        const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
+        const int in = i < m_o ? i : m;
+        T[in * stride + qn] = v;
+    }
+    if (lane <= m_o) {
+        const int b = basis_o[lane];
+        const int bn = b < n_gen_o ? b : (b == n_gen_o ? n_gen : n + (b - n_o));
+        S.basis[lane < m_o ? lane : m] = bn;
+    }
+    if (lane >= m_o && lane < m) S.basis[lane] = -1;            // the new block's rows are passive in stage 1
+    wave_sync<IN_LDS>();
+    // the new block's rows: rhs (perturbation + weight on the Fz row), carrier = identity
+    const int nbn = A.n_blocks - 1;
+    if (lane < 3) {
+        const int i = m_o + lane;
+        double rhs = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
+        if (lane == 1) rhs += density * A.S(nbn).volume;
+        T[i * stride + n] = rhs;
+        T[i * stride + n + 1 + i] = 1.0;
+    }
+    // new generator columns: R * a for the old rows and the budget row, raw entries in the new rows
+    for (int j = n_gen_o; j < n_gen; ++j) {
+        const int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
+        const double* g = A.ig(k);
+        const int32_t* bd = A.ib(k);
+        const double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+        const double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
+        const double gx = ig ? nx - mu * tx : nx + mu * tx;
+        const double gz = ig ? nz - mu * tz : nz + mu * tz;
+        const int bodyA = bd[0];                                 // floor (-1) or an older block; body B is the new block
+        if (lane <= m_o) {
+            const int row = lane < m_o ? lane : m;
+            double v = T[row * stride + n_gen];                  // budget coefficient 1 times the slack column
+            if (bodyA >= 0) {
+                const bridges_shape& sh = A.S(bodyA);
+                const double* P = A.P(bodyA);
+                double rgx, rgz;
+                rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
+                const double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+                const double a0 = -gx, a1 = -gz, a2 = rx * a1 - rz * a0;
+                const int c0 = n + 1 + 3 * bodyA;
+                v += a0 * T[row * stride + c0] + a1 * T[row * stride + c0 + 1] + a2 * T[row * stride + c0 + 2];
+            }
+            T[row * stride + j] = v;
+        } else if (lane < m_o + 4) {
+            const int cmp = lane - m_o - 1;                      // 0, 1, 2: Fx, Fz, My of the new block
+            const bridges_shape& sh = A.S(nbn);
+            const double* P = A.P(nbn);
+            double rgx, rgz;
+            rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
+            const double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+            T[(m_o + cmp) * stride + j] = cmp == 0 ? gx : (cmp == 1 ? gz : rx * gz - rz * gx);
+        }
+    }
+    wave_sync<IN_LDS>();
+    // phase-1 cost row over the structural columns and the rhs: minus the rows whose artificial is still basic
+    for (int q = lane; q <= n; q += WAVE) {
+        double sacc = 0.0;
+        for (int i = 0; i < m_o; ++i)
+            if (S.basis[i] >= n) sacc += T[i * stride + q];
+        T[(m + 1) * stride + q] = -sacc;
+    }
+    wave_sync<IN_LDS>();
+}
+
+// Stage 1 (last block frozen: its rows passive) and stage 2 (nothing frozen) of gym_env.py:325-333 on one tableau
+// that is either freshly built (warm == false) or continued from the persisted one (prepared by lp_warm_prepare).
+template <bool IN_LDS, typename TP>
+__device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu, double density,
+                                    int lane, bool warm, bool* st_frozen, bool* st_free, bool* error) {
     const int m_act = m - 3;
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
-    lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane);
+    if (!warm) lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane, m);
     int piv = 0;
-    double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, true, feas);
+    double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, !warm, feas, m);
     *st_frozen = w <= feas;
     if (*st_frozen && m_act > 0 && lp_verify(T, stride, m, m_act, n, S, A, mu, density, lane) > vtol) {
         *st_frozen = false;                 // the verdict does not survive the check on the original rows
         *error = true;
     }
     if (!*st_frozen) { *st_free = false; return; }
-    lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane);
-    w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas);
+    lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane, m);
+    w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas, m);
     *st_free = w <= feas;
     if (*st_free && lp_verify(T, stride, m, m, n, S, A, mu, density, lane) > vtol) {
         *st_free = false;
@@ -588,23 +698,73 @@ __device__ inline void rbe_both_in(TP T, int stride, int m, int n, LpScratch& S,
     }
 }
 
-__device__ inline void rbe_both(double* tab_lds, double* tab_ws, int64_t ws_cap, LpScratch& S, const AsmView& A,
-                                double mu, double density, int lane, bool* st_frozen, bool* st_free, bool* error) {
+// Persist rows 0..m (equilibrium + budget) of the LDS tableau.
+__device__ inline void lp_warm_store(const double* T, int stride, int m, int n_gen, double* dst, int lane) {
+    const int ncols = n_gen + 2 + m;
+    const int cells = (m + 1) * ncols;
+    for (int idx = lane; idx < cells; idx += WAVE) {
+        const int i = idx / ncols, q = idx - i * ncols;
+        dst[(size_t)i * stride + q] = T[i * stride + q];
+    }
+}
+
+// k_step's solve: both stability variants of the assembly A (A.n_blocks blocks, the last one new), continuing from the
+// environment's persisted tableau in `ws` when it matches the state (n_blocks - 1 blocks, n_if_old interfaces), and
+// persisting the result there when `keep`.  *warm_used reports which path produced the verdict.
+__device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
+                                double mu, double density, int lane, bool* st_frozen, bool* st_free, bool* error,
+                                bool* warm_used) {
+    WarmHdr* hdr = reinterpret_cast<WarmHdr*>(ws);
+    double* halves = ws + WARM_HDR_DOUBLES;
+    *warm_used = false;
+    const int nb = A.n_blocks;
     if (A.n_if == 0) {                                 // stability.py:53-56: no edges -> stable iff no free node
-        *st_frozen = A.n_blocks == 1;
+        *st_frozen = nb == 1;
         *st_free = false;
+        if (lane == 0) hdr->magic = 0;
         return;
     }
-    const uint32_t all = A.n_blocks >= 32 ? 0xffffffffu : ((1u << A.n_blocks) - 1u);
+    const uint32_t all = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
     lp_row_map(S, all, lane);
     int m, n, stride;
     int64_t cells;
-    lp_dims(A.n_blocks, A.n_if, m, n, stride, cells);
-    if (cells <= LP_TAB_LDS) {
-        rbe_both_in<true>(tab_lds, stride, m, n, S, A, mu, density, lane, st_frozen, st_free, error);
-    } else {
-        if (cells > ws_cap) { *error = true; *st_frozen = false; *st_free = false; return; }
-        rbe_both_in<false>(tab_ws, stride, m, n, S, A, mu, density, lane, st_frozen, st_free, error);
+    lp_dims(nb, A.n_if, m, n, stride, cells, true);
+    if (ws_cap < WARM_WS_DOUBLES || cells > WARM_HALF) {
+        *error = true; *st_frozen = false; *st_free = false;
+        if (lane == 0) hdr->magic = 0;
+        return;
+    }
+    // the persisted tableau continues this state iff it was written for exactly the assembly without the new block
+    bool warm = hdr->magic == WARM_MAGIC && hdr->n_blocks == nb - 1 && hdr->n_if == n_if_old && nb >= 2 &&
+                hdr->m == 3 * (nb - 1);
+    const int half_o = hdr->half & 1, stride_o = hdr->stride;
+    const bool in_lds = cells <= LP_TAB_LDS;
+    const int half_n = in_lds ? 0 : 1 - half_o;        // a tableau worked on in global memory alternates halves
+    double* Tg = halves + (int64_t)half_n * WARM_HALF;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool err = false;
+        if (warm) {
+            const double* src = halves + (int64_t)half_o * WARM_HALF;
+            if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, hdr->basis, S, A, mu, density, lane);
+            else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, hdr->basis, S, A, mu, density, lane);
+        }
+        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
+        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
+        if (!(warm && err)) { *error = err; *warm_used = warm; break; }
+        warm = false;                                  // the continued tableau failed its check: solve from scratch
+        lp_row_map(S, all, lane);
+    }
+    __syncthreads();
+    // persist for the next step (pointless when the episode ends here; the caller invalidates on reset)
+    if (*st_frozen && !*error) {
+        if (in_lds) lp_warm_store(tab_lds, stride, m, n, halves, lane);
+        if (lane <= m) hdr->basis[lane] = S.basis[lane];
+        if (lane == 0) {
+            hdr->n_blocks = nb; hdr->n_if = A.n_if; hdr->stride = stride; hdr->half = half_n; hdr->m = m;
+            hdr->magic = WARM_MAGIC;
+        }
+    } else if (lane == 0) {
+        hdr->magic = 0;
     }
     __syncthreads();
 }

@@ -34,6 +34,9 @@ extern "C" {
 #define BRIDGES_MAX_TARGETS 8
 #define BRIDGES_MAX_INTERFACES 64
 #define BRIDGES_IMG 64          /* rasters are 64x64 (successor_dqn.py:585 default) */
+/* doubles of lp_ws per environment: 64 (header, basis) + 2 halves of (3*MAX_BLOCKS+2) rows x (4*MAX_IF + 2 + 3*MAX_BLOCKS + 1) columns */
+#define BRIDGES_LP_WS_DOUBLES (64 + 2 * (3 * BRIDGES_MAX_BLOCKS + 2) * (4 * BRIDGES_MAX_INTERFACES + 2 + 3 * BRIDGES_MAX_BLOCKS + 1))
+#define BRIDGES_CAND_WS_SLOTS 512
 
 /* One block shape: a convex (x,z) outline extruded along y.
  * Replaces Shape.from_urdf / from_mesh / get_face_frame_2d
@@ -131,13 +134,16 @@ typedef struct {
     const uint64_t* obstacle_bits; /* [64] */
     const float* reward_map;       /* [64,64] */
     /* --- scratch --- */
-    double* lp_ws;             /* [E, lp_ws_stride] simplex tableau overflow */
-    int64_t lp_ws_stride;      /* >= 9*MAX_IF + (3K+2)*(4*MAX_IF+3) */
+    double* lp_ws;             /* [E, lp_ws_stride] per-env persistent simplex tableau (incremental solve of bridges_env_step):
+                                  header + basis + two tableau halves; owned by the library between reset and step calls */
+    int64_t lp_ws_stride;      /* >= BRIDGES_LP_WS_DOUBLES */
     uint64_t* stats;           /* [8] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps */
     /* --- candidate stability (bridges_env_candidate_stability; all three may be NULL if it is never called) --- */
     uint8_t* cand_stable;      /* [C] 1 = stable, 0 = unstable or masked-out candidate, 2 = solver error / contact overflow */
     int32_t* cand_queue;       /* [C] scratch: candidates whose tableau needs the large workspace */
     int32_t* cand_counters;    /* [4] scratch: queue length, queue head */
+    double* cand_ws;           /* [BRIDGES_CAND_WS_SLOTS, cand_ws_stride] scratch: tableaux too large for LDS */
+    int64_t cand_ws_stride;    /* >= (3K+2)*(4*MAX_IF+3) */
 } bridges_env_buffers;
 
 typedef struct bridges_env bridges_env;

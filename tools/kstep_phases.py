@@ -13,7 +13,7 @@ for _ in range(40):
     env.select_random(); env.step()
 for rep in range(3):
     env.select_random(); env.step(); torch.cuda.synchronize()
-    w = env.lp_ws[:, :8].cpu().numpy()
+    w = env.lp_ws[:, -8:].cpu().numpy()
     ok = env.step_flags[:, 0].cpu().numpy().astype(bool)
     w = w[ok]
     t0, t4 = w[:, 0], w[:, 7]
@@ -25,6 +25,8 @@ for rep in range(3):
         v = w[:, col] / 100.0
         print(f"    {name:15s} mean {v.mean():6.1f}  p95 {np.percentile(v,95):6.1f}  max {v.max():6.1f} us")
     nb = w[:, 5].astype(int)
+    warm = (w[:, 6] % 1.0) > 0.25
+    print(f"    continued from the persisted tableau: {warm.mean()*100:.1f} % of the envs")
     for k in sorted(set(nb)):
         sel = nb == k
         print(f"    nb={k:2d} n={sel.sum():5d} LP us mean {w[sel,3].mean()/100:6.1f} max {w[sel,3].max()/100:6.1f}  total mean {tot[sel].mean():6.1f}")
