@@ -109,6 +109,7 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     c.seed = t->seed;
     c.debug = t->debug;
     c.env_id_base = t->env_id_base;
+    c.n_shapes = t->n_shapes;
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -148,6 +148,7 @@ struct DevCtx {
     const TaskTable* tt;
     int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
     int32_t debug, env_id_base;     // debug bit0: skip the LPs (timing experiments only)
+    int32_t n_shapes, pad_;
     int32_t group_shape[BRIDGES_MAX_GROUPS];
     int32_t group_face[BRIDGES_MAX_GROUPS];
     double mu, density, floor_hw, floor_depth;

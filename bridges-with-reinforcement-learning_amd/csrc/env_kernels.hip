@@ -59,22 +59,82 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One wave per environment.  The kernel is a chain of dependent steps, and beside another env group's rasteriser
+// (which keeps the HBM write queues full) every dependent global-memory round trip costs microseconds, so the loads
+// are organised in exactly two levels: (0) everything addressed by the env id alone -- counters, the placed blocks,
+// the contact list, the shape table, the persisted tableau's header -- is requested up front and staged in LDS;
+// (1) what the selected candidate and the header point to (candidate pose / vertices / raster, tableau cells).
+// After that the wave works on LDS and registers only; results leave as stores nobody waits for.
+#define STEP_IF_LDS 32      // contacts kept in LDS (the rest of a longer list is read in place from global memory)
+struct StepLds {
+    bridges_shape shapes[8];
+    double pose[MAXK * 4];
+    double verts[MAXK * MAXV * 2];
+    double if_geom[STEP_IF_LDS * 8];
+    int32_t if_body[STEP_IF_LDS * 2];
+    int32_t shape_id[MAXK];
+    int32_t occ[MAXK];
+};
+
+// free faces of the first nb blocks (occupancy and shape ids from LDS) -> number of raw candidates of that state
+__device__ inline int count_candidates_lds(const DevCtx& c, const StepLds& L, int nb, int lane) {
+    int nf = 0;
+    if (lane < nb) {
+        const int nv = L.shapes[L.shape_id[lane]].nv;
+        nf = nv - __popc((uint32_t)L.occ[lane] & ((1u << nv) - 1u));
+    }
+    int nfree = 0;
+    for (int b = 0; b < nb; ++b) nfree += __builtin_amdgcn_readlane(nf, b);
+    const int n = c.n_groups * (c.n_ground + nfree * c.n_offsets);
+    return n > c.a_max ? c.a_max : n;
+}
+
 __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
-    // LDS: the staged face frames are dead once the interfaces are found, so they share storage with the tableau
-    __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
+    __shared__ __attribute__((aligned(16))) double tab[LP_TAB_LDS];
     __shared__ LpScratch S;
-    FaceLds& F = *reinterpret_cast<FaceLds*>(lds_tab);
-    double* tab = lds_tab;
+    __shared__ StepLds L;
     // latency-bound kernel that usually runs beside another env group's bandwidth-bound rasteriser: take the
     // instruction arbiter's priority so the dependent pivot chain is not stretched by the co-resident store waves
     __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
-    const bridges_shape* shapes = c.tt->shapes;
     uint8_t* flags = c.b.step_flags + (size_t)e * 8;
     const long long ts0 = (c.debug & 8) ? wall_clock64() : 0;      // debug bit3: per-env phase stamps (tools/kstep_phases.py)
+    int32_t* shape_id_g = c.b.blk_shape + (size_t)e * K;
+    double* pose_g = c.b.blk_pose + (size_t)e * K * 4;
+    double* verts_g = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+    uint8_t* occ_g = c.b.blk_occ + (size_t)e * K;
+    int32_t* if_body_g = c.b.if_body + (size_t)e * MAXIF * 2;
+    double* if_geom_g = c.b.if_geom + (size_t)e * MAXIF * 8;
+    double* ws = c.b.lp_ws + (size_t)e * c.b.lp_ws_stride;
+    const WarmHdr* hdr_g = reinterpret_cast<const WarmHdr*>(ws);
 
-    if (c.b.needs_reset[e]) {                       // reset-only lock-step (previous state had no valid action)
+    // ---- level 0: everything the env id addresses ----
+    const uint8_t need_reset = c.b.needs_reset[e];
+    const int a = c.b.sel_index[e];
+    const int off = c.b.cand_offset[e];
+    const int nb = c.b.n_blocks[e];                 // index of the new block
+    const int n_if_old = c.b.n_if[e];
+    uint32_t left = c.b.targets_left[e];
+    const uint64_t sbits = c.b.state_bits[(size_t)e * IMG + lane];
+    WarmPre W;
+    W.magic = hdr_g->magic; W.n_blocks = hdr_g->n_blocks; W.n_if = hdr_g->n_if; W.stride = hdr_g->stride;
+    W.half = hdr_g->half; W.m = hdr_g->m;
+    W.basis_lane = hdr_g->basis[lane];
+    {
+        const double* src = reinterpret_cast<const double*>(c.tt->shapes);
+        double* dst = reinterpret_cast<double*>(L.shapes);
+        const int nd = c.n_shapes * (int)(sizeof(bridges_shape) / 8);
+        for (int i = lane; i < nd; i += WAVE) dst[i] = src[i];
+        for (int i = lane; i < nb * 4; i += WAVE) L.pose[i] = pose_g[i];
+        for (int i = lane; i < nb * MAXV * 2; i += WAVE) L.verts[i] = verts_g[i];
+        if (lane < K) { L.shape_id[lane] = shape_id_g[lane]; L.occ[lane] = occ_g[lane]; }
+        const int n0 = n_if_old < STEP_IF_LDS ? n_if_old : STEP_IF_LDS;
+        for (int i = lane; i < n0 * 8; i += WAVE) L.if_geom[i] = if_geom_g[i];
+        for (int i = lane; i < n0 * 2; i += WAVE) L.if_body[i] = if_body_g[i];
+    }
+
+    if (need_reset) {                               // reset-only lock-step (previous state had no valid action)
         reset_env(c, e, lane);
         if (lane < 8) flags[lane] = 0;
         if (lane == 0) {
@@ -82,44 +142,52 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
             c.b.lin_reward[e] = 0.f;
             c.b.n_reached[e] = 0;
         }
-        int nc = count_candidates(c, e, 0, lane);
-        if (lane == 0) c.b.n_cand[e] = nc;
+        const int nc0 = c.n_groups * c.n_ground;
+        if (lane == 0) c.b.n_cand[e] = nc0 > c.a_max ? c.a_max : nc0;
         return;
     }
 
-    const int a = c.b.sel_index[e];
-    const size_t ci = (size_t)c.b.cand_offset[e] + a;
-    const int nb = c.b.n_blocks[e];                 // index of the new block
-    int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
-    double* pose = c.b.blk_pose + (size_t)e * K * 4;
-    double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
-    const int tb = c.b.cand_desc[ci * 4 + 0], tf = c.b.cand_desc[ci * 4 + 1];
-    const int sh = c.b.cand_desc[ci * 4 + 2], fc = c.b.cand_desc[ci * 4 + 3];
+    // ---- level 1: the selected candidate, the cells of the persisted tableau ----
+    const size_t ci = (size_t)off + a;
+    const int dsc = lane < 4 ? c.b.cand_desc[ci * 4 + lane] : 0;
+    const double cpose = lane < 4 ? c.b.cand_pose[ci * 4 + lane] : 0.0;
+    const double cvert = lane < MAXV * 2 ? c.b.cand_verts[ci * MAXV * 2 + lane] : 0.0;
+    const uint64_t cbits = c.b.cand_bits[ci * IMG + lane];
+    const float base = c.b.cand_lin[ci];
+    warm_prefetch(W, ws, nb, n_if_old, lane);
+    const int tb = __builtin_amdgcn_readlane(dsc, 0), tf = __builtin_amdgcn_readlane(dsc, 1);
+    const int sh = __builtin_amdgcn_readlane(dsc, 2), fc = __builtin_amdgcn_readlane(dsc, 3);
 
-    // ---- append the block (gym_env.py:220-232) ----
-    if (lane < 4) pose[nb * 4 + lane] = c.b.cand_pose[ci * 4 + lane];
-    if (lane < MAXV * 2) verts[nb * MAXV * 2 + lane] = c.b.cand_verts[ci * MAXV * 2 + lane];
-    c.b.state_bits[(size_t)e * IMG + lane] |= c.b.cand_bits[ci * IMG + lane];
+    // ---- append the block (gym_env.py:220-232): LDS copy for this step, global copy for the next ones ----
+    if (lane < 4) { L.pose[nb * 4 + lane] = cpose; pose_g[nb * 4 + lane] = cpose; }
+    if (lane < MAXV * 2) { L.verts[nb * MAXV * 2 + lane] = cvert; verts_g[nb * MAXV * 2 + lane] = cvert; }
+    c.b.state_bits[(size_t)e * IMG + lane] = sbits | cbits;
+    __syncthreads();                                // level-0 staging and the new block are in LDS
     if (lane == 0) {
-        shape_id[nb] = sh;
-        uint8_t* occ = c.b.blk_occ + (size_t)e * K;
-        occ[nb] = (uint8_t)(1u << fc);
-        if (tb >= 0) occ[tb] |= (uint8_t)(1u << tf);
+        L.shape_id[nb] = sh;
+        shape_id_g[nb] = sh;
+        L.occ[nb] = (int32_t)(1u << fc);
+        occ_g[nb] = (uint8_t)(1u << fc);
+        if (tb >= 0) {
+            L.occ[tb] |= (int32_t)(1u << tf);
+            occ_g[tb] = (uint8_t)L.occ[tb];
+        }
         c.b.n_blocks[e] = nb + 1;
     }
     __syncthreads();
+    const bridges_shape* shapes = L.shapes;
+    const bridges_shape& shn = shapes[sh];
 
     // ---- targets (gym_env.py:163-169, compas Box.contains_point tol 1e-6) ----
     double vx = 0.0, vz = 0.0;
-    const int nvn = shapes[sh].nv;
+    const int nvn = shn.nv;
     bool hasv = lane < nvn;
-    if (hasv) { vx = verts[nb * MAXV * 2 + 2 * lane]; vz = verts[nb * MAXV * 2 + 2 * lane + 1]; }
+    if (hasv) { vx = L.verts[nb * MAXV * 2 + 2 * lane]; vz = L.verts[nb * MAXV * 2 + 2 * lane + 1]; }
     double x0 = wave_min_d(hasv ? vx : 1e300), x1 = wave_max_d(hasv ? vx : -1e300);
     double z0 = wave_min_d(hasv ? vz : 1e300), z1 = wave_max_d(hasv ? vz : -1e300);
-    uint32_t left = c.b.targets_left[e];
     {
         double cx = (x0 + x1) * 0.5, cz = (z0 + z1) * 0.5, hx = (x1 - x0) * 0.5, hz = (z1 - z0) * 0.5;
-        double hy = shapes[sh].depth * 0.5;
+        double hy = shn.depth * 0.5;
         for (int t = 0; t < c.n_targets; ++t) {
             if (!((left >> t) & 1u)) continue;
             bool in = fabs(c.targets[t][0] - cx) < hx + 1e-6 && fabs(c.targets[t][1]) < hy + 1e-6 &&
@@ -128,27 +196,78 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         }
     }
     const int n_reached = c.n_targets - __popc(left);
-
     const long long ts1 = (c.debug & 8) ? wall_clock64() : 0;
-    // ---- contact interfaces of the new block (assembly_env.py:281-304) ----
-    int32_t* if_body = c.b.if_body + (size_t)e * MAXIF * 2;
-    double* if_geom = c.b.if_geom + (size_t)e * MAXIF * 8;
-    stage_faces(F, 0, 1 + (nb + 1) * MAXV, verts, shape_id, shapes, c.floor_hw, lane);
-    __syncthreads();
+
+    // ---- contact interfaces of the new block (assembly_env.py:281-304): its faces against the floor and every
+    //      older block's faces, frames computed on the fly from the LDS vertices (same pair order and arithmetic as
+    //      append_interfaces / oracle/rbe.py face_pair_contact); hits go to the persistent list and its LDS copy ----
+    int n_if = n_if_old;
     bool overflow = false;
-    const int n_if_old = c.b.n_if[e];
-    int n_if = append_interfaces(F, nb, shape_id, shapes, c.floor_depth, n_if_old, if_body, if_geom, lane, &overflow);
+    {
+        const double* nverts = L.verts + nb * MAXV * 2;
+        const int totalp = (1 + nb * MAXV) * MAXV;
+        for (int p0 = 0; p0 < totalp; p0 += WAVE) {
+            const int p = p0 + lane;
+            bool hit = false;
+            double g[8];
+            int bodyA = -1;
+            if (p < totalp) {
+                const int qa = p / MAXV, fn = p % MAXV;
+                if (fn < shn.nv) {
+                    const int ia = shn.fa[fn], ib = shn.fb[fn];
+                    const double aBx = nverts[2 * ia], aBz = nverts[2 * ia + 1], bBx = nverts[2 * ib], bBz = nverts[2 * ib + 1];
+                    const Frame2 fB = edge_frame(aBx, aBz, bBx, bBz);
+                    if (qa == 0) {
+                        hit = face_pair_contact_v(-c.floor_hw, 0.0, c.floor_hw, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, aBx, aBz, bBx,
+                                                  bBz, fB.cx, fB.cz, fB.nx, fB.nz, fmin(c.floor_depth, shn.depth), g);
+                    } else {
+                        bodyA = (qa - 1) / MAXV;
+                        const int f = (qa - 1) % MAXV;
+                        const bridges_shape& sa = shapes[L.shape_id[bodyA]];
+                        if (f < sa.nv) {
+                            const double* v = L.verts + bodyA * MAXV * 2;
+                            const double ax = v[2 * sa.fa[f]], az = v[2 * sa.fa[f] + 1], bx = v[2 * sa.fb[f]], bz = v[2 * sa.fb[f] + 1];
+                            const Frame2 fr = edge_frame(ax, az, bx, bz);
+                            hit = face_pair_contact_v(ax, az, bx, bz, fr.cx, fr.cz, fr.tx, fr.tz, fr.nx, fr.nz, aBx, aBz, bBx, bBz,
+                                                      fB.cx, fB.cz, fB.nx, fB.nz, fmin(sa.depth, shn.depth), g);
+                        }
+                    }
+                }
+            }
+            const uint64_t bal = __ballot(hit);
+            const int idx = n_if + __popcll(bal & ((1ull << lane) - 1ull));
+            if (hit && idx < MAXIF) {
+                if_body_g[2 * idx] = bodyA;
+                if_body_g[2 * idx + 1] = nb;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if_geom_g[8 * idx + k] = g[k];
+                if (idx < STEP_IF_LDS) {
+                    L.if_body[2 * idx] = bodyA;
+                    L.if_body[2 * idx + 1] = nb;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) L.if_geom[8 * idx + k] = g[k];
+                }
+            }
+            n_if += __popcll(bal);
+        }
+        if (n_if > MAXIF) { overflow = true; n_if = MAXIF; }
+    }
     __syncthreads();
 
     // ---- stability with the last block frozen / nothing frozen (gym_env.py:238-245, 325-333) ----
-    double* ws = c.b.lp_ws + (size_t)e * c.b.lp_ws_stride;
     bool err = false;
     bool st_frozen = true, st_free = true;
     const long long ts2 = (c.debug & 8) ? wall_clock64() : 0;
     bool warm_used = false;
-    if (!(c.debug & 1))
-        rbe_both(tab, ws, c.b.lp_ws_stride, S, env_view(nb + 1, pose, shape_id, shapes, n_if, if_body, if_geom), n_if_old,
-                 c.mu, c.density, lane, &st_frozen, &st_free, &err, &warm_used);
+    if (!(c.debug & 1)) {
+        AsmView A;
+        A.pose = L.pose; A.shape_id = L.shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
+        A.cand_b = -1; A.cand_pose = L.pose; A.cand_shape = 0;
+        A.n_if = n_if; A.n_if0 = n_if < STEP_IF_LDS ? n_if : STEP_IF_LDS;
+        A.if_body0 = L.if_body; A.if_geom0 = L.if_geom;
+        A.if_body1 = if_body_g + 2 * STEP_IF_LDS; A.if_geom1 = if_geom_g + 8 * STEP_IF_LDS;
+        rbe_both(tab, ws, c.b.lp_ws_stride, S, A, n_if_old, W, c.mu, c.density, lane, &st_frozen, &st_free, &err, &warm_used);
+    }
 
     const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
@@ -159,7 +278,6 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     const bool truncated = (c.max_steps > 0 && (nb + 1) >= c.max_steps) || (nb + 1) >= K;
     const bool done = terminated || truncated;
     float reward = !st_frozen ? -1.f : (all_reached ? (float)n_reached : (float)(-1 + n_reached));
-    const float base = c.b.cand_lin[ci];
     float lin = st_free ? base : (st_frozen ? base / 100.f : 0.f);          // successor_dqn.py:397-401
 
     if (lane == 0) {
@@ -172,14 +290,12 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         c.b.n_if[e] = n_if;
         c.b.targets_left[e] = left;
     }
-    __syncthreads();
     int nb_after = nb + 1;
-    if (done) {                                     // auto-reset
+    if (done) {                                     // auto-reset (after the stores above: same lanes, program order)
         reset_env(c, e, lane);
         nb_after = 0;
-        __syncthreads();
     }
-    int nc = count_candidates(c, e, nb_after, lane);
+    const int nc = count_candidates_lds(c, L, nb_after, lane);
     if (lane == 0) c.b.n_cand[e] = nc;
     if ((c.debug & 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
         const long long ts4 = wall_clock64();

@@ -591,12 +591,42 @@ struct WarmHdr {
     int32_t basis[64];
 };
 
+// What k_step requests of the persisted tableau before it knows anything else about the step: the header with the
+// first batch of loads, the cells (up to WARM_PRE per lane, compact index lane + 64 u over rows 0..m_o x the old
+// columns) with the second -- so that continuing costs no further global-memory round trip for all but the largest
+// tableaux.
+#define WARM_PRE 16
+struct WarmPre {
+    int32_t magic, n_blocks, n_if, stride, half, m;
+    int32_t basis_lane;                 // hdr.basis[lane]
+    bool ok;                            // the header describes exactly the assembly without the new block
+    double cell[WARM_PRE];
+};
+
+__device__ __forceinline__ void warm_prefetch(WarmPre& W, const double* ws, int n_old_blocks, int n_if_old, int lane) {
+    W.ok = W.magic == WARM_MAGIC && W.n_blocks == n_old_blocks && W.n_if == n_if_old && n_old_blocks >= 1 &&
+           W.m == 3 * n_old_blocks;
+    const int m_o = 3 * n_old_blocks, ncols_o = 4 * n_if_old + 2 + m_o;
+    const int cells_o = W.ok ? (m_o + 1) * ncols_o : 0;
+    const double* src = ws + WARM_HDR_DOUBLES + (int64_t)(W.half & 1) * WARM_HALF;
+#pragma unroll
+    for (int u = 0; u < WARM_PRE; ++u) {
+        const int idx = lane + WAVE * u;
+        double v = 0.0;
+        if (idx < cells_o) {
+            const int i = idx / ncols_o, q = idx - i * ncols_o;
+            v = src[(size_t)i * W.stride + q];
+        }
+        W.cell[u] = v;
+    }
+}
+
 // Continue from the persisted tableau `src` (stride_o, m_o rows + budget, n_gen_o generators, carriers for its m_o
 // rows): fill T (stride, m = m_o + 3 rows, n_gen generators) and S.basis, rebuild the cost row for stage 1 (active
 // rows = the old ones).  A.n_blocks - 1 is the new block, interfaces >= n_gen_o / 4 are its contacts.
 template <bool IN_LDS, typename TP>
 __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const double* src, int stride_o, int m_o,
-                                       int n_gen_o, const int32_t* basis_o, LpScratch& S, const AsmView& A, double mu,
+                                       int n_gen_o, const WarmPre& W, LpScratch& S, const AsmView& A, double mu,
                                        double density, int lane) {
     const int n = n_gen + 1, n_o = n_gen_o + 1;                 // rhs column index (new / old)
     const int ncols_o = n_o + 1 + m_o;
@@ -605,7 +635,17 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
     wave_sync<IN_LDS>();
     // old rows (equilibrium rows keep their index, the budget row moves from m_o to m), old columns remapped
     const int cells_o = (m_o + 1) * ncols_o;
-    for (int idx = lane; idx < cells_o; idx += WAVE) {
+#pragma unroll
+    for (int u = 0; u < WARM_PRE; ++u) {                         // the prefetched cells
+        const int idx = lane + WAVE * u;
+        if (idx < cells_o) {
+            const int i = idx / ncols_o, q = idx - i * ncols_o;
+            const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
+            const int in = i < m_o ? i : m;
+            T[in * stride + qn] = W.cell[u];
+        }
+    }
+    for (int idx = lane + WAVE * WARM_PRE; idx < cells_o; idx += WAVE) {    // the rest of a large tableau
         const int i = idx / ncols_o, q = idx - i * ncols_o;
         const double v = src[(size_t)i * stride_o + q];
         const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
@@ -613,7 +653,7 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
         T[in * stride + qn] = v;
     }
     if (lane <= m_o) {
-        const int b = basis_o[lane];
+        const int b = W.basis_lane;
         const int bn = b < n_gen_o ? b : (b == n_gen_o ? n_gen : n + (b - n_o));
         S.basis[lane < m_o ? lane : m] = bn;
     }
@@ -712,8 +752,8 @@ __device__ inline void lp_warm_store(const double* T, int stride, int m, int n_g
 // environment's persisted tableau in `ws` when it matches the state (n_blocks - 1 blocks, n_if_old interfaces), and
 // persisting the result there when `keep`.  *warm_used reports which path produced the verdict.
 __device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
-                                double mu, double density, int lane, bool* st_frozen, bool* st_free, bool* error,
-                                bool* warm_used) {
+                                const WarmPre& W, double mu, double density, int lane, bool* st_frozen, bool* st_free,
+                                bool* error, bool* warm_used) {
     WarmHdr* hdr = reinterpret_cast<WarmHdr*>(ws);
     double* halves = ws + WARM_HDR_DOUBLES;
     *warm_used = false;
@@ -735,9 +775,8 @@ __device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpS
         return;
     }
     // the persisted tableau continues this state iff it was written for exactly the assembly without the new block
-    bool warm = hdr->magic == WARM_MAGIC && hdr->n_blocks == nb - 1 && hdr->n_if == n_if_old && nb >= 2 &&
-                hdr->m == 3 * (nb - 1);
-    const int half_o = hdr->half & 1, stride_o = hdr->stride;
+    bool warm = W.ok;
+    const int half_o = W.half & 1, stride_o = W.stride;
     const bool in_lds = cells <= LP_TAB_LDS;
     const int half_n = in_lds ? 0 : 1 - half_o;        // a tableau worked on in global memory alternates halves
     double* Tg = halves + (int64_t)half_n * WARM_HALF;
@@ -745,8 +784,8 @@ __device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpS
         bool err = false;
         if (warm) {
             const double* src = halves + (int64_t)half_o * WARM_HALF;
-            if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, hdr->basis, S, A, mu, density, lane);
-            else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, hdr->basis, S, A, mu, density, lane);
+            if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
+            else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
         }
         if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
         else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
