@@ -227,6 +227,9 @@ def parse_args():
     ap.add_argument("--max_steps", type=int, default=15)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, one HIP stream each")
+    ap.add_argument("--raster-split", type=int, default=0,
+                    help="per mille of a lock-step's images in the rasteriser's head launch (the next group's rasteriser is "
+                         "released behind it); 0 = one launch")
     ap.add_argument("--mode", choices=["sim", "candidate-stability"], default="sim",
                     help="candidate-stability: every lock-step also decides is_action_stable_rbe for every valid candidate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -299,7 +302,7 @@ def main():
                 env.candidate_stability_mask()
         env.sync = lambda: None
     else:
-        env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, **kw)
+        env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, raster_split=args.raster_split, **kw)
         lockstep = env.lockstep_random
 
     for _ in range(args.warmup):
@@ -379,7 +382,8 @@ def main():
             "config": {
                 "workload": "%d envs/GPU lock-step, %s, %s, max_steps=%d, uniform-random policy, %s"
                             % (args.envs, task_label, args.shapes, args.max_steps, raster_mode),
-                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups, "tower_height": args.tower_height,
+                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups, "raster_split": args.raster_split,
+                "tower_height": args.tower_height,
                 "bridge_length": args.bridge_length, "shapes": args.shapes, "max_steps": args.max_steps,
                 "mean_raw_candidates": d["sum_cand"] / max(units, 1),
                 "mean_valid_candidates": d["sum_valid"] / max(units, 1),

@@ -158,6 +158,7 @@ def lib():
         "bridges_gate_create": [C.POINTER(vp)],
         "bridges_gate_destroy": [vp],
         "bridges_env_set_gate": [vp, vp],
+        "bridges_env_set_raster_split": [vp, i32],
         "bridges_env_timing_begin": [vp, i32],
         "bridges_env_timing_end": [vp, C.POINTER(C.c_double), C.POINTER(i32)],
         "bridges_shapes_upload": [C.POINTER(Shape), i32, C.POINTER(vp)],
@@ -188,7 +189,7 @@ EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_env_candidate_stability",
-    "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
+    "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate", "bridges_env_set_raster_split",
     "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",

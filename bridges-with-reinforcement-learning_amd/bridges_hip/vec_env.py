@@ -364,7 +364,7 @@ class VecAssemblyGymGroups:
     rasteriser of another.  Environments are independent, so results are identical to a single group with the same
     global env ids (policy RNG streams are keyed by seed and global env id)."""
 
-    def __init__(self, num_envs, *args, groups=2, device="cuda:0", raster_gate=None, **kw):
+    def __init__(self, num_envs, *args, groups=2, device="cuda:0", raster_gate=None, raster_split=0, **kw):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.G = int(groups)
@@ -390,6 +390,8 @@ class VecAssemblyGymGroups:
         if self.G > 1 and raster_gate:
             for env in self.envs:
                 abi.check(L.bridges_env_set_gate(env._env, self._gate), "bridges_env_set_gate")
+                # release the next group's rasteriser behind the first raster_split / 1000 of this one's images
+                abi.check(L.bridges_env_set_raster_split(env._env, int(raster_split)), "bridges_env_set_raster_split")
         self.sync()
 
     def sync(self):

@@ -43,6 +43,7 @@ struct bridges_env {
     TaskTable* tt_dev;
     int32_t* h_total;          // pinned: candidate count of the previous lock-step (sizes the raster / expand grids)
     int max_blocks;            // upper bound of a useful grid
+    int split_permille;        // > 0: rasteriser launched as head (this share of the expected items) + tail
     // optional per-launch timing of the dominant kernel (k_raster) with HIP events on the launch stream
     hipEvent_t* ev_start;
     hipEvent_t* ev_stop;
@@ -124,6 +125,7 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (e != hipSuccess) { (void)hipFree(env->tt_dev); delete env; return fail_hip(e, "hipHostMalloc"); }
     *env->h_total = t->n_envs * 64;        // first guess; replaced after every scan
     env->max_blocks = 1 << 22;
+    env->split_permille = 0;
     *out = env;
     return BRIDGES_OK;
 }
@@ -170,6 +172,12 @@ int bridges_env_set_gate(bridges_env* env, bridges_gate* gate) {
     return BRIDGES_OK;
 }
 
+int bridges_env_set_raster_split(bridges_env* env, int32_t head_permille) {
+    if (!env || head_permille < 0 || head_permille >= 1000) return fail_arg("set_raster_split");
+    env->split_permille = head_permille;
+    return BRIDGES_OK;
+}
+
 int bridges_env_timing_begin(bridges_env* env, int32_t max_launches) {
     if (!env || max_launches <= 0 || max_launches > (1 << 16)) return fail_arg("timing_begin");
     free_events(env);
@@ -212,17 +220,34 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     if (est < c.E) est = c.E;
     est += est / 32 + 64;
     HIP_TRY(hipMemcpyAsync(env->h_total, c.b.cand_offset + c.E, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    long long rblocks = (est + c.E + 3) / 4;          // one wave per image (candidates + state rasters)
+    const long long items_est = est + c.E;            // one wave per image (candidates + state rasters)
+    long long rblocks = (items_est + 3) / 4;
     if (rblocks > env->max_blocks) rblocks = env->max_blocks;
     const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
     if (env->gate && env->gate->last) HIP_TRY(hipStreamWaitEvent(s, env->gate->last, 0));
     if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
-    hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, s, c);
-    LAUNCH_CHECK("k_raster");
-    if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
-    if (env->gate) {
+    if (env->gate && env->split_permille > 0 && env->split_permille < 1000) {
+        // head: the first share of the expected items; the gate is released behind it, so the next group's rasteriser
+        // ramps up (and the ~25 us cross-queue hand-over passes) while the tail of this one drains
+        const long long head_items = items_est * env->split_permille / 1000 / 4 * 4;
+        const long long hblocks = head_items / 4 > 0 ? head_items / 4 : 1;
+        hipLaunchKernelGGL(k_raster, dim3((unsigned)hblocks), dim3(256), 0, s, c, 0, (int)head_items);
+        LAUNCH_CHECK("k_raster (head)");
         HIP_TRY(hipEventRecord(env->raster_done, s));
         env->gate->last = env->raster_done;
+        long long tblocks = rblocks - hblocks;
+        if (tblocks < 64) tblocks = 64;                // the tail grid-strides over whatever the estimate missed
+        hipLaunchKernelGGL(k_raster, dim3((unsigned)tblocks), dim3(256), 0, s, c, (int)head_items, 0x7fffffff);
+        LAUNCH_CHECK("k_raster (tail)");
+        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
+    } else {
+        hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, s, c, 0, 0x7fffffff);
+        LAUNCH_CHECK("k_raster");
+        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
+        if (env->gate) {
+            HIP_TRY(hipEventRecord(env->raster_done, s));
+            env->gate->last = env->raster_done;
+        }
     }
     hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
     LAUNCH_CHECK("k_select");

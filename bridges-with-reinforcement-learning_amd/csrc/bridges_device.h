@@ -61,6 +61,13 @@ __device__ __forceinline__ void align_place(const Frame2& f1, double c2x, double
 // Conservative image-row window of a block spanning z in [zmin, zmax]: one extra pixel row either side; outside it
 // every pixel fails some half-plane test by a margin of ~0.08 world units >> 1 ulp, so skipping the rows cannot
 // change a bit of the raster.  grid_y = np.linspace(ylim1, ylim0, 64) (row 0 = top).
+__device__ __forceinline__ void row_window2(double gy_first, double gy_last, double zmin, double zmax, int& r_lo, int& r_hi) {
+    const double ytop = gy_first, dy = (gy_first - gy_last) / (double)(IMG - 1);
+    r_lo = (int)floor((ytop - zmax) / dy) - 1;
+    r_hi = (int)ceil((ytop - zmin) / dy) + 1;
+    r_lo = r_lo < 0 ? 0 : r_lo;
+    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
+}
 __device__ __forceinline__ void row_window(const double* gy, double zmin, double zmax, int& r_lo, int& r_hi) {
     const double ytop = gy[0], dy = (gy[0] - gy[IMG - 1]) / (double)(IMG - 1);
     r_lo = (int)floor((ytop - zmax) / dy) - 1;

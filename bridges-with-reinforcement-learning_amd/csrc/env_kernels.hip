@@ -66,33 +66,28 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
 // (1) what the selected candidate and the header point to (candidate pose / vertices / raster, tableau cells).
 // After that the wave works on LDS and registers only; results leave as stores nobody waits for.
 #define STEP_IF_LDS 32      // contacts kept in LDS (the rest of a longer list is read in place from global memory)
-struct StepLds {
+#define STEP_TAB_LDS 4096   // doubles of LDS tableau in k_step (32 KiB: carriers included, 12 blocks with 17 contacts still fit;
+                            // 4 workgroups per CU, which costs nothing: a 2048-env group needs two rounds at 5 per CU as well)
+struct StepStage {          // dead once the contacts are found: shares its storage with the tableau
     bridges_shape shapes[8];
     double pose[MAXK * 4];
     double verts[MAXK * MAXV * 2];
-    double if_geom[STEP_IF_LDS * 8];
-    int32_t if_body[STEP_IF_LDS * 2];
     int32_t shape_id[MAXK];
     int32_t occ[MAXK];
 };
-
-// free faces of the first nb blocks (occupancy and shape ids from LDS) -> number of raw candidates of that state
-__device__ inline int count_candidates_lds(const DevCtx& c, const StepLds& L, int nb, int lane) {
-    int nf = 0;
-    if (lane < nb) {
-        const int nv = L.shapes[L.shape_id[lane]].nv;
-        nf = nv - __popc((uint32_t)L.occ[lane] & ((1u << nv) - 1u));
-    }
-    int nfree = 0;
-    for (int b = 0; b < nb; ++b) nfree += __builtin_amdgcn_readlane(nf, b);
-    const int n = c.n_groups * (c.n_ground + nfree * c.n_offsets);
-    return n > c.a_max ? c.a_max : n;
-}
+struct StepKeep {           // what the LP reads of the assembly
+    double if_geom[STEP_IF_LDS * 8];
+    int32_t if_body[STEP_IF_LDS * 2];
+    double cen[MAXK * 2];
+    double vol[MAXK];
+};
+static_assert(sizeof(StepStage) <= STEP_TAB_LDS * sizeof(double), "staging area must fit into the tableau storage");
 
 __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
-    __shared__ __attribute__((aligned(16))) double tab[LP_TAB_LDS];
+    __shared__ __attribute__((aligned(16))) double tab[STEP_TAB_LDS];
     __shared__ LpScratch S;
-    __shared__ StepLds L;
+    __shared__ StepKeep Lk;
+    StepStage& L = *reinterpret_cast<StepStage*>(tab);
     // latency-bound kernel that usually runs beside another env group's bandwidth-bound rasteriser: take the
     // instruction arbiter's priority so the dependent pivot chain is not stretched by the co-resident store waves
     __builtin_amdgcn_s_setprio(3);
@@ -130,8 +125,8 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         for (int i = lane; i < nb * MAXV * 2; i += WAVE) L.verts[i] = verts_g[i];
         if (lane < K) { L.shape_id[lane] = shape_id_g[lane]; L.occ[lane] = occ_g[lane]; }
         const int n0 = n_if_old < STEP_IF_LDS ? n_if_old : STEP_IF_LDS;
-        for (int i = lane; i < n0 * 8; i += WAVE) L.if_geom[i] = if_geom_g[i];
-        for (int i = lane; i < n0 * 2; i += WAVE) L.if_body[i] = if_body_g[i];
+        for (int i = lane; i < n0 * 8; i += WAVE) Lk.if_geom[i] = if_geom_g[i];
+        for (int i = lane; i < n0 * 2; i += WAVE) Lk.if_body[i] = if_body_g[i];
     }
 
     if (need_reset) {                               // reset-only lock-step (previous state had no valid action)
@@ -177,6 +172,18 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     __syncthreads();
     const bridges_shape* shapes = L.shapes;
     const bridges_shape& shn = shapes[sh];
+    // per block: world centroid and volume for the LP (the staging area becomes the tableau), free faces for the
+    // candidate count of the next state
+    int nf = 0;
+    if (lane <= nb) {
+        const bridges_shape& sb = shapes[L.shape_id[lane]];
+        double rgx, rgz;
+        rot2(sb.gx, sb.gz, L.pose[4 * lane + 2], L.pose[4 * lane + 3], rgx, rgz);
+        Lk.cen[2 * lane] = L.pose[4 * lane] + rgx;
+        Lk.cen[2 * lane + 1] = L.pose[4 * lane + 1] + rgz;
+        Lk.vol[lane] = sb.volume;
+        nf = sb.nv - __popc((uint32_t)L.occ[lane] & ((1u << sb.nv) - 1u));
+    }
 
     // ---- targets (gym_env.py:163-169, compas Box.contains_point tol 1e-6) ----
     double vx = 0.0, vz = 0.0;
@@ -242,10 +249,10 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if_geom_g[8 * idx + k] = g[k];
                 if (idx < STEP_IF_LDS) {
-                    L.if_body[2 * idx] = bodyA;
-                    L.if_body[2 * idx + 1] = nb;
+                    Lk.if_body[2 * idx] = bodyA;
+                    Lk.if_body[2 * idx + 1] = nb;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) L.if_geom[8 * idx + k] = g[k];
+                    for (int k = 0; k < 8; ++k) Lk.if_geom[8 * idx + k] = g[k];
                 }
             }
             n_if += __popcll(bal);
@@ -259,14 +266,16 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     bool st_frozen = true, st_free = true;
     const long long ts2 = (c.debug & 8) ? wall_clock64() : 0;
     bool warm_used = false;
+    int lp_diag = 0;
     if (!(c.debug & 1)) {
-        AsmView A;
-        A.pose = L.pose; A.shape_id = L.shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
-        A.cand_b = -1; A.cand_pose = L.pose; A.cand_shape = 0;
+        AsmView A;                                  // centroids / volumes / contacts from LDS; the block arrays are gone
+        A.pose = nullptr; A.shape_id = nullptr; A.shapes = nullptr; A.n_blocks = nb + 1;
+        A.cand_b = -1; A.cand_pose = nullptr; A.cand_shape = 0; A.cen = Lk.cen; A.vol = Lk.vol;
         A.n_if = n_if; A.n_if0 = n_if < STEP_IF_LDS ? n_if : STEP_IF_LDS;
-        A.if_body0 = L.if_body; A.if_geom0 = L.if_geom;
+        A.if_body0 = Lk.if_body; A.if_geom0 = Lk.if_geom;
         A.if_body1 = if_body_g + 2 * STEP_IF_LDS; A.if_geom1 = if_geom_g + 8 * STEP_IF_LDS;
-        rbe_both(tab, ws, c.b.lp_ws_stride, S, A, n_if_old, W, c.mu, c.density, lane, &st_frozen, &st_free, &err, &warm_used);
+        rbe_both(tab, STEP_TAB_LDS, ws, c.b.lp_ws_stride, S, A, n_if_old, W, c.mu, c.density, lane, &st_frozen, &st_free, &err,
+                 &warm_used, &lp_diag);
     }
 
     const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
@@ -295,13 +304,16 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         reset_env(c, e, lane);
         nb_after = 0;
     }
-    const int nc = count_candidates_lds(c, L, nb_after, lane);
+    int nfree = 0;
+    for (int b = 0; b < nb_after; ++b) nfree += __builtin_amdgcn_readlane(nf, b);
+    int nc = c.n_groups * (c.n_ground + nfree * c.n_offsets);
+    nc = nc > c.a_max ? c.a_max : nc;
     if (lane == 0) c.b.n_cand[e] = nc;
     if ((c.debug & 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
         const long long ts4 = wall_clock64();
         double* st = ws + c.b.lp_ws_stride - 8;     // the last 8 doubles of the env's workspace are never used otherwise
         st[0] = (double)ts0; st[1] = (double)(ts1 - ts0); st[2] = (double)(ts2 - ts1); st[3] = (double)(ts3 - ts2);
-        st[4] = (double)(ts4 - ts3); st[5] = (double)(nb + 1); st[6] = (double)n_if + (warm_used ? 0.5 : 0.0); st[7] = (double)ts4;
+        st[4] = (double)(ts4 - ts3); st[5] = (double)(nb + 1); st[6] = (double)n_if + (warm_used ? 0.5 : 0.0) + 100.0 * (double)lp_diag; st[7] = (double)ts4;
     }
 }
 
@@ -311,6 +323,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 // group's rasteriser (28 of a CU's 32 wave slots taken) a 16-wave workgroup waited ~100 us for a CU to place it.
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / WAVE)
+#define SCAN_BATCH 8        // envs per thread whose loads are in flight together (one round trip per 2048 envs)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step) {
     __shared__ int wave_tot[SCAN_WAVES];
     __shared__ int carry_s;
@@ -320,35 +333,52 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
     if (t == 0) carry_s = 0;
     __syncthreads();
     unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};   // blocks, env-steps, reset-only, lp errors, if overflow, valid
-    for (int base = 0; base < c.E; base += SCAN_THREADS) {
-        const int i = base + t;
-        const int v = i < c.E ? c.b.n_cand[i] : 0;
-        if (i < c.E) {
-            acc[0] += (unsigned long long)c.b.n_blocks[i];
-            if (after_step) {
-                const uint8_t* fl = c.b.step_flags + (size_t)i * 8;
-                acc[1] += fl[F_VALID] ? 1 : 0;
-                acc[2] += fl[F_VALID] ? 0 : 1;
-                acc[3] += (fl[F_LP_ERROR] & 1) ? 1 : 0;
-                acc[4] += (fl[F_LP_ERROR] & 2) ? 1 : 0;
-                acc[5] += (unsigned long long)c.b.n_valid[i];      // valid candidates of the state just left
-            }
-        }
-        int incl = v;                                    // inclusive scan inside the wave
+    for (int base0 = 0; base0 < c.E; base0 += SCAN_THREADS * SCAN_BATCH) {
+        // all loads of the batch first: beside a rasteriser every dependent round trip costs microseconds
+        int v[SCAN_BATCH], nbk[SCAN_BATCH], nval[SCAN_BATCH];
+        uint64_t fl8[SCAN_BATCH];
 #pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            int up = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += up;
+        for (int u = 0; u < SCAN_BATCH; ++u) {
+            const int i = base0 + u * SCAN_THREADS + t;
+            const bool in = i < c.E;
+            v[u] = in ? c.b.n_cand[i] : 0;
+            nbk[u] = in ? c.b.n_blocks[i] : 0;
+            nval[u] = (in && after_step) ? c.b.n_valid[i] : 0;
+            fl8[u] = (in && after_step) ? *reinterpret_cast<const uint64_t*>(c.b.step_flags + (size_t)i * 8) : 0ull;
         }
-        if (lane == WAVE - 1) wave_tot[wv] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
-        const int carry = carry_s;
-        if (i < c.E) c.b.cand_offset[i] = carry + wbase + incl - v;
-        __syncthreads();
-        if (t == SCAN_THREADS - 1) carry_s = carry + wbase + incl;
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SCAN_BATCH; ++u) {
+            const int base = base0 + u * SCAN_THREADS;
+            if (base >= c.E) break;
+            const int i = base + t;
+            if (i < c.E) {
+                acc[0] += (unsigned long long)nbk[u];
+                if (after_step) {
+                    const unsigned valid = (unsigned)(fl8[u] >> (8 * F_VALID)) & 0xffu;
+                    const unsigned lperr = (unsigned)(fl8[u] >> (8 * F_LP_ERROR)) & 0xffu;
+                    acc[1] += valid ? 1 : 0;
+                    acc[2] += valid ? 0 : 1;
+                    acc[3] += (lperr & 1) ? 1 : 0;
+                    acc[4] += (lperr & 2) ? 1 : 0;
+                    acc[5] += (unsigned long long)nval[u];             // valid candidates of the state just left
+                }
+            }
+            int incl = v[u];                                 // inclusive scan inside the wave
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                int up = __shfl_up(incl, o, WAVE);
+                if (lane >= o) incl += up;
+            }
+            if (lane == WAVE - 1) wave_tot[wv] = incl;
+            __syncthreads();
+            int wbase = 0;
+            for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+            const int carry = carry_s;
+            if (i < c.E) c.b.cand_offset[i] = carry + wbase + incl - v[u];
+            __syncthreads();
+            if (t == SCAN_THREADS - 1) carry_s = carry + wbase + incl;
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -377,13 +407,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
     __shared__ uint8_t free_b[MAXK * MAXV], free_f[MAXK * MAXV];
+    __shared__ bridges_shape sh_l[8];
+    __shared__ double verts_l[MAXK * MAXV * 2];
+    __shared__ int32_t shape_l[MAXK], occ_l[MAXK];
+    __shared__ double xg_l[32], offs_l[8], gy_l[2];
     __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
-    const bridges_shape* shapes = c.tt->shapes;
+    // everything the env id addresses is requested at once and staged in LDS (see k_step)
+    if (lane < 32) xg_l[lane] = c.tt->x_ground[lane];
+    if (lane < 8) offs_l[lane] = c.tt->offsets[lane];
+    if (lane < 2) gy_l[lane] = c.tt->grid_y[lane * (IMG - 1)];
     const int nb = c.b.n_blocks[e];
-    const int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
-    const double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+    const int ncand = c.b.n_cand[e];
+    const size_t off = (size_t)c.b.cand_offset[e];
+    {
+        const double* src = reinterpret_cast<const double*>(c.tt->shapes);
+        double* dst = reinterpret_cast<double*>(sh_l);
+        const int nd = c.n_shapes * (int)(sizeof(bridges_shape) / 8);
+        for (int i = lane; i < nd; i += WAVE) dst[i] = src[i];
+        const double* vg = c.b.blk_verts + (size_t)e * K * MAXV * 2;
+        for (int i = lane; i < nb * MAXV * 2; i += WAVE) verts_l[i] = vg[i];
+        if (lane < K) { shape_l[lane] = c.b.blk_shape[(size_t)e * K + lane]; occ_l[lane] = c.b.blk_occ[(size_t)e * K + lane]; }
+    }
+    __syncthreads();
+    const bridges_shape* shapes = sh_l;
+    const int32_t* shape_id = shape_l;
+    const double* verts = verts_l;
     // free (block, face) list in (block, face) order (actions.py:28-45)
     int nfree = 0;
     for (int i0 = 0; i0 < nb * MAXV; i0 += WAVE) {
@@ -392,7 +442,7 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
         int b = i / MAXV, f = i % MAXV;
         if (i < nb * MAXV) {
             int nv = shapes[shape_id[b]].nv;
-            fr = f < nv && !((c.b.blk_occ[(size_t)e * K + b] >> f) & 1);
+            fr = f < nv && !((occ_l[b] >> f) & 1);
         }
         uint64_t bal = __ballot(fr);
         if (fr) {
@@ -404,8 +454,6 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
     }
     __syncthreads();
     const int gsize = c.n_ground + nfree * c.n_offsets;
-    const int ncand = c.b.n_cand[e];
-    const size_t off = (size_t)c.b.cand_offset[e];
     for (int a = lane; a < ncand; a += WAVE) {
         int grp = a / gsize, slot = a % gsize;
         int sh = c.group_shape[grp], fc = c.group_face[grp];
@@ -413,11 +461,11 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
         double ox;
         Frame2 f1;
         if (slot < c.n_ground) {
-            ox = c.tt->x_ground[slot];
+            ox = xg_l[slot];
             f1.cx = 0.0; f1.cz = 0.0; f1.tx = 1.0; f1.tz = 0.0; f1.nx = 0.0; f1.nz = 1.0;   // assembly_env.py:339-340
         } else {
             int k = (slot - c.n_ground) / c.n_offsets;
-            ox = c.tt->offsets[(slot - c.n_ground) % c.n_offsets];
+            ox = offs_l[(slot - c.n_ground) % c.n_offsets];
             tb = free_b[k]; tf = free_f[k];
             const bridges_shape& st = shapes[shape_id[tb]];
             const double* v = verts + (size_t)tb * MAXV * 2;
@@ -463,7 +511,7 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
             }
 #undef PICK6
             int r_lo, r_hi;
-            row_window(c.tt->grid_y, zmin, zmax, r_lo, r_hi);
+            row_window2(gy_l[0], gy_l[1], zmin, zmax, r_lo, r_hi);
             c.b.cand_rows[ci * 2 + 0] = r_lo | (r_hi << 8) | (sn.nv << 16) | ((inb ? 1 : 0) << 24);   // packed for the rasteriser
             c.b.cand_rows[ci * 2 + 1] = e;
         }
@@ -623,13 +671,17 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
 // memory) so that a wave sees about one item -- short-lived waves dispatched in item order keep the HBM write
 // stream close to linear, which sustains ~14 % more bandwidth than a persistent grid (tools/store_bench.hip) -- and
 // the grid-stride loop makes any count correct.  The half-plane tests hide behind the 16 KiB of stores per image.
-__global__ __launch_bounds__(256) void k_raster(DevCtx c) {
+// item_begin / item_end: the launch covers the work items [item_begin, min(item_end, items)) -- the host splits one
+// lock-step's rasterisation into a head and a tail launch so that the next env group's rasteriser can be released
+// when the head is done (api.hip: refresh).
+__global__ __launch_bounds__(256) void k_raster(DevCtx c, int item_begin, int item_end) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     const int total = c.b.cand_offset[c.E];
-    const int items = total + (c.b.state_raster ? c.E : 0);
-    for (int itv = wave; itv < items; itv += nwaves) {
+    const int items_all = total + (c.b.state_raster ? c.E : 0);
+    const int items = items_all < item_end ? items_all : item_end;
+    for (int itv = item_begin + wave; itv < items; itv += nwaves) {
         const int it = __builtin_amdgcn_readfirstlane(itv);       // wave-uniform: metadata comes through scalar loads
         if (it < total) {
             const size_t ci = (size_t)it;
@@ -807,7 +859,7 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
         } else {
             AsmView A;
             A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
-            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh;
+            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh; A.cen = nullptr; A.vol = nullptr;
             A.n_if = n_if0 + n_new; A.n_if0 = n_if0;
             A.if_body0 = c.b.if_body + (size_t)e * MAXIF * 2; A.if_geom0 = c.b.if_geom + (size_t)e * MAXIF * 8;
             A.if_body1 = new_body; A.if_geom1 = new_geom;

@@ -40,7 +40,7 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
                               // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
 #ifndef LP_TAB_LDS
-#define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (16 KiB); larger tableaux live in lp_ws
+#define LP_TAB_LDS 2048                       // doubles of LDS tableau per wave (16 KiB); larger tableaux live in global memory
 #endif
 #define MAXFACES (1 + MAXK * MAXV)            // floor + K blocks
 #define LP_MAX_COLS (4 * MAXIF)
@@ -163,17 +163,29 @@ struct AsmView {
     const double* if_geom0;        // [n_if0,8]
     const int32_t* if_body1;       // [n_if-n_if0,2]
     const double* if_geom1;
+    const double* cen;             // optional [K,2]: world centroid of every block (then pose / shapes are not read)
+    const double* vol;             // optional [K]
     __device__ __forceinline__ const double* P(int b) const { return b == cand_b ? cand_pose : pose + 4 * b; }
     __device__ __forceinline__ const bridges_shape& S(int b) const { return shapes[b == cand_b ? cand_shape : shape_id[b]]; }
     __device__ __forceinline__ const int32_t* ib(int k) const { return k < n_if0 ? if_body0 + 2 * k : if_body1 + 2 * (k - n_if0); }
     __device__ __forceinline__ const double* ig(int k) const { return k < n_if0 ? if_geom0 + 8 * k : if_geom1 + 8 * (k - n_if0); }
+    // world centroid of block b: pose position + rotated local centroid (the moment reference of its equilibrium rows)
+    __device__ __forceinline__ void centroid(int b, double& gcx, double& gcz) const {
+        if (cen) { gcx = cen[2 * b]; gcz = cen[2 * b + 1]; return; }
+        const bridges_shape& sh = S(b);
+        const double* Pb = P(b);
+        double rgx, rgz;
+        rot2(sh.gx, sh.gz, Pb[2], Pb[3], rgx, rgz);
+        gcx = Pb[0] + rgx; gcz = Pb[1] + rgz;
+    }
+    __device__ __forceinline__ double volume(int b) const { return vol ? vol[b] : S(b).volume; }
 };
 
 __device__ __forceinline__ AsmView env_view(int n_blocks, const double* pose, const int32_t* shape_id, const bridges_shape* shapes,
                                             int n_if, const int32_t* if_body, const double* if_geom) {
     AsmView A;
     A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = n_blocks;
-    A.cand_b = -1; A.cand_pose = pose; A.cand_shape = 0;
+    A.cand_b = -1; A.cand_pose = pose; A.cand_shape = 0; A.cen = nullptr; A.vol = nullptr;
     A.n_if = n_if; A.n_if0 = n_if; A.if_body0 = if_body; A.if_geom0 = if_geom; A.if_body1 = if_body; A.if_geom1 = if_geom;
     return A;
 }
@@ -215,11 +227,9 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
             if (r >= 0) {
                 double sgx = side == 0 ? gx : -gx;
                 double sgz = side == 0 ? gz : -gz;
-                const bridges_shape& sh = A.S(body);
-                const double* P = A.P(body);
-                double rgx, rgz;
-                rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
-                double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+                double gcx, gcz;
+                A.centroid(body, gcx, gcz);
+                double rx = px - gcx, rz = pz - gcz;
                 T[(r + 0) * stride + j] = sgx;
                 T[(r + 1) * stride + j] = sgz;
                 T[(r + 2) * stride + j] = rx * sgz - rz * sgx;
@@ -232,7 +242,7 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
     for (int i = lane; i < ncarr; i += WAVE) T[i * stride + nn + 1 + i] = 1.0;
     __syncthreads();
     for (int b = lane; b < A.n_blocks; b += WAVE)
-        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * A.S(b).volume;
+        if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * A.volume(b);
     __syncthreads();
     for (int q = lane; q <= nn; q += WAVE) {         // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
         double s = 0.0;
@@ -464,11 +474,8 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
         int b = -1;
         for (int k = 0; k < A.n_blocks; ++k) if (S.row_of[k] >= 0 && S.row_of[k] <= lane && lane < S.row_of[k] + 3) b = k;
         const int comp = lane - S.row_of[b];
-        const bridges_shape& sh = A.S(b);
-        const double* P = A.P(b);
-        double rgx, rgz;
-        rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
-        const double gcx = P[0] + rgx, gcz = P[1] + rgz;
+        double gcx, gcz;
+        A.centroid(b, gcx, gcz);
         double acc = 0.0;
         for (int k = 0; k < A.n_if; ++k) {
             const int32_t* bd = A.ib(k);
@@ -488,7 +495,7 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
                 acc += coef * x;
             }
         }
-        const double rhs = comp == 1 ? density * sh.volume : 0.0;
+        const double rhs = comp == 1 ? density * A.volume(b) : 0.0;
         res = fabs(acc - rhs);
     }
     return wave_sum_d(res);
@@ -664,7 +671,7 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
     if (lane < 3) {
         const int i = m_o + lane;
         double rhs = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-        if (lane == 1) rhs += density * A.S(nbn).volume;
+        if (lane == 1) rhs += density * A.volume(nbn);
         T[i * stride + n] = rhs;
         T[i * stride + n + 1 + i] = 1.0;
     }
@@ -682,11 +689,9 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
             const int row = lane < m_o ? lane : m;
             double v = T[row * stride + n_gen];                  // budget coefficient 1 times the slack column
             if (bodyA >= 0) {
-                const bridges_shape& sh = A.S(bodyA);
-                const double* P = A.P(bodyA);
-                double rgx, rgz;
-                rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
-                const double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+                double gcx, gcz;
+                A.centroid(bodyA, gcx, gcz);
+                const double rx = px - gcx, rz = pz - gcz;
                 const double a0 = -gx, a1 = -gz, a2 = rx * a1 - rz * a0;
                 const int c0 = n + 1 + 3 * bodyA;
                 v += a0 * T[row * stride + c0] + a1 * T[row * stride + c0 + 1] + a2 * T[row * stride + c0 + 2];
@@ -694,11 +699,9 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
             T[row * stride + j] = v;
         } else if (lane < m_o + 4) {
             const int cmp = lane - m_o - 1;                      // 0, 1, 2: Fx, Fz, My of the new block
-            const bridges_shape& sh = A.S(nbn);
-            const double* P = A.P(nbn);
-            double rgx, rgz;
-            rot2(sh.gx, sh.gz, P[2], P[3], rgx, rgz);
-            const double rx = px - (P[0] + rgx), rz = pz - (P[1] + rgz);
+            double gcx, gcz;
+            A.centroid(nbn, gcx, gcz);
+            const double rx = px - gcx, rz = pz - gcz;
             T[(m_o + cmp) * stride + j] = cmp == 0 ? gx : (cmp == 1 ? gz : rx * gz - rz * gx);
         }
     }
@@ -717,11 +720,11 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
 // that is either freshly built (warm == false) or continued from the persisted one (prepared by lp_warm_prepare).
 template <bool IN_LDS, typename TP>
 __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu, double density,
-                                    int lane, bool warm, bool* st_frozen, bool* st_free, bool* error) {
+                                    int lane, bool warm, bool* st_frozen, bool* st_free, bool* error, int* pivots) {
     const int m_act = m - 3;
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
     if (!warm) lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane, m);
-    int piv = 0;
+    int& piv = *pivots;
     double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, !warm, feas, m);
     *st_frozen = w <= feas;
     if (*st_frozen && m_act > 0 && lp_verify(T, stride, m, m_act, n, S, A, mu, density, lane) > vtol) {
@@ -751,9 +754,9 @@ __device__ inline void lp_warm_store(const double* T, int stride, int m, int n_g
 // k_step's solve: both stability variants of the assembly A (A.n_blocks blocks, the last one new), continuing from the
 // environment's persisted tableau in `ws` when it matches the state (n_blocks - 1 blocks, n_if_old interfaces), and
 // persisting the result there when `keep`.  *warm_used reports which path produced the verdict.
-__device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
+__device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
                                 const WarmPre& W, double mu, double density, int lane, bool* st_frozen, bool* st_free,
-                                bool* error, bool* warm_used) {
+                                bool* error, bool* warm_used, int* diag = nullptr) {
     WarmHdr* hdr = reinterpret_cast<WarmHdr*>(ws);
     double* halves = ws + WARM_HDR_DOUBLES;
     *warm_used = false;
@@ -777,9 +780,10 @@ __device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpS
     // the persisted tableau continues this state iff it was written for exactly the assembly without the new block
     bool warm = W.ok;
     const int half_o = W.half & 1, stride_o = W.stride;
-    const bool in_lds = cells <= LP_TAB_LDS;
+    const bool in_lds = cells <= lds_cap;
     const int half_n = in_lds ? 0 : 1 - half_o;        // a tableau worked on in global memory alternates halves
     double* Tg = halves + (int64_t)half_n * WARM_HALF;
+    int pivots = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool err = false;
         if (warm) {
@@ -787,8 +791,9 @@ __device__ inline void rbe_both(double* tab_lds, double* ws, int64_t ws_cap, LpS
             if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
             else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
         }
-        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
-        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err);
+        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots);
+        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots);
+        if (diag) *diag = pivots * 4 + (in_lds ? 0 : 2) + attempt;     // pivots, global-memory tableau, second attempt
         if (!(warm && err)) { *error = err; *warm_used = warm; break; }
         warm = false;                                  // the continued tableau failed its check: solve from scratch
         lp_row_map(S, all, lane);

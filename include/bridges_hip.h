@@ -177,6 +177,10 @@ typedef struct bridges_gate bridges_gate;
 int bridges_gate_create(bridges_gate** out);
 int bridges_gate_destroy(bridges_gate* gate);
 int bridges_env_set_gate(bridges_env* env, bridges_gate* gate);
+/* With a gate: launch the rasteriser of a lock-step as a head (head_permille / 1000 of the expected images) and a tail,
+ * and release the gate behind the head, so the next group's rasteriser starts while this one's tail drains.
+ * 0 = one launch (default).  Results do not depend on it. */
+int bridges_env_set_raster_split(bridges_env* env, int32_t head_permille);
 /* Candidate refresh only (used after the host edited the state). */
 int bridges_env_refresh(bridges_env* env, void* stream);
 /* is_action_stable_rbe (assembly_gym/assembly_gym/utils/stability.py:122-130) for EVERY valid candidate of every

@@ -25,8 +25,24 @@ for rep in range(3):
         v = w[:, col] / 100.0
         print(f"    {name:15s} mean {v.mean():6.1f}  p95 {np.percentile(v,95):6.1f}  max {v.max():6.1f} us")
     nb = w[:, 5].astype(int)
+    diag = (w[:, 6] // 100).astype(int)
+    piv, glob, second = diag // 4, (diag & 2) > 0, (diag & 1) > 0
+    w[:, 6] = w[:, 6] % 100
     warm = (w[:, 6] % 1.0) > 0.25
+    print(f"    pivots mean {piv.mean():.2f} max {piv.max()}; tableau in global memory: {glob.sum()} envs; second (cold) attempt: {second.sum()} envs")
+    slow = np.argsort(-w[:, 3])[:8]
+    print("    slowest LPs: " + "; ".join(f"{w[i,3]/100:.0f}us nb={int(w[i,5])} n_if={int(w[i,6])} piv={piv[i]} glob={int(glob[i])} 2nd={int(second[i])} warm={int(warm[i])}" for i in slow))
     print(f"    continued from the persisted tableau: {warm.mean()*100:.1f} % of the envs")
     for k in sorted(set(nb)):
         sel = nb == k
         print(f"    nb={k:2d} n={sel.sum():5d} LP us mean {w[sel,3].mean()/100:6.1f} max {w[sel,3].max()/100:6.1f}  total mean {tot[sel].mean():6.1f}")
+from bridges_hip import abi
+import ctypes as C
+Lb = abi.lib()
+if hasattr(Lb, "bridges_debug_lp_profile"):
+    buf = (C.c_ulonglong * 8)()
+    Lb.bridges_debug_lp_profile(buf, 1)           # reset
+    env.select_random(); env.step(); torch.cuda.synchronize()
+    Lb.bridges_debug_lp_profile(buf, 1)
+    v = list(buf); n = max(v[5], 1)
+    print(f"LP_PROFILE build, one lock-step: cycles per pivot: price {v[0]/n:.0f}  ratio {v[1]/n:.0f}  stage {v[2]/n:.0f}  sweep {v[3]/n:.0f}  (pivots {v[5]})")
