@@ -203,3 +203,127 @@ def test_sigmoid_dot_matches_torch():
     assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5), float((got.double() - want).abs().max())
     view = torch.randn((50, 8192), generator=g).to(dev)[:, 4096:]             # row stride != k
     assert torch.allclose(ops.sigmoid_dot(view, w).double(), (torch.sigmoid(view.double()) * w.double()).sum(dim=1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("loss_fct", ["mse_q_values", "mse_block_features", "mse_q_values+mse_block_features"])
+def test_train_policy_net_reproduces_the_reference_net_fixture(loss_fct, golden_dir):
+    """tests/golden/dqn_fixtures.pt (made by make_dqn_fixtures.py from the REFERENCE's own SuccessorMLP / init_weights
+    and the restatement of train_policy_net): the same hand-built batch, initial weights and Adam through the product's
+    train_policy_net (HIP td-target op) and update_target_net (HIP soft update) -> per-step losses and parameter
+    checksums."""
+    import os
+    import warnings
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.training.successor_dqn import Transition, flatten_nets, train_policy_net, update_target_net
+    warnings.filterwarnings("ignore", message="Using a target size")
+    fx = torch.load(os.path.join(golden_dir, "dqn_fixtures.pt"), weights_only=True)
+    b, case = fx["batch"], fx["cases"][loss_fct]
+    size = tuple(fx["size"])
+    mk = lambda: SuccessorMLP(img_size=size, hidden_dims=fx["hidden"])
+    pol, tgt = mk().to(DEV), mk().to(DEV)
+    pol.load_state_dict(fx["init_state"])
+    tgt.load_state_dict(fx["init_state"])
+    flatten_nets(pol, tgt)
+    opt = torch.optim.Adam(pol.parameters(), lr=fx["lr"])
+    na = [int(x) for x in b["num_actions"]]
+
+    class FixedBatch:                                          # replay buffer that always returns the fixture batch
+        def __len__(self):
+            return 1000
+
+        def sample(self, batch_size=None, stack_tensors=True, device=None):
+            d = lambda t: t.to(device)
+            return None, Transition(
+                block_features=d(b["block"]), binary_features=d(b["binary"]), action=None, action_features=d(b["action"]),
+                reward=None, lin_reward=d(b["lin_reward"]), done=tuple(bool(x) for x in b["done"]),
+                reward_features=d(b["reward"]), obstacle_features=d(b["obstacle"]), next_block_features=d(b["next_block"]),
+                next_binary_features=d(b["next_binary"]), next_available_actions=[[0] * n for n in na],
+                next_actions_features=d(b["next_action"]), next_reward_features=d(b["next_reward"]),
+                next_obstacle_features=d(b["next_obstacle"]), td_error=None)
+
+    losses = train_policy_net(pol, tgt, opt, FixedBatch(), fx["gamma"], loss_fct=loss_fct, n_steps=3, batch_size=len(na), device=DEV)
+    update_target_net(pol, tgt, fx["tau"])
+    np.testing.assert_allclose(losses, case["losses"], rtol=1e-5, atol=1e-6)
+    for k, v in pol.state_dict().items():
+        assert abs(float(v.double().sum()) - case["policy_checksum"][k]) <= 1e-4 * (1.0 + case["policy_abs_checksum"][k]), k
+    for k, v in tgt.state_dict().items():
+        assert abs(float(v.double().sum()) - case["target_checksum"][k]) <= 1e-4 * (1.0 + case["policy_abs_checksum"][k]), k
+
+
+def test_epsilon_greedy_follows_the_reference_rule():
+    """EpsilonGreedy (successor_dqn.py:98-132): exploit = argmax q, explore = argmin of the overlap with the count image
+    of the episode step (first minimum), then the image grows by the chosen raster; epsilon decays per step() call.
+    Same random.random() stream for the product class and the restatement, 40 calls over 4 episode steps."""
+    from robotoddler.training.successor_dqn import EpsilonGreedy
+    g = torch.Generator().manual_seed(5)
+    calls = []
+    for i in range(40):
+        A = int(torch.randint(1, 9, (1,), generator=g))
+        feats = (torch.rand(A, 1, 64, 64, generator=g) > 0.9).float()
+        if i % 7 == 3 and A > 1:
+            feats[1] = feats[0]                                 # a tie: the first minimum must win
+        calls.append((torch.randn(A, generator=g), i % 4, feats))
+    for eps_start in (1.0, 0.6, 0.0):
+        random.seed(11)
+        prod = EpsilonGreedy(eps_start=eps_start, eps_end=0.05 if eps_start else 0.0, gamma=0.9, max_steps=4, device=torch.device(DEV))
+        got = []
+        for k, (q, step, feats) in enumerate(calls):
+            got.append(prod(q.to(DEV), step, feats.to(DEV)))
+            if k % 5 == 4:
+                prod.step()
+        random.seed(11)
+        ref = O.EpsilonGreedyOracle(eps_start=eps_start, eps_end=0.05 if eps_start else 0.0, gamma=0.9, max_steps=4)
+        want = []
+        for k, (q, step, feats) in enumerate(calls):
+            want.append(ref(q, step, feats))
+            if k % 5 == 4:
+                ref.step()
+        assert got == want, eps_start
+        assert prod.epsilon == ref.epsilon
+        for a, bb in zip(prod.step_images, ref.step_images):
+            assert torch.equal(a.cpu(), bb)
+        if eps_start == 1.0:
+            assert sum(float(im.sum()) for im in ref.step_images) > 0          # it did explore
+        if eps_start == 0.0:
+            assert got == [int(torch.argmax(q)) for q, _, _ in calls]
+
+
+def test_log_episode_reports_the_reference_numbers():
+    """log_episode (successor_dqn.py:479-503): discounted reward / lin_reward sums, mean loss, step count, the stable /
+    collision flags of the last next state, epsilon -- on hand-made transitions and on a real greedy rollout."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import AssemblyGym, bridge_setup, sparse_reward
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.training.successor_dqn import EpsilonGreedy, Transition, log_episode, rollout_episode
+    from robotoddler.utils.utils import init_weights
+    blank = dict(block_features=None, binary_features=None, action=None, action_features=None, done=False, reward_features=None,
+                 obstacle_features=None, next_block_features=None, next_available_actions=None, next_actions_features=None,
+                 next_reward_features=None, next_obstacle_features=None, td_error=0)
+    rewards, lins = [-1.0, -1.0, 0.0, 1.0], [0.25, 0.0, 0.0125, 1.5]
+    nb = [torch.tensor([[1., 0, 0, 0, 0, 0]]), torch.tensor([[1., 0, 0, 0, 0, 0]]), torch.tensor([[1., 0, 0, 0, 0, 0]]),
+          torch.tensor([[0., 1, 0, 0, 0, 0], [0., 1, 0, 0, 0, 0]])]
+    trans = [Transition(reward=torch.Tensor([r]), lin_reward=torch.tensor([[l]]), next_binary_features=b, **blank)
+             for r, l, b in zip(rewards, lins, nb)]
+    pol = EpsilonGreedy(eps_start=0.3, device=torch.device("cpu"))
+    info, fig = log_episode(7, trans, [0.5, 0.25, 0.75], 0.8, policy=pol)
+    want = O.log_episode_values(rewards, lins, [0.5, 0.25, 0.75], 0.8, nb[-1][0].tolist(), epsilon=pol.epsilon)
+    assert fig is None and set(info) == set(want)
+    for k in want:
+        assert info[k] == pytest.approx(want[k], rel=1e-6), k
+    assert log_episode(8, trans[:1], None, 0.8)[0]["avg_loss"] is None
+    # a real rollout on the drop-in API
+    torch.manual_seed(0)
+    random.seed(0)
+    net = SuccessorMLP(img_size=(64, 64), hidden_dims=[32, 16, 32]).to(DEV)
+    net.apply(init_weights)
+    env = AssemblyGym(reward_fct=sparse_reward, max_steps=6, restrict_2d=True, assembly_env=AssemblyEnv(render=False))
+    greedy = lambda q, *a, **k: torch.argmax(q)
+    transitions, _ = rollout_episode(env=env, policy=greedy, policy_net=net, setup_fct=lambda: bridge_setup(num_stories=2),
+                                     x_discr_ground=np.linspace(-2, 0, 10), xlim=(-3, 7), ylim=(0., 10), offset_values=[0],
+                                     img_size=(64, 64), device=torch.device(DEV))
+    info, _ = log_episode(1, transitions, [1.0, 3.0], 0.8)
+    want = O.log_episode_values([float(t.reward) for t in transitions], [float(t.lin_reward) for t in transitions], [1.0, 3.0], 0.8,
+                                transitions[-1].next_binary_features[0].tolist())
+    assert info["num_steps"] == len(transitions) >= 1
+    for k in want:
+        assert info[k] == pytest.approx(want[k], rel=1e-5, abs=1e-7), k

@@ -84,3 +84,46 @@ def test_full_size_invariants():
     st = env.read_stats()
     assert st["env_steps"] - st0["env_steps"] + st["reset_only"] - st0["reset_only"] == 20 * E
     assert st["lp_errors"] == 0 and st["if_overflow"] == 0
+
+
+def test_config5_workload_full_size():
+    """BASELINE.json configs[4]'s simulator workload at full size: 4096 envs, hexagon blocks, the bridge-span task
+    (horizontal_bridge_setup), max_steps = 15 -- A_max = 600 candidate slots per env (a 40 GB f32 raster buffer).
+    Determinism across env grouping, count / mask / raster invariants, no LP error or contact overflow, and the fused
+    candidate-stability mask against the unfused operator path on a sample."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym, VecAssemblyGymGroups
+    from gpu_helpers import candidate_stability_unfused
+    sq, n_obs, E = 0.6, 3, 4096
+    args = ([load_urdf("shapes/hexagon.urdf")], [(i * sq, 0.0, sq / 2) for i in range(1, n_obs + 1)], [(n_obs * sq + 2.5 * sq, 0.0, sq / 2)])
+    env = VecAssemblyGym(E, *args, max_steps=15, seed=12, f32_rasters=True)
+    assert env.a_max == 600
+    grouped = VecAssemblyGymGroups(E, *args, groups=2, max_steps=15, seed=12, f32_rasters=False)
+    max_blocks = 0
+    for it in range(30):
+        env.select_random()
+        env.step()
+        grouped.lockstep_random()
+        grouped.sync()
+        fl = env.flags()
+        total = env.total_candidates()
+        assert not bool(fl["lp_error"].any())
+        assert torch.equal(env.step_flags.cpu(), torch.cat([g.step_flags.cpu() for g in grouped.envs]))
+        assert torch.equal(env.n_valid.cpu(), torch.cat([g.n_valid.cpu() for g in grouped.envs]))
+        assert total == int(env.n_cand.sum()) and int(env.n_cand.max()) <= env.a_max
+        assert bool((~fl["stable_unfrozen"] | fl["stable_frozen"])[fl["valid_step"]].all())
+        env_of = env.cand_env[:total].long()
+        overlap = ((env.cand_bits[:total] & (env.state_bits[env_of] | env.obstacle_bits[None, :])) != 0).any(dim=1)
+        assert bool((env.cand_mask[:total].bool() == (env.cand_inb[:total].bool() & ~overlap)).all())
+        k = torch.randint(0, total, (64,), device=env.device)
+        expect = ((env.cand_bits[k][:, :, None] >> torch.arange(64, device=env.device)[None, None, :]) & 1).float()
+        assert torch.equal(env.cand_raster[k], expect)
+        max_blocks = max(max_blocks, int(env.n_blocks.max()))
+        if it % 10 == 9:
+            rows, stable = env.candidate_stability()
+            rows2, stable2, err2 = candidate_stability_unfused(env)
+            assert torch.equal(rows, rows2) and torch.equal(stable, stable2) and not bool(err2.any())
+            assert int((env.cand_stable[rows] == 2).sum()) == 0
+    st = env.read_stats()
+    assert st["lp_errors"] == 0 and st["if_overflow"] == 0 and st["env_steps"] > 25 * E
+    assert max_blocks >= 6

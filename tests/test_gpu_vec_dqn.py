@@ -250,3 +250,54 @@ def test_cpu_device_is_rejected():
     from robotoddler.training.successor_dqn import main
     with pytest.raises(SystemExit):
         main(["--device", "cpu"])
+
+
+def test_vectorised_exploration_follows_the_batched_reading_of_the_reference_rule():
+    """VecDQN.act with every env exploring (epsilon = 1): each env takes the valid candidate whose raster overlaps
+    least with the count image of its episode step AS IT WAS AT THE START of the lock-step (first minimum, in candidate
+    order), and the chosen rasters are added to the images afterwards -- successor_dqn.py:116-129 applied env by env
+    (oracle.dqn.vectorised_explore).  With epsilon = 0 every env takes its arg-max q candidate and the images stay."""
+    from oracle import dqn as O
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev = torch.device("cuda")
+    for f32 in (False, True):                               # bit-packed acting path and the f32-raster path
+        env = make_env(64, seed=21, tower=2, max_steps=10)
+        if f32:
+            import os
+            os.environ["BRIDGES_FACTORED_ACT"] = "0"
+        try:
+            torch.manual_seed(6)
+            pol, tgt = make_nets(args, dev)
+            opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+            agent = VecDQN(pol, tgt, opt, env, 4096, 8, 0.9, 0.01, "mse_q_values", seed=2, eps_start=1.0, eps_end=1.0)
+            n_checked = 0
+            for it in range(6):
+                E = env.E
+                idx, row_env = env.valid_rows()
+                off = env.cand_offset[:E].cpu().numpy()
+                step_of_env = env.n_blocks.cpu().tolist()
+                dense = ((env.cand_bits[idx].cpu().numpy().astype(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1))
+                dense = torch.tensor(dense.astype(np.float32))
+                rows_of_env = [torch.nonzero(row_env.cpu() == e).squeeze(1) for e in range(E)]
+                rasters = [dense[r] for r in rows_of_env]
+                images_before = agent.step_images.cpu().clone()
+                agent.epsilon = 1.0 if it < 4 else 0.0
+                explore = [agent.epsilon == 1.0] * E
+                sel, images_after = O.vectorised_explore(images_before, step_of_env, rasters, explore)
+                q_all = agent._policy_q(env, idx, row_env, agent._stable_flags(env)).cpu() if it >= 4 else None
+                agent.act()
+                chosen = env.sel_index.cpu().numpy()
+                for e in range(E):
+                    if len(rows_of_env[e]) == 0:
+                        continue
+                    want_row = sel[e] if sel[e] is not None else int(torch.argmax(q_all[rows_of_env[e]]))
+                    assert chosen[e] == int(idx[rows_of_env[e][want_row]]) - off[e], (f32, it, e)
+                    n_checked += 1
+                assert torch.equal(agent.step_images.cpu(), images_after), (f32, it)
+            assert n_checked > 250
+        finally:
+            if f32:
+                import os
+                os.environ.pop("BRIDGES_FACTORED_ACT", None)
