@@ -375,8 +375,6 @@ def main(argv=None):
         random.seed(args['seed'])
         np.random.seed(args['seed'])
         torch.manual_seed(args['seed'])
-    if args['load_checkpoint']:
-        raise NotImplementedError("Loading checkpoints is not tested.")     # successor_dqn.py:655
     aim_run = wandb_run = None
     if args['aim']:                                                         # successor_dqn.py:671-674
         try:
@@ -410,10 +408,19 @@ def main(argv=None):
     env = AssemblyGym(reward_fct=sparse_reward, max_steps=args['max_steps'], restrict_2d=True,
                       assembly_env=AssemblyEnv(render=False))
     optimizer = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'])
+    first_episode = 1
+    if args['load_checkpoint']:                          # successor_dqn.py:654-665 (disabled there: "not tested")
+        from robotoddler.utils.utils import load_checkpoint, optimizer_to
+        meta = load_checkpoint(args['load_checkpoint'], policy_net, target_net, replay_buffer, optimizer,
+                               devices=dict(policy_net=device, target_net=device, optimizer=device))
+        optimizer_to(optimizer, device)
+        first_episode = int(meta['episode']) + 1
+        eps_greedy = EpsilonGreedy(eps_start=0.5, gamma=0.999, eps_end=0.05, episode=int(meta['episode']),
+                                   max_steps=args['max_steps'], device=device)
     history = []
     roll = dict(env=env, policy_net=policy_net, setup_fct=setup_fct, x_discr_ground=x_discr_ground, xlim=xlim, ylim=ylim,
                 offset_values=offset_values, img_size=args['image_size'], device=device, log_images=False)
-    for i in range(1, args['num_episodes'] + 1):
+    for i in range(first_episode, args['num_episodes'] + 1):
         transitions, images = rollout_episode(policy=eps_greedy.step(), **roll)
         replay_buffer.push(transitions)
         losses = train_policy_net(policy_net=policy_net, target_net=target_net, optimizer=optimizer,

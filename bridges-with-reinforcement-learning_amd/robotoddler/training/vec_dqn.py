@@ -372,6 +372,20 @@ class VecDQN:
         from robotoddler.training.successor_dqn import update_target_net
         update_target_net(self.policy_net, self.target_net, self.tau)
 
+    # ------------------------------------------------------------------ checkpoint of what the nets / ring do not hold
+    def save_extra(self, path, **counters):
+        torch.save(dict(epsilon=float(self.epsilon), episodes_done=int(self.episodes_done), env_steps=int(self.env_steps),
+                        step_images=self.step_images.cpu(), sample_gen=self.sample_gen.get_state().cpu(),
+                        explore_gen=self.explore_gen.get_state().cpu(), counters={k: int(v) for k, v in counters.items()}), path)
+
+    def load_extra(self, path):
+        blob = torch.load(path, weights_only=True)
+        self.epsilon, self.episodes_done, self.env_steps = blob["epsilon"], blob["episodes_done"], blob["env_steps"]
+        self.step_images.copy_(blob["step_images"])
+        self.sample_gen.set_state(blob["sample_gen"])
+        self.explore_gen.set_state(blob["explore_gen"])
+        return blob["counters"]
+
     # ------------------------------------------------------------------ driver
     def lockstep(self, n_train_steps):
         rec, valid = self.act()
@@ -413,14 +427,27 @@ def run_vectorised(args, device):
                    args['loss_function'], seed=seed, rank=rank, prioritized=args.get('prioritized_replay', False))
     history, t0, it = [], time.time(), 0
     next_ckpt = args['checkpoint_every']
+    if args.get('load_checkpoint'):                      # successor_dqn.py:654-665 + utils.py:31-50 of the reference
+        from robotoddler.utils.utils import load_checkpoint
+        path = args['load_checkpoint']
+        load_checkpoint(path, policy_net, target_net, agent.ring, opt,
+                        devices=dict(policy_net=device, target_net=device, optimizer=device))
+        it = agent.load_extra(os.path.join(path, 'agent.pt'))['lockstep']
+        next_ckpt = (agent.episodes_done // args['checkpoint_every'] + 1) * args['checkpoint_every']
+        env.reset()                                      # a checkpoint is taken with all environments freshly reset
     while agent.episodes_done < args['num_episodes']:
         losses, rec = agent.lockstep(args['num_training_steps'])
         it += 1
-        if args.get('save_checkpoint') and rank == 0 and agent.episodes_done >= next_ckpt:     # utils.py:54-89 layout
-            from robotoddler.utils.utils import save_checkpoint
-            save_checkpoint(args['save_checkpoint'], policy_net, target_net, agent.ring, opt, agent.episodes_done,
-                            {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in args.items()})
+        if args.get('save_checkpoint') and agent.episodes_done >= next_ckpt:                  # utils.py:54-89 layout
+            if rank == 0:
+                from robotoddler.utils.utils import save_checkpoint
+                save_checkpoint(args['save_checkpoint'], policy_net, target_net, agent.ring, opt, agent.episodes_done,
+                                {k: (v if isinstance(v, (int, float, str, bool, type(None))) else str(v)) for k, v in args.items()})
+                agent.save_extra(os.path.join(args['save_checkpoint'], str(agent.episodes_done), 'agent.pt'), lockstep=it)
             next_ckpt = (agent.episodes_done // args['checkpoint_every'] + 1) * args['checkpoint_every']
+            # the single-env reference checkpoints between episodes; the lock-step analogue: every rank starts all its
+            # environments afresh, so that a resumed run (fresh environments) continues exactly like this one
+            env.reset()
         if it % 100 == 0:
             D.broadcast_module(policy_net)
             D.broadcast_module(target_net)

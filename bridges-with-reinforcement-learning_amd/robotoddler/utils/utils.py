@@ -54,9 +54,10 @@ def load_checkpoint(path, policy_net, target_net, replay_buffer, optimizer, devi
     with open(os.path.join(path, 'meta.json')) as f:
         meta = json.load(f)
     devices = devices or dict()
-    policy_net.load_state_dict(torch.load(os.path.join(path, 'policy_net.pt'), map_location=devices.get('policy_net')))
-    target_net.load_state_dict(torch.load(os.path.join(path, 'target_net.pt'), map_location=devices.get('target_net')))
-    optimizer.load_state_dict(torch.load(os.path.join(path, 'optimizer.pt'), map_location=devices.get('optimizer')))
+    ld = lambda stem: torch.load(os.path.join(path, stem + '.pt'), map_location=devices.get(stem), weights_only=True)
+    policy_net.load_state_dict(ld('policy_net'))
+    target_net.load_state_dict(ld('target_net'))
+    optimizer.load_state_dict(ld('optimizer'))
     replay_buffer.load(os.path.join(path, 'replay_buffer.pt'))
     return meta
 

@@ -225,3 +225,42 @@ def test_checkpoint_layout_matches_the_reference(tmp_path):
     with pytest.raises(FileNotFoundError):
         load_checkpoint(str(tmp_path / "nope"), pol2, tgt2, rb, opt)
 
+
+
+def test_replay_buffer_checkpoint_is_plain_tensors_and_round_trips(tmp_path):
+    """ReplayBuffer.save / load (replay_memory.py:33-43 of the reference pickles the deque): here the file holds tensors
+    and plain containers only and is read back with torch.load(weights_only=True); a pickled deque is refused."""
+    from assembly_gym.envs.gym_env import Action
+    from robotoddler.training.successor_dqn import Transition
+    from robotoddler.utils.replay_memory import PrioritizedReplayBuffer, ReplayBuffer
+    acts = [Action(target_block=-1, target_face=0, shape=0, face=3, offset_x=-1.5), Action(0, 1, 0, 3, 0.0)]
+
+    def tr(i):
+        img = torch.full((1, 1, 4, 4), float(i))
+        return Transition(block_features=img, binary_features=torch.zeros(1, 6), action=acts[i % 2], action_features=img,
+                          reward=torch.Tensor([i]), lin_reward=torch.tensor([[0.5 * i]]), done=bool(i % 2), reward_features=img,
+                          obstacle_features=img, next_block_features=img.expand(2, -1, -1, -1), next_binary_features=torch.zeros(2, 6),
+                          next_available_actions=list(acts), next_actions_features=img.expand(2, -1, -1, -1),
+                          next_reward_features=img.expand(2, -1, -1, -1), next_obstacle_features=img.expand(2, -1, -1, -1),
+                          td_error=0.25 * i)
+    rb = ReplayBuffer(capacity=5)
+    rb.push([tr(i) for i in range(7)])                       # maxlen drops the two oldest
+    rb.save(str(tmp_path / "rb.pt"))
+    blob = torch.load(str(tmp_path / "rb.pt"), weights_only=True)       # nothing but tensors / containers inside
+    assert blob["format"] == 2 and len(blob["items"]) == 5
+    rb2 = ReplayBuffer(capacity=1)
+    rb2.load(str(tmp_path / "rb.pt"))
+    assert len(rb2) == 5 and rb2.memory.maxlen == 5
+    for a, b in zip(rb.memory, rb2.memory):
+        assert a.action == b.action and a.next_available_actions == b.next_available_actions and a.done == b.done
+        assert torch.equal(a.block_features, b.block_features) and torch.equal(a.lin_reward, b.lin_reward) and a.td_error == b.td_error
+    prb = PrioritizedReplayBuffer(capacity=4)
+    prb.push([tr(i) for i in range(3)])
+    prb.save(str(tmp_path / "prb.pt"))
+    prb2 = PrioritizedReplayBuffer(capacity=4)
+    prb2.load(str(tmp_path / "prb.pt"))
+    assert list(prb2.priorities) == list(prb.priorities) and len(prb2) == 3
+    import collections
+    torch.save(collections.deque([1, 2]), str(tmp_path / "legacy.pt"))
+    with pytest.raises(Exception):
+        ReplayBuffer().load(str(tmp_path / "legacy.pt"))

@@ -231,7 +231,8 @@ def test_vectorised_loop_writes_reference_layout_checkpoints(tmp_path):
           "--num_episodes", "120", "--num_training_steps", "1", "--batch_size", "8", "--seed", "0", "--learning_rate", "1e-4",
           "--save_checkpoint", str(tmp_path), "--checkpoint_every", "50"])
     latest = os.path.realpath(tmp_path / "latest")
-    assert sorted(os.listdir(latest)) == ["meta.json", "optimizer.pt", "policy_net.pt", "replay_buffer.pt", "target_net.pt"]
+    # the reference's five files (utils.py:54-89) + agent.pt: what the vectorised loop needs on top to resume exactly
+    assert sorted(os.listdir(latest)) == ["agent.pt", "meta.json", "optimizer.pt", "policy_net.pt", "replay_buffer.pt", "target_net.pt"]
     assert json.load(open(os.path.join(latest, "meta.json")))["episode"] >= 50
     blob = torch.load(os.path.join(latest, "replay_buffer.pt"), weights_only=True)
     assert blob["records"].shape[0] > 0
@@ -301,3 +302,30 @@ def test_vectorised_exploration_follows_the_batched_reading_of_the_reference_rul
             if f32:
                 import os
                 os.environ.pop("BRIDGES_FACTORED_ACT", None)
+
+
+def test_load_checkpoint_resumes_the_vectorised_loop(tmp_path):
+    """--save_checkpoint / --load_checkpoint (utils.py:31-89, successor_dqn.py:654-665 of the reference): a run that is
+    checkpointed after ~150 episodes and a second main() call that resumes from that directory produce the same losses
+    for the lock-steps that follow (nets, optimiser, replay ring, epsilon, count images, RNG streams and counters are
+    restored; a checkpoint is taken with all environments freshly reset)."""
+    import os
+    from robotoddler.training.successor_dqn import main
+    common = ["--model", "SuccessorMLP", "--loss_function", "mse_q_values+mse_block_features", "--tower_height", "2", "--num_envs", "64",
+              "--num_training_steps", "2", "--batch_size", "16", "--seed", "3", "--learning_rate", "1e-4", "--checkpoint_every", "150"]
+    a = main([*common, "--num_episodes", "290", "--save_checkpoint", str(tmp_path)])
+    ckpts = sorted(int(d) for d in os.listdir(tmp_path) if d.isdigit())
+    assert ckpts and ckpts[0] < 290
+    first = os.path.join(str(tmp_path), str(ckpts[0]))
+    assert sorted(os.listdir(first)) == ["agent.pt", "meta.json", "optimizer.pt", "policy_net.pt", "replay_buffer.pt", "target_net.pt"]
+    b = main([*common, "--num_episodes", "290", "--load_checkpoint", first])
+    by_step = {h["lockstep"]: h for h in a}
+    assert b[0]["lockstep"] == min(k for k, h in by_step.items() if h["episodes"] >= ckpts[0]) + 1
+    n = 0
+    for h in b[:20]:
+        ref = by_step[h["lockstep"]]
+        assert h["episodes"] == ref["episodes"] and h["env_steps"] == ref["env_steps"]
+        assert h["epsilon"] == ref["epsilon"]
+        assert h["avg_loss"] == pytest.approx(ref["avg_loss"], rel=1e-4), h["lockstep"]
+        n += 1
+    assert n >= 10
