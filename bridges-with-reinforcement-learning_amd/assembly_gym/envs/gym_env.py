@@ -108,9 +108,17 @@ class AssemblyGym:
         return [min(distance_box_point(b.bounding_box, t) for b in self.assembly_env.blocks) for t in self.targets]
 
     def _update_targets(self, new_block):
-        still_open = []
-        for t in self.targets_remaining:           # a target counts as reached once a block's bounding box holds it
-            (self.targets_reached if new_block.bounding_box.contains_point(t) else still_open).append(t)
+        # A target counts as reached once a block's bounding box holds it.  The reference removes from the list it is
+        # iterating over (gym_env.py:164-168), which makes CPython skip the open target that follows a reached one (it
+        # stays open for later blocks); kept, because reward and termination depend on it.
+        still_open, skip = [], False
+        for t in self.targets_remaining:
+            if not skip and new_block.bounding_box.contains_point(t):
+                self.targets_reached.append(t)
+                skip = True
+            else:
+                still_open.append(t)
+                skip = False
         self.targets_remaining = still_open
 
     def all_targets_reached(self):

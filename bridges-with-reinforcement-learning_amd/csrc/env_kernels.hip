@@ -195,11 +195,16 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     {
         double cx = (x0 + x1) * 0.5, cz = (z0 + z1) * 0.5, hx = (x1 - x0) * 0.5, hz = (z1 - z0) * 0.5;
         double hy = shn.depth * 0.5;
+        // the reference removes from targets_remaining while iterating over it (gym_env.py:164-168): CPython's list
+        // iterator then skips the element that moves into the freed slot, so the open target after a reached one is not
+        // tested for this block.  Reproduced literally (oracle/env.py does the same).
+        bool skip = false;
         for (int t = 0; t < c.n_targets; ++t) {
             if (!((left >> t) & 1u)) continue;
+            if (skip) { skip = false; continue; }
             bool in = fabs(c.targets[t][0] - cx) < hx + 1e-6 && fabs(c.targets[t][1]) < hy + 1e-6 &&
                       fabs(c.targets[t][2] - cz) < hz + 1e-6;
-            if (in) left &= ~(1u << t);
+            if (in) { left &= ~(1u << t); skip = true; }
         }
     }
     const int n_reached = c.n_targets - __popc(left);

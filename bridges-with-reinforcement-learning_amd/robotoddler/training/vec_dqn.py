@@ -9,7 +9,13 @@ Semantics follow rollout_episode / train_policy_net / update_target_net of the r
   start and the chosen rasters added afterwards;
 * the TD target is the elementwise  lin_reward + gamma * q'  (the single-env reference path trains on a [B,B]
   broadcast of it because its lin_reward is [B,1]; that quirk is reproduced only in the single-env loop);
-* "done" of a transition = terminated | truncated | no next action (successor_dqn.py:393, 409-411).
+* "done" of a transition = terminated | truncated | no next action (successor_dqn.py:393, 409-411);
+* epsilon decays once per LOCK-STEP (the reference: once per episode, successor_dqn.py:702 -- with thousands of envs
+  hundreds of episodes end per lock-step and a per-episode decay would reach the floor within a dozen lock-steps);
+* uniform replay draws WITH replacement (torch.randint on the device ring; the reference's random.sample draws without:
+  a duplicate inside a batch of 32 out of >= 10^4 records has probability ~5e-2 and only repeats a sample);
+* with several ranks every rank trains an identical replica on the identical gathered ring (same sampling seed); extra
+  GPUs add rollout throughput, not optimiser throughput; parameters are re-broadcast every 100 lock-steps.
 
 How a lock-step is spent: acting through the factored SuccessorMLP forward whose first layer reads
 the bit-packed rasters (bridges_bits_linear); the TD / successor-feature targets of ALL optimiser steps of the lock-step
@@ -349,7 +355,15 @@ class VecDQN:
             st["losses"].zero_()
             for _ in range(n_steps):
                 st["graph"].replay()
-            return st["losses"][:n_steps].tolist()
+            losses = st["losses"][:n_steps].tolist()            # the one host sync of the call
+            # Guard for the anomaly recorded in DESIGN.md: a multi-workgroup reduction inside a replayed graph once
+            # returned garbage (a negative "MSE"; ROCm 7.2 + torch 2.10, cause not established).  The graph holds only
+            # single-workgroup reductions since, and every replay's loss is checked here: a sum of squares that is
+            # negative or not finite means a kernel in the graph misbehaved -- from then on the step runs eagerly.
+            if not all(np.isfinite(l) and l >= 0.0 for l in losses):
+                warnings.warn(f"train-step graph produced an invalid loss {losses}; switching to the eager step")
+                self._graph_state, self._eager_calls = None, -(1 << 30)
+            return losses
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
         self.policy_net.train()

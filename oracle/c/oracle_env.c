@@ -496,10 +496,15 @@ void orc_lockstep(orc_env* e, uint64_t seed, int32_t env_id, orc_out* out) {
             z0 = fmin(z0, cd->verts[i][1]); z1 = fmax(z1, cd->verts[i][1]);
         }
         double cx = (x0 + x1) * 0.5, cz = (z0 + z1) * 0.5, hx = (x1 - x0) * 0.5, hz = (z1 - z0) * 0.5, hy = sh->depth * 0.5;
-        for (int t = 0; t < c->n_targets; ++t)
-            if (((e->targets_left >> t) & 1u) && fabs(c->targets[t][0] - cx) < hx + 1e-6 && fabs(c->targets[t][1]) < hy + 1e-6 &&
-                fabs(c->targets[t][2] - cz) < hz + 1e-6)
+        /* gym_env.py:163-169 removes from the list it iterates over: the open target after each reached one is skipped */
+        for (int t = 0, skip = 0; t < c->n_targets; ++t) {
+            if (!((e->targets_left >> t) & 1u)) continue;
+            if (skip) { skip = 0; continue; }
+            if (fabs(c->targets[t][0] - cx) < hx + 1e-6 && fabs(c->targets[t][1]) < hy + 1e-6 && fabs(c->targets[t][2] - cz) < hz + 1e-6) {
                 e->targets_left &= ~(1u << t);
+                skip = 1;
+            }
+        }
         int n_reached = c->n_targets - __builtin_popcount(e->targets_left);
         append_interfaces(e, nb);
         int sf, su;

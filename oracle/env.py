@@ -119,8 +119,10 @@ class OracleGym:
         if honour_frozen_flag:      # the recorded golden table predates the forced freeze (:238)
             freeze = bool(action[6]) if len(action) > 6 else False
         self.frozen = nb if freeze else None
-        # gym_env.py:163-169
-        for t in list(self.targets_remaining):
+        # gym_env.py:163-169 removes from targets_remaining WHILE iterating over it: CPython's list iterator then skips
+        # the element that moves into the freed position, i.e. the open target after each reached one is not tested for
+        # this block (it can still be reached by a later block).  Reproduced literally.
+        for t in self.targets_remaining:
             if new_block.aabb_contains(t):
                 self.targets_reached.append(t)
                 self.targets_remaining.remove(t)

@@ -162,6 +162,19 @@ def test_hexagon_bridge_lockstep_parity():
     run_lockstep_parity(vec, oracles, seed, n_lock=16)
 
 
+def test_several_targets_in_one_bounding_box_parity():
+    """Three targets that one block's bounding box can hold at once + a far one: the reference's remove-while-iterating
+    bookkeeping (gym_env.py:163-169) skips the target after a reached one; k_step and the oracle agree step by step."""
+    from oracle.shapes import get_shape
+
+    def setup():
+        return dict(shapes=[get_shape("trapezoid")], obstacles=[], targets=[(-1.0, 0, 0.4), (-0.9, 0, 0.4), (-0.8, 0, 0.4), (5.0, 0, 5.0)])
+    E, seed = 32, 8
+    vec, oracles = make_pair({}, setup, E, 10, seed, ["trapezoid"])
+    run_lockstep_parity(vec, oracles, seed, n_lock=14)
+    assert int(vec.n_reached.max()) >= 1
+
+
 def test_task_features_match_oracle():
     vec, oracles = make_pair(dict(num_stories=4), bridge_setup, 4, 15, 0, ["trapezoid"])
     g = oracles[0].gym

@@ -132,3 +132,33 @@ def test_stability_booleans_do_not_depend_on_the_density(density):
                 assert (bool(b.stable_frozen), bool(b.stable_unfrozen)) == (ref["stable_frozen"], ref["stable_unfrozen"])
                 n += 1
     assert n > 60
+
+
+def test_target_bookkeeping_skips_the_target_after_a_reached_one():
+    """gym_env.py:163-169 removes from targets_remaining while iterating over it, so with three targets inside one
+    block's bounding box only the first and the third count for that block (reward 1, episode goes on); the second is
+    reached by a later block.  Both oracles reproduce it."""
+    from oracle.shapes import get_shape
+    targets = [(-1.0, 0, 0.4), (-0.9, 0, 0.4), (-0.8, 0, 0.4), (5.0, 0, 5.0)]
+    gym = OracleGym(shapes=[get_shape("trapezoid")], obstacles=[], targets=targets, max_steps=10)
+    gym.reset()
+    acts = gym.generate_actions()
+    a = next(x for x in acts if x[0] == -1 and x[3] == 3 and abs(x[4] + 0.8888888888888888) < 1e-9)   # flat on the floor near x = -0.9
+    stable, reward, term, trunc = gym.step(a)
+    assert stable and [t[0] for t in gym.targets_reached] == [-1.0, -0.8] and [t[0] for t in gym.targets_remaining] == [-0.9, 5.0]
+    assert reward == 1 and not term
+    ce = CEnv(OracleGym(shapes=[get_shape("trapezoid")], obstacles=[], targets=targets, max_steps=10))
+    L = OracleLockstep(OracleGym(shapes=[get_shape("trapezoid")], obstacles=[], targets=targets, max_steps=10))
+    ctr = [0]
+
+    def pick(nv):
+        r = policy_draw(4, 0, ctr[0]) % nv
+        ctr[0] += 1
+        return r
+    seen = 0
+    for it in range(40):
+        o, ref = ce.lockstep(4, 0), L.lockstep(pick)
+        if ref["valid_step"]:
+            assert (o.n_reached, o.reward, bool(o.terminated)) == (ref["targets_reached"], ref["reward"], ref["terminated"])
+            seen = max(seen, o.n_reached)
+    assert seen >= 2
