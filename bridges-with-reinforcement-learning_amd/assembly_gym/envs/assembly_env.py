@@ -171,12 +171,15 @@ class AssemblyEnv:
         self.client = None
         if stability == "rbe":
             self.stability_fct = is_stable_rbe
+        elif stability == "rbe_penalty":                  # assembly_env.py:180-181 of the reference
+            from assembly_gym.utils.stability import is_stable_rbe_penalty
+            self.stability_fct = is_stable_rbe_penalty
         elif stability is None:
             self.stability_fct = lambda x: (None, None)
         elif callable(stability):
             self.stability_fct = stability
         else:
-            raise NotImplementedError(f"stability='{stability}' is not part of the path (only 'rbe')")
+            raise NotImplementedError(f"stability='{stability}' is not built (only 'rbe' and 'rbe_penalty'; see assembly_gym/utils/stability.py)")
         self.cra_env = cra_env
         self.reset()
 

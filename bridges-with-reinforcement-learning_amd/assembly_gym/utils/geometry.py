@@ -26,3 +26,16 @@ def distance_box_point(box, point):
         return 0.
     q = project_point_on_box(box, point)
     return math.sqrt(sum((a - b) ** 2 for a, b in zip(point, q)))
+
+
+def maximum_tension(forces):
+    """geometry.py:132-143 of the reference: the largest net tension c_nn - c_np over all contact points (0 if none
+    pulls).  ``forces``: [n_interfaces, points, >= 2] rows of (c_np, c_nn, ...) as ops.stability(..., tension_tol=)
+    returns them (the reference walks the interfaces of a solved CRA assembly, which this build does not model)."""
+    worst = 0.0
+    for interface in forces:
+        for point in interface:
+            tension = float(point[0]) - float(point[1])
+            if tension < 0:
+                worst = max(worst, -tension)
+    return worst

@@ -1,8 +1,8 @@
 """Regression harness over the known-answer structures (the reference's assembly_gym/utils/test_suite.py): every
 structure x build step x stability method -> ``<output_path>/<md5 of the structure>/structure.json`` with the same
-keys (``structure``, ``methods``, ``tests``; entries addressed by md5 hashes of their parameters).  Only the RBE method
-exists in this build (pybullet and the CRA / penalty solvers are out of scope), and no plots are
-written.
+keys (``structure``, ``methods``, ``tests``; entries addressed by md5 hashes of their parameters).  Methods: ``rbe`` and
+``rbe_penalty`` (test_suite.py:32-38 of the reference also lists pybullet, cra and cra_penalty, which this build does not
+have); no plots are written.
     python -m assembly_gym.utils.test_suite --output_path out/ --mu 0.8"""
 import argparse
 import hashlib
@@ -11,14 +11,14 @@ import os
 import time
 
 from assembly_gym.utils import structures
-from assembly_gym.utils.stability import is_stable_rbe
+from assembly_gym.utils.stability import is_stable_rbe, is_stable_rbe_penalty
 
 STRUCTURES = [("hexagon_bridge_3", dict(freeze_last=True)), ("hexagon_bridge_5", dict(freeze_last=True)),
               ("trapezoid_bridge", dict(freeze_last=True)), ("trapezoid_bridge", dict(freeze_last=False)),
               ("horizontal_bridge", dict(freeze_last=False)), ("horizontal_bridge", dict(freeze_last=True)),
               ("hexagon", dict()), ("tower", dict(num_blocks=10)),
               ("levitating_block", dict()), ("levitating_block", dict(freeze_last=True))]
-METHODS = [("rbe", is_stable_rbe, dict())]
+METHODS = [("rbe", is_stable_rbe, dict()), ("rbe_penalty", is_stable_rbe_penalty, dict(tol=1e-3))]
 
 
 def compute_hash(**kwargs):

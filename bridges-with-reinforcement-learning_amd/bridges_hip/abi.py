@@ -174,6 +174,7 @@ def lib():
         "bridges_bits_linear": [i32, vp, vp, vp, i32, vp, vp, vp, vp],
         "bridges_sigmoid_dot": [i32, vp, i64, vp, i32, vp, vp],
         "bridges_stability": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp, vp, vp, i64, vp],
+        "bridges_stability_penalty": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, vp, vp, vp, vp, i64, vp],
         "bridges_soft_update": [vp, vp, i64, f32, f32, vp],
         "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
     }
@@ -191,7 +192,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate", "bridges_env_set_raster_split",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target",
 )
 

@@ -155,8 +155,11 @@ def sigmoid_dot(d, w):
     return out
 
 
-def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
-    """is_stable_rbe (stability.py:49-71) of ONE assembly.  Returns (stable: bool, info: dict)."""
+def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension_tol=None):
+    """is_stable_rbe (stability.py:49-71) of ONE assembly.  Returns (stable: bool, info: dict).
+    With ``tension_tol`` the penalty variant (is_stable_rbe_penalty, stability.py:75-88): contact points may pull, stable
+    iff an equilibrium with total tension <= tension_tol exists; info['forces'] then holds that equilibrium's contact
+    forces [n_interfaces, 2, 3] = (compression, tension, tangential) per contact point."""
     L = abi.require_gpu()
     dev = device()
     K = abi.MAX_BLOCKS
@@ -184,13 +187,24 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth):
     # keep every argument tensor alive until the call returned (a temporary's storage would be recycled at once)
     a_pose, a_verts, a_ids = t(pose, torch.float64), t(verts, torch.float64), t(ids, torch.int32)
     a_n, a_mask = t([n], torch.int32), t([mask], torch.int32)
-    abi.check(L.bridges_stability(tab, 1, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
-                                  float(mu), float(density), float(floor_half_width), float(floor_depth),
-                                  _ptr(stable), _ptr(info), _ptr(ws), ws_stride, _stream()), "bridges_stability")
+    forces = None
+    if tension_tol is None:
+        abi.check(L.bridges_stability(tab, 1, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
+                                      float(mu), float(density), float(floor_half_width), float(floor_depth),
+                                      _ptr(stable), _ptr(info), _ptr(ws), ws_stride, _stream()), "bridges_stability")
+    else:
+        forces = torch.zeros((1, abi.MAX_INTERFACES, 2, 3), dtype=torch.float64, device=dev)
+        abi.check(L.bridges_stability_penalty(tab, 1, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
+                                              float(mu), float(density), float(floor_half_width), float(floor_depth),
+                                              float(tension_tol), _ptr(stable), _ptr(info), _ptr(forces), _ptr(ws), ws_stride,
+                                              _stream()), "bridges_stability_penalty")
     inf = info[0].cpu().numpy()
     if inf[3] != 0:
         return None, dict(error="lp", objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
-    return bool(stable.item()), dict(objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
+    out = dict(objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
+    if forces is not None:
+        out["forces"] = forces[0, :int(inf[1])].cpu().numpy()
+    return bool(stable.item()), out
 
 
 def create_block(target_block, target_face, geom, face, ox, oy):

@@ -407,19 +407,38 @@ int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* strea
     return BRIDGES_OK;
 }
 
-int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose, const double* verts,
-                      const int32_t* shape_id, const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
-                      double density, double floor_half_width, double floor_depth, uint8_t* stable, double* info,
-                      double* lp_ws, int64_t lp_ws_stride, void* stream) {
+static int stability_launch(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose, const double* verts,
+                            const int32_t* shape_id, const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
+                            double density, double floor_half_width, double floor_depth, uint8_t* stable, double* info,
+                            double* lp_ws, int64_t lp_ws_stride, double tension_tol, double* forces, void* stream) {
     if (n < 0 || !shapes_dev) return fail_arg("bridges_stability");
     if (K <= 0 || K > BRIDGES_MAX_BLOCKS) return fail_arg("K > BRIDGES_MAX_BLOCKS");
     if (lp_ws_stride < 9 * BRIDGES_MAX_INTERFACES + (int64_t)(3 * K + 2) * (4 * BRIDGES_MAX_INTERFACES + 3))
         return fail_arg("lp_ws_stride");
     if (n == 0) return BRIDGES_OK;
     hipLaunchKernelGGL(k_stability, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, shapes_dev, n, K, pose, verts, shape_id,
-                       n_blocks, fixed_mask, mu, density, floor_half_width, floor_depth, stable, info, lp_ws, lp_ws_stride);
+                       n_blocks, fixed_mask, mu, density, floor_half_width, floor_depth, stable, info, lp_ws, lp_ws_stride,
+                       tension_tol, forces);
     LAUNCH_CHECK("k_stability");
     return BRIDGES_OK;
+}
+
+int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose, const double* verts,
+                      const int32_t* shape_id, const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
+                      double density, double floor_half_width, double floor_depth, uint8_t* stable, double* info,
+                      double* lp_ws, int64_t lp_ws_stride, void* stream) {
+    return stability_launch(shapes_dev, n, K, pose, verts, shape_id, n_blocks, fixed_mask, mu, density, floor_half_width,
+                            floor_depth, stable, info, lp_ws, lp_ws_stride, 0.0, nullptr, stream);
+}
+
+int bridges_stability_penalty(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose, const double* verts,
+                              const int32_t* shape_id, const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
+                              double density, double floor_half_width, double floor_depth, double tension_tol,
+                              uint8_t* stable, double* info, double* forces, double* lp_ws, int64_t lp_ws_stride,
+                              void* stream) {
+    if (!(tension_tol >= 0.0)) return fail_arg("tension_tol");
+    return stability_launch(shapes_dev, n, K, pose, verts, shape_id, n_blocks, fixed_mask, mu, density, floor_half_width,
+                            floor_depth, stable, info, lp_ws, lp_ws_stride, tension_tol, forces, stream);
 }
 
 #ifdef LP_PROFILE

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     if (!(c.debug & 1)) {
         AsmView A;                                  // centroids / volumes / contacts from LDS; the block arrays are gone
         A.pose = nullptr; A.shape_id = nullptr; A.shapes = nullptr; A.n_blocks = nb + 1;
-        A.cand_b = -1; A.cand_pose = nullptr; A.cand_shape = 0; A.cen = Lk.cen; A.vol = Lk.vol;
+        A.cand_b = -1; A.cand_pose = nullptr; A.cand_shape = 0; A.cen = Lk.cen; A.vol = Lk.vol; A.n_tens = 0; A.tens_coef = 1.0;
         A.n_if = n_if; A.n_if0 = n_if < STEP_IF_LDS ? n_if : STEP_IF_LDS;
         A.if_body0 = Lk.if_body; A.if_geom0 = Lk.if_geom;
         A.if_body1 = if_body_g + 2 * STEP_IF_LDS; A.if_geom1 = if_geom_g + 8 * STEP_IF_LDS;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
         } else {
             AsmView A;
             A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
-            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh; A.cen = nullptr; A.vol = nullptr;
+            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh; A.cen = nullptr; A.vol = nullptr; A.n_tens = 0; A.tens_coef = 1.0;
             A.n_if = n_if0 + n_new; A.n_if0 = n_if0;
             A.if_body0 = c.b.if_body + (size_t)e * MAXIF * 2; A.if_geom0 = c.b.if_geom + (size_t)e * MAXIF * 8;
             A.if_body1 = new_body; A.if_geom1 = new_geom;

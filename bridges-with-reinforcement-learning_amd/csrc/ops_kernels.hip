@@ -163,7 +163,8 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
                                                     const double* verts_all, const int32_t* shape_all,
                                                     const int32_t* n_blocks, const uint32_t* fixed_mask, double mu,
                                                     double density, double floor_hw, double floor_depth,
-                                                    uint8_t* stable, double* info, double* lp_ws, int64_t ws_stride) {
+                                                    uint8_t* stable, double* info, double* lp_ws, int64_t ws_stride,
+                                                    double tension_tol, double* forces) {
     __shared__ __attribute__((aligned(16))) double lds_tab[LP_TAB_LDS > (sizeof(FaceLds) / 8) ? LP_TAB_LDS : (sizeof(FaceLds) / 8)];
     __shared__ LpScratch S;
     FaceLds& F = *reinterpret_cast<FaceLds*>(lds_tab);
@@ -196,9 +197,35 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     int piv = 0;
     const long long t1 = clock64();
     bool too_big = false;
-    bool st = rbe_stable(tab, LP_TAB_LDS, LP_MAX_COLS, tab_ws, tab_cap, S, env_view(nb, pose, shape_id, shapes, n_if, if_body, if_geom),
-                         fm, mu, density, lane, &w, &piv, &err, &too_big);
+    AsmView A = env_view(nb, pose, shape_id, shapes, n_if, if_body, if_geom);
+    if (tension_tol > 0.0) {
+        // is_stable_rbe_penalty (stability.py:75-88): contact points may also PULL (one column per point along -n).  "Some
+        // equilibrium has a total tension <= tol" is again a feasibility question: the tension columns enter the force
+        // budget with the coefficient S_MAX / tol, so  sum x + (S_MAX / tol) sum t <= S_MAX  bounds the total tension by
+        // tol (and the compressive total by what is left of S_MAX).
+        A.n_tens = n_if;
+        A.tens_coef = LP_S_MAX * density / tension_tol;
+        if (6 * n_if > LP_MAX_COLS) { err = true; A.n_tens = 0; }
+    }
+    bool st = rbe_stable(tab, LP_TAB_LDS, LP_MAX_COLS, tab_ws, tab_cap, S, A, fm, mu, density, lane, &w, &piv, &err, &too_big);
     err = err || too_big;
+    if (forces) {
+        // basic solution of a feasible verdict (lp_verify left it in S.rowr): per contact point the compressive normal
+        // force c_np = a + b of the two cone generators, the tension c_nn and the tangential force mu (a - b)
+        __syncthreads();
+        const bool have = st && !err && n_if > 0 && __popc(((nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u)) & ~fm)) > 0;
+        for (int i = lane; i < MAXIF * 2; i += WAVE) {
+            const int k = i >> 1, ip = i & 1;
+            double cnp = 0.0, cnn = 0.0, ft = 0.0;
+            if (have && k < n_if) {
+                const double a = S.rowr[4 * k + 2 * ip], b = S.rowr[4 * k + 2 * ip + 1];
+                cnp = a + b; ft = mu * (a - b);
+                if (A.n_tens) cnn = S.rowr[4 * n_if + 2 * k + ip];
+            }
+            double* f = forces + ((size_t)e * MAXIF * 2 + i) * 3;
+            f[0] = cnp; f[1] = cnn; f[2] = ft;
+        }
+    }
     if (lane == 0) {
         stable[e] = (uint8_t)(st && !bad_mask);
         const long long t2 = clock64();

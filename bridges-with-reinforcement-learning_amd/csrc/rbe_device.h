@@ -165,6 +165,9 @@ struct AsmView {
     const double* if_geom1;
     const double* cen;             // optional [K,2]: world centroid of every block (then pose / shapes are not read)
     const double* vol;             // optional [K]
+    int n_tens;                    // 0, or n_if: one tension column per contact point behind the generators (penalty
+                                   // variant, stability.py:75-88): a force along -n, budget coefficient tens_coef
+    double tens_coef;
     __device__ __forceinline__ const double* P(int b) const { return b == cand_b ? cand_pose : pose + 4 * b; }
     __device__ __forceinline__ const bridges_shape& S(int b) const { return shapes[b == cand_b ? cand_shape : shape_id[b]]; }
     __device__ __forceinline__ const int32_t* ib(int k) const { return k < n_if0 ? if_body0 + 2 * k : if_body1 + 2 * (k - n_if0); }
@@ -185,7 +188,7 @@ __device__ __forceinline__ AsmView env_view(int n_blocks, const double* pose, co
                                             int n_if, const int32_t* if_body, const double* if_geom) {
     AsmView A;
     A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = n_blocks;
-    A.cand_b = -1; A.cand_pose = pose; A.cand_shape = 0; A.cen = nullptr; A.vol = nullptr;
+    A.cand_b = -1; A.cand_pose = pose; A.cand_shape = 0; A.cen = nullptr; A.vol = nullptr; A.n_tens = 0; A.tens_coef = 1.0;
     A.n_if = n_if; A.n_if0 = n_if; A.if_body0 = if_body; A.if_geom0 = if_geom; A.if_body1 = if_body; A.if_geom1 = if_geom;
     return A;
 }
@@ -212,14 +215,16 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
     int cells = (m + 2) * stride;
     for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
     __syncthreads();
+    const int n4 = 4 * A.n_if;                         // cone generators; columns [n4, n) are tension columns
     for (int j = lane; j < n; j += WAVE) {
-        int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
+        const bool tens = j >= n4;
+        int k = tens ? (j - n4) >> 1 : j >> 2, ip = tens ? (j - n4) & 1 : (j >> 1) & 1, ig = j & 1;
         const double* g = A.ig(k);
         const int32_t* bd = A.ib(k);
         double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
         double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
-        double gx = ig ? nx - mu * tx : nx + mu * tx;
-        double gz = ig ? nz - mu * tz : nz + mu * tz;
+        double gx = tens ? -nx : (ig ? nx - mu * tx : nx + mu * tx);
+        double gz = tens ? -nz : (ig ? nz - mu * tz : nz + mu * tz);
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             int body = bd[side == 0 ? 1 : 0];                  // side 0: body B (+), side 1: body A (-)
@@ -238,7 +243,7 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
     }
     for (int i = lane; i < m; i += WAVE)
         T[i * stride + nn] = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? 1.0 : LP_S_MAX * density;
+    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? ((q >= n4 && q < n) ? A.tens_coef : 1.0) : LP_S_MAX * density;
     for (int i = lane; i < ncarr; i += WAVE) T[i * stride + nn + 1 + i] = 1.0;
     __syncthreads();
     for (int b = lane; b < A.n_blocks; b += WAVE)
@@ -494,6 +499,17 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
                 const double coef = comp == 0 ? gx : (comp == 1 ? gz : (px - gcx) * gz - (pz - gcz) * gx);
                 acc += coef * x;
             }
+            if (A.n_tens) {
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    const double x = S.rowr[4 * A.n_if + 2 * k + ip];
+                    if (x == 0.0) continue;
+                    const double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+                    const double gx = -sign * g[4], gz = -sign * g[5];
+                    const double coef = comp == 0 ? gx : (comp == 1 ? gz : (px - gcx) * gz - (pz - gcz) * gx);
+                    acc += coef * x;
+                }
+            }
         }
         const double rhs = comp == 1 ? density * A.volume(b) : 0.0;
         res = fabs(acc - rhs);
@@ -530,9 +546,10 @@ __device__ inline void lp_row_map(SC& S, uint32_t free_mask, int lane) {
 
 // Tableau geometry of an assembly with n_free free blocks and n_if interfaces: rows m = 3 n_free (+ budget + cost),
 // generator columns n = 4 n_if, odd row stride (conflict-free column reads).
-__device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, int& stride, int64_t& cells, bool carriers = false) {
+__device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, int& stride, int64_t& cells, bool carriers = false,
+                                        int n_tens = 0) {
     m = 3 * n_free;
-    n = 4 * n_if;
+    n = 4 * n_if + 2 * n_tens;
     stride = n + 2 + (carriers ? m : 0);
     if ((stride & 1) == 0) stride += 1;
     cells = (int64_t)(m + 2) * stride;
@@ -555,7 +572,7 @@ __device__ inline bool rbe_stable(double* tab_lds, int lds_cap, int max_cols, do
     if (n_free == 0) return true;
     int m, n, stride;
     int64_t cells;
-    lp_dims(n_free, A.n_if, m, n, stride, cells);
+    lp_dims(n_free, A.n_if, m, n, stride, cells, false, A.n_tens);
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
     double w;
     if (cells <= lds_cap && n <= max_cols) {          // LDS path: address space known at compile time (ds_read/ds_write)

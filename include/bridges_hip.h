@@ -244,6 +244,16 @@ int bridges_stability(const bridges_shape* shapes_dev, int32_t n, int32_t K, con
                       const uint32_t* fixed_mask, double mu, double density, double floor_half_width,
                       double floor_depth, uint8_t* stable, double* info, double* lp_ws, int64_t lp_ws_stride,
                       void* stream);
+/* is_stable_rbe_penalty (assembly_gym/assembly_gym/utils/stability.py:75-88; compas_cra rbe_solve(penalty=True) +
+ * maximum_tension, assembly_gym/assembly_gym/utils/geometry.py:132-143): contact points may also pull; stable iff some
+ * equilibrium keeps the total tension <= tension_tol (> 0; 0 = plain is_stable_rbe).  forces (may be NULL):
+ * [n, MAX_INTERFACES, 2, 3] = per contact point (compression c_np, tension c_nn, tangential force) of the equilibrium
+ * found, zeros when unstable.  No output of the reference pins this variant ("parity unpinned"). */
+int bridges_stability_penalty(const bridges_shape* shapes_dev, int32_t n, int32_t K, const double* pose,
+                              const double* verts, const int32_t* shape_id, const int32_t* n_blocks,
+                              const uint32_t* fixed_mask, double mu, double density, double floor_half_width,
+                              double floor_depth, double tension_tol, uint8_t* stable, double* info, double* forces,
+                              double* lp_ws, int64_t lp_ws_stride, void* stream);
 /* upload a shape table; returns a device pointer the stand-alone operators take. */
 int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, bridges_shape** out_dev);
 int bridges_shapes_free(bridges_shape* dev);

@@ -175,3 +175,51 @@ def is_stable_rbe(blocks, fixed, mu=0.8, density=1.0, bounds=((-3.0, -3.0, -1.0)
     v = infeasibility(M, w, S_MAX * density)
     stable = v <= FEAS_TOL * density
     return (stable, dict(v=v, n_if=len(interfaces))) if return_info else stable
+
+
+def is_stable_rbe_penalty(blocks, fixed, mu=0.8, density=1.0, tol=1e-3, bounds=((-3.0, -3.0, -1.0), (7.0, 7.0, 9.0)),
+                          return_info=False):
+    """stability.py:75-88 (compas_cra rbe_solve(penalty=True) + maximum_tension <= tol), restated as a feasibility
+    question like is_stable_rbe: every contact point may additionally PULL with t_p >= 0 along -n; stable iff an
+    equilibrium exists with  sum x + (S_MAX / tol) sum t <= S_MAX  (i.e. total tension <= tol).  No output of the
+    reference pins this variant -- PARITY UNPINNED.  Also returns the true minimum total tension (HiGHS)."""
+    from scipy.optimize import linprog
+    fixed = set(fixed)
+    interfaces = find_interfaces(blocks, bounds)
+    n_free = len(blocks) - len([b for b in fixed if 0 <= b < len(blocks)])
+    if len(interfaces) == 0:
+        stable = n_free == 0
+        return (stable, dict(v=None, min_tension=None)) if return_info else stable
+    M, w = equilibrium_system(blocks, interfaces, fixed, mu, density)
+    m, n = M.shape
+    if m == 0:
+        return (True, dict(v=0.0, min_tension=0.0)) if return_info else True
+    free = [i for i in range(len(blocks)) if i not in fixed]
+    row = {b: 3 * k for k, b in enumerate(free)}
+    N = np.zeros((m, 2 * len(interfaces)))
+    for k, (A, B, p_lo, p_hi, nrm, _t) in enumerate(interfaces):
+        for ip, p in enumerate((p_lo, p_hi)):
+            for body, sign in ((B, -1.0), (A, 1.0)):                     # tension pulls B towards A
+                if body in row:
+                    r = row[body]
+                    gx, gz = sign * nrm[0], sign * nrm[1]
+                    cx, cz = blocks[body].centroid
+                    N[r, 2 * k + ip] += gx
+                    N[r + 1, 2 * k + ip] += gz
+                    N[r + 2, 2 * k + ip] += (p[0] - cx) * gz - (p[1] - cz) * gx
+    nt = N.shape[1]
+    s_max = S_MAX * density
+    Aeq = np.hstack([M, N, np.eye(m), -np.eye(m)])
+    cost = np.concatenate([np.zeros(n + nt), np.ones(2 * m)])
+    budget = np.concatenate([np.ones(n), np.full(nt, s_max / tol), np.zeros(2 * m)])[None, :]
+    res = linprog(cost, A_eq=Aeq, b_eq=w, A_ub=budget, b_ub=[s_max], bounds=(0, None), method="highs")
+    if res.status != 0:
+        raise RuntimeError(f"HiGHS failed on an always-feasible LP: {res.message}")
+    v = float(res.fun)
+    stable = v <= FEAS_TOL * density
+    if not return_info:
+        return stable
+    # the true minimum total tension (any budget on the tension removed)
+    res2 = linprog(np.concatenate([np.zeros(n), np.ones(nt)]), A_eq=np.hstack([M, N]), b_eq=w,
+                   A_ub=np.concatenate([np.ones(n), np.zeros(nt)])[None, :], b_ub=[s_max], bounds=(0, None), method="highs")
+    return stable, dict(v=v, min_tension=float(res2.fun) if res2.status == 0 else None)

@@ -60,8 +60,8 @@ def test_structure_harness_reproduces_the_recorded_table(golden_dir, tmp_path):
     for mu in (0.8, 2.0):
         for path in test_suite.run(str(tmp_path / f"mu{mu}"), mu=mu):
             data = json.load(open(path))
-            (mid, meth), = data["methods"].items()
-            assert meth["name"] == "rbe"
+            assert sorted(m["name"] for m in data["methods"].values()) == ["rbe", "rbe_penalty"]
+            mid = next(k for k, m in data["methods"].items() if m["name"] == "rbe")
             for t in data["tests"].values():
                 key = (data["structure"]["name"], json.dumps(data["structure"]["kwargs"], sort_keys=True), mu, t["step"])
                 got[key] = (t[mid]["is_stable"], t["is_stable"])
@@ -149,3 +149,46 @@ def test_contains_2d_points_and_scripted_rollout():
         assert np.array_equal(b.contains_2d(pts).reshape(64, 64), contains_2d(ob, X, Y))
     # lin_reward of the scripted rollout = sum(action raster * reward map)
     np.testing.assert_allclose(trans[0].lin_reward.item(), og.reward_map[contains_2d(og.blocks[0], X, Y)].sum(), rtol=1e-5)
+
+
+def test_rbe_penalty_variant_against_the_oracle(golden_dir):
+    """is_stable_rbe_penalty (stability.py:75-88 of the reference; maximum_tension geometry.py:132-143) through the
+    drop-in API on every build step of the known-answer structures, against the oracle's restatement of the same
+    predicate (HiGHS).  The reference holds NO recorded output of this variant: parity unpinned, oracle only.
+    Properties on top: RBE-stable implies penalty-stable; a penalty-stable verdict comes with forces whose largest net
+    tension is <= tol; AssemblyEnv(stability='rbe_penalty') serves it; the CRA variants say that they are not built."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.utils import structures
+    from assembly_gym.utils.stability import is_stable_cra, is_stable_rbe, is_stable_rbe_penalty
+    from oracle import rbe as ORB
+    from oracle.geometry import Block
+    from oracle.shapes import get_shape
+    n = differ_from_rbe = 0
+    for name, kw in (("trapezoid_bridge", dict(freeze_last=False)), ("hexagon", dict()), ("hexagon_bridge_5", dict(freeze_last=True)),
+                     ("horizontal_bridge", dict(freeze_last=False)), ("tower", dict(num_blocks=6)), ("levitating_block", dict())):
+        for mu in (0.4, 0.8, 2.0):
+            env, actions = structures.build(name, mu=mu, **kw)
+            for step, action, expected, (rbe, _) in structures.replay(env, actions, method=is_stable_rbe):
+                asm = env.assembly_env
+                pen, extra = is_stable_rbe_penalty(asm, tol=1e-3)
+                loose, _ = is_stable_rbe_penalty(asm, tol=50.0)
+                blocks = [Block(get_shape(b.shape.name), (b.pose[0], b.pose[1]), (b.pose[2], b.pose[3])) for b in asm.blocks]
+                fixed = {i for i, b in enumerate(asm.blocks) if b.is_static}
+                want, info = ORB.is_stable_rbe_penalty(blocks, fixed, mu=mu, tol=1e-3, return_info=True)
+                assert pen == want, (name, kw, mu, step, info)
+                assert loose == ORB.is_stable_rbe_penalty(blocks, fixed, mu=mu, tol=50.0), (name, kw, mu, step)
+                if rbe:
+                    assert pen
+                if pen:
+                    assert extra["max_tension"] is not None and extra["max_tension"] <= 1e-3 + 1e-9
+                else:
+                    assert extra["max_tension"] is None and (info["min_tension"] is None or info["min_tension"] > 1e-3)
+                differ_from_rbe += int(bool(loose) != bool(rbe))
+                n += 1
+    assert n > 70 and differ_from_rbe > 0              # a generous tension allowance does change verdicts
+    env = AssemblyEnv(render=False, stability="rbe_penalty")
+    assert env.stability_fct is is_stable_rbe_penalty
+    with pytest.raises(NotImplementedError):
+        is_stable_cra(env)
+    with pytest.raises(NotImplementedError):
+        AssemblyEnv(render=False, stability="cra")
