@@ -167,7 +167,10 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension
     if n > K:
         raise abi.BridgesHipError(f"{n} blocks > BRIDGES_MAX_BLOCKS ({K})")
     if n == 0:                                   # empty assembly: no edges, no free node (stability.py:53-56)
-        return True, dict(objective=0.0, n_interfaces=0, pivots=0)
+        out = dict(objective=0.0, n_interfaces=0, pivots=0)
+        if tension_tol is not None:
+            out["forces"] = np.zeros((0, 2, 3))
+        return True, out
     pose = np.zeros((1, K, 4))
     verts = np.zeros((1, K, 6, 2))
     ids = np.zeros((1, K), dtype=np.int32)
