@@ -119,16 +119,17 @@ ENV_BUFFER_FIELDS_TAIL = [
     ("cand_counters", "int32", "4"),
     ("cand_ws", "float64", "CWS,WSC"),
 ]
+ENV_LP_SNAP_DOUBLES = 64 + (3 * MAX_BLOCKS + 2) * (4 * MAX_INTERFACES + 2 + 3 * MAX_BLOCKS + 1)
 
 
 class EnvBuffers(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS] + [
         ("lp_ws_stride", C.c_int64), ("stats", C.c_void_p)] + [(name, C.c_void_p) for name, _, _ in ENV_BUFFER_FIELDS_TAIL] + [
-        ("cand_ws_stride", C.c_int64)]
+        ("cand_ws_stride", C.c_int64), ("lp_snap", C.c_void_p), ("lp_snap_stride", C.c_int64)]
 
 
 # put lp_ws_stride right after lp_ws as in the header (fields above are already in header order)
-assert [f[0] for f in EnvBuffers._fields_][-8:-5] == ["lp_ws", "lp_ws_stride", "stats"]
+assert [f[0] for f in EnvBuffers._fields_][-10:-7] == ["lp_ws", "lp_ws_stride", "stats"]
 
 _lib = None
 

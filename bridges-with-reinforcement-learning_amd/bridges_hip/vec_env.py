@@ -80,7 +80,7 @@ class VecAssemblyGym:
     def __init__(self, num_envs, shapes, obstacles, targets, max_steps=None, mu=0.8, density=1.0, bounds=None,
                  xlim=(-3.0, 7.0), ylim=(0.0, 10.0), x_discr_ground=None, offset_values=(0.0,), seed=0,
                  device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64), debug=0, env_id_base=0,
-                 sparse_raster_update=False):
+                 sparse_raster_update=False, candidate_snapshots=True):
         L = abi.require_gpu()
         if tuple(img_size) != (64, 64):
             raise NotImplementedError("the HIP rasteriser is built for 64x64 images (successor_dqn.py:585 default)")
@@ -119,6 +119,8 @@ class VecAssemblyGym:
         self.a_max = int(a_max) if a_max else bound
         self.f32_rasters = bool(f32_rasters)
         self.sparse_raster_update = bool(sparse_raster_update)
+        # keep the "last block frozen" tableau of every env for candidate_stability_mask() (123 KB per env)
+        self.candidate_snapshots = bool(candidate_snapshots)
         self.grid_x = np.linspace(self.xlim[0], self.xlim[1], 64)          # rendering.py:108
         self.grid_y = np.linspace(self.ylim[1], self.ylim[0], 64)
         self._alloc()
@@ -147,6 +149,8 @@ class VecAssemblyGym:
             shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))
             self.buf[name] = torch.zeros(shp, dtype=getattr(torch, dt), device=self.device)
         self.stats = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.lp_snap = (torch.zeros((E, abi.ENV_LP_SNAP_DOUBLES), dtype=torch.float64, device=self.device)
+                        if self.candidate_snapshots else None)
         for k, v in self.buf.items():
             setattr(self, k, v)
         self._contacts_current = True
@@ -227,6 +231,8 @@ class VecAssemblyGym:
         for name, _, _ in abi.ENV_BUFFER_FIELDS_TAIL:
             setattr(b, name, self.buf[name].data_ptr())
         b.cand_ws_stride = self.cand_ws_stride
+        b.lp_snap = self.lp_snap.data_ptr() if self.lp_snap is not None else None
+        b.lp_snap_stride = abi.ENV_LP_SNAP_DOUBLES
         self._env = C.c_void_p()
         abi.check(self.L.bridges_env_create(C.byref(t), C.byref(b), C.byref(self._env)), "bridges_env_create")
 

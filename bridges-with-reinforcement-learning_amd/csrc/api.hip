@@ -71,6 +71,8 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (t->a_max <= 0) return fail_arg("a_max");
     if (buf->lp_ws_stride < (int64_t)BRIDGES_LP_WS_DOUBLES) return fail_arg("lp_ws_stride < BRIDGES_LP_WS_DOUBLES");
     static_assert(BRIDGES_LP_WS_DOUBLES == WARM_WS_DOUBLES, "header and device code disagree on the persistent tableau size");
+    static_assert(BRIDGES_LP_SNAP_DOUBLES == WARM_HDR_DOUBLES + WARM_HALF, "header and device code disagree on the snapshot size");
+    if (buf->lp_snap && buf->lp_snap_stride < (int64_t)BRIDGES_LP_SNAP_DOUBLES) return fail_arg("lp_snap_stride < BRIDGES_LP_SNAP_DOUBLES");
     for (int g = 0; g < t->n_groups; ++g) {
         if (t->group_shape[g] < 0 || t->group_shape[g] >= t->n_shapes) return fail_arg("group_shape");
         if (t->group_face[g] < 0 || t->group_face[g] >= t->shapes[t->group_shape[g]].nv) return fail_arg("group_face");
@@ -275,8 +277,9 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
-#define CS_TAB_SMALL 640
+#define CS_TAB_SMALL 1152    // 9 KiB: with carriers, candidates on up to 5 placed blocks; 148 VGPRs allow 12 waves per CU anyway
 #define CS_COLS_SMALL 92
+#define CS_TAB_LARGE 4096
 int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");
     const DevCtx& c = env->ctx;
@@ -292,7 +295,7 @@ int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     hipLaunchKernelGGL((k_candidate_stability<CS_TAB_SMALL, CS_COLS_SMALL, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability");
     const int drain = BRIDGES_CAND_WS_SLOTS;          // one cand_ws slot per workgroup
-    hipLaunchKernelGGL((k_candidate_stability<LP_TAB_LDS, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
+    hipLaunchKernelGGL((k_candidate_stability<CS_TAB_LARGE, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability (queue)");
     return BRIDGES_OK;
 }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         A.if_body0 = Lk.if_body; A.if_geom0 = Lk.if_geom;
         A.if_body1 = if_body_g + 2 * STEP_IF_LDS; A.if_geom1 = if_geom_g + 8 * STEP_IF_LDS;
         rbe_both(tab, STEP_TAB_LDS, ws, c.b.lp_ws_stride, S, A, n_if_old, W, c.mu, c.density, lane, &st_frozen, &st_free, &err,
-                 &warm_used, &lp_diag);
+                 &warm_used, &lp_diag, c.b.lp_snap ? c.b.lp_snap + (size_t)e * c.b.lp_snap_stride : nullptr);
     }
 
     const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
@@ -872,15 +872,40 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
             bool err = false, too_big = false;
             double w = 0.0;
             int piv = 0;
-            double* ws = QUEUE ? c.b.cand_ws + (size_t)blockIdx.x * c.b.cand_ws_stride : nullptr;
-            const bool st = rbe_stable(tab, TAB, MAXCOLS, ws, QUEUE ? c.b.cand_ws_stride : (int64_t)0, S, A, fixed, c.mu, c.density,
-                                       lane, &w, &piv, &err, &too_big);
-            if (too_big) {
-                if constexpr (!QUEUE) {
-                    if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;
-                    continue;                          // decided by the second launch
+            bool st = false, solved = false;
+            // continue from the env's snapshot (k_step's "last block frozen" tableau of this very state): ~3 pivots
+            // instead of ~2 per row from scratch
+            if (c.b.lp_snap && nb > 0) {
+                const double* snap = c.b.lp_snap + (size_t)e * c.b.lp_snap_stride;
+                WarmPre W;
+                warm_header(W, snap, lane);
+                W.ok = warm_matches(W, nb, n_if0);
+                W.n_pre = 0;
+                if (W.ok) {
+                    bool fits = false, werr = false;
+                    st = rbe_candidate_warm(tab, TAB, MAXCOLS, S, A, n_if0, W, snap, c.mu, c.density, lane, &fits, &werr, &piv);
+                    if (!fits) {
+                        if constexpr (!QUEUE) {
+                            if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;
+                            continue;                  // decided by the second launch
+                        }
+                    } else if (!werr) {
+                        solved = true;
+                    }
+                    __syncthreads();
                 }
-                err = true;
+            }
+            if (!solved) {                             // no snapshot (first block, foreign state) or a failed check: from scratch
+                double* ws = QUEUE ? c.b.cand_ws + (size_t)blockIdx.x * c.b.cand_ws_stride : nullptr;
+                st = rbe_stable(tab, TAB, MAXCOLS, ws, QUEUE ? c.b.cand_ws_stride : (int64_t)0, S, A, fixed, c.mu, c.density,
+                                lane, &w, &piv, &err, &too_big);
+                if (too_big) {
+                    if constexpr (!QUEUE) {
+                        if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;
+                        continue;                      // decided by the second launch
+                    }
+                    err = true;
+                }
             }
             res = err ? 2 : (st ? 1 : 0);
         }

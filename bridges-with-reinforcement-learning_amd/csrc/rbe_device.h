@@ -314,8 +314,10 @@ __device__ __forceinline__ double fast_rcp(double x) {
 template <bool IN_LDS, typename TP, typename SC>
 __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int* pivots_out,
                                    bool* error, bool init_basis, double feas, int ncarr = 0) {
-    // m equilibrium rows are stored and swept; only rows < m_act take part in the ratio test and carry artificials
-    // (the others are "passive": equality rows that are transformed along but not enforced yet, see rbe_both).
+    // m equilibrium rows are stored and swept; only ACTIVE rows take part in the ratio test and carry artificials
+    // (the others are "passive": equality rows that are transformed along but not enforced, see rbe_both).  A row is
+    // passive iff its basis entry is -1: with init_basis that is rows >= m_act, otherwise whatever the caller set up
+    // (the candidate LPs keep the frozen block's rows passive in the middle of the tableau).
     // Row m is the force-budget row (always enforced, basic variable = its slack, column n_gen), row m+1 the cost.
     int* basis = S.basis;
     const int n = n_gen + 1;                           // structural columns incl. the slack; also the rhs column index
@@ -330,10 +332,11 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
     const int ncols = n + 1 + ncarr;                   // swept columns: structural, rhs, carriers
     const double progress = 1e-7 * feas;               // 1e-12 at density 1
     LP_PROF_DECL;
-    double w = artificial_sum(T, stride, m_act, n, basis, lane);
+    (void)m_act;                                       // from here on activity is read off the basis
+    double w = artificial_sum(T, stride, m, n, basis, lane);
     for (;;) {
         if (w <= feas) {                                           // confirm with the exact artificial sum
-            w = artificial_sum(T, stride, m_act, n, basis, lane);
+            w = artificial_sum(T, stride, m, n, basis, lane);
             if (w <= feas) break;
         }
         LP_STAMP(t_a);
@@ -360,7 +363,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
             }
         }
         if (jin < 0) {                                             // optimal: w is the true minimum
-            w = artificial_sum(T, stride, m_act, n, basis, lane);
+            w = artificial_sum(T, stride, m, n, basis, lane);
             break;
         }
         LP_STAMP(t_b);
@@ -368,7 +371,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         // ---- ratio test, lanes over rows (m + 2 <= 50 < 64) ----
         double col = (lane <= mc) ? T[lane * stride + jin] : 0.0;  // lane m: budget row, lane m+1: cost entry
         double ratio = 1e300;
-        if ((lane < m_act || lane == mb) && col > LP_TAU) {
+        if (((lane < m && basis[lane] >= 0) || lane == mb) && col > LP_TAU) {
             double rhs = T[lane * stride + n];
             ratio = (rhs > 0.0 ? rhs : 0.0) * fast_rcp(col);
         }
@@ -453,7 +456,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         if (wn < w - progress) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
-        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m_act, n, basis, lane); break; }
+        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m, n, basis, lane); break; }
     }
     *pivots_out = pivots;
     LP_PROF_FLUSH;
@@ -474,7 +477,7 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
     }
     __syncthreads();
     double res = 0.0;
-    if (lane < m_chk) {
+    if (lane < m_chk && S.basis[lane] != -1) {                      // enforced rows only (passive rows have basis -1)
         // row -> (block, component): rows are 3 per free block in block order (row_of)
         int b = -1;
         for (int k = 0; k < A.n_blocks; ++k) if (S.row_of[k] >= 0 && S.row_of[k] <= lane && lane < S.row_of[k] + 3) b = k;
@@ -624,12 +627,24 @@ struct WarmPre {
     int32_t magic, n_blocks, n_if, stride, half, m;
     int32_t basis_lane;                 // hdr.basis[lane]
     bool ok;                            // the header describes exactly the assembly without the new block
+    int n_pre;                          // cells prefetched per lane: WARM_PRE, or 0 (lp_warm_prepare reads them in place)
     double cell[WARM_PRE];
 };
 
-__device__ __forceinline__ void warm_prefetch(WarmPre& W, const double* ws, int n_old_blocks, int n_if_old, int lane) {
-    W.ok = W.magic == WARM_MAGIC && W.n_blocks == n_old_blocks && W.n_if == n_if_old && n_old_blocks >= 1 &&
+__device__ __forceinline__ void warm_header(WarmPre& W, const double* ws, int lane) {
+    const WarmHdr* h = reinterpret_cast<const WarmHdr*>(ws);
+    W.magic = h->magic; W.n_blocks = h->n_blocks; W.n_if = h->n_if; W.stride = h->stride; W.half = h->half; W.m = h->m;
+    W.basis_lane = h->basis[lane];
+}
+
+__device__ __forceinline__ bool warm_matches(const WarmPre& W, int n_old_blocks, int n_if_old) {
+    return W.magic == WARM_MAGIC && W.n_blocks == n_old_blocks && W.n_if == n_if_old && n_old_blocks >= 1 &&
            W.m == 3 * n_old_blocks;
+}
+
+__device__ __forceinline__ void warm_prefetch(WarmPre& W, const double* ws, int n_old_blocks, int n_if_old, int lane) {
+    W.ok = warm_matches(W, n_old_blocks, n_if_old);
+    W.n_pre = WARM_PRE;
     const int m_o = 3 * n_old_blocks, ncols_o = 4 * n_if_old + 2 + m_o;
     const int cells_o = W.ok ? (m_o + 1) * ncols_o : 0;
     const double* src = ws + WARM_HDR_DOUBLES + (int64_t)(W.half & 1) * WARM_HALF;
@@ -648,9 +663,9 @@ __device__ __forceinline__ void warm_prefetch(WarmPre& W, const double* ws, int 
 // Continue from the persisted tableau `src` (stride_o, m_o rows + budget, n_gen_o generators, carriers for its m_o
 // rows): fill T (stride, m = m_o + 3 rows, n_gen generators) and S.basis, rebuild the cost row for stage 1 (active
 // rows = the old ones).  A.n_blocks - 1 is the new block, interfaces >= n_gen_o / 4 are its contacts.
-template <bool IN_LDS, typename TP>
+template <bool IN_LDS, typename TP, typename SC>
 __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const double* src, int stride_o, int m_o,
-                                       int n_gen_o, const WarmPre& W, LpScratch& S, const AsmView& A, double mu,
+                                       int n_gen_o, const WarmPre& W, SC& S, const AsmView& A, double mu,
                                        double density, int lane) {
     const int n = n_gen + 1, n_o = n_gen_o + 1;                 // rhs column index (new / old)
     const int ncols_o = n_o + 1 + m_o;
@@ -662,14 +677,14 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
 #pragma unroll
     for (int u = 0; u < WARM_PRE; ++u) {                         // the prefetched cells
         const int idx = lane + WAVE * u;
-        if (idx < cells_o) {
+        if (u < W.n_pre && idx < cells_o) {
             const int i = idx / ncols_o, q = idx - i * ncols_o;
             const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
             const int in = i < m_o ? i : m;
             T[in * stride + qn] = W.cell[u];
         }
     }
-    for (int idx = lane + WAVE * WARM_PRE; idx < cells_o; idx += WAVE) {    // the rest of a large tableau
+    for (int idx = lane + WAVE * W.n_pre; idx < cells_o; idx += WAVE) {     // the rest (everything without a prefetch)
         const int i = idx / ncols_o, q = idx - i * ncols_o;
         const double v = src[(size_t)i * stride_o + q];
         const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
@@ -733,11 +748,22 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
     wave_sync<IN_LDS>();
 }
 
+// Persist rows 0..m (equilibrium + budget) of the LDS tableau.
+__device__ inline void lp_warm_store(const double* T, int stride, int m, int n_gen, double* dst, int lane) {
+    const int ncols = n_gen + 2 + m;
+    const int cells = (m + 1) * ncols;
+    for (int idx = lane; idx < cells; idx += WAVE) {
+        const int i = idx / ncols, q = idx - i * ncols;
+        dst[(size_t)i * stride + q] = T[i * stride + q];
+    }
+}
+
 // Stage 1 (last block frozen: its rows passive) and stage 2 (nothing frozen) of gym_env.py:325-333 on one tableau
 // that is either freshly built (warm == false) or continued from the persisted one (prepared by lp_warm_prepare).
 template <bool IN_LDS, typename TP>
 __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu, double density,
-                                    int lane, bool warm, bool* st_frozen, bool* st_free, bool* error, int* pivots) {
+                                    int lane, bool warm, bool* st_frozen, bool* st_free, bool* error, int* pivots,
+                                    double* snap) {
     const int m_act = m - 3;
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
     if (!warm) lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane, m);
@@ -749,6 +775,18 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
         *error = true;
     }
     if (!*st_frozen) { *st_free = false; return; }
+    if (snap) {
+        // the tableau of "last block frozen" is what the candidate-stability LPs of the NEXT state continue from (the
+        // frozen block's rows are in it, passive: basis -1)
+        wave_sync<IN_LDS>();
+        lp_warm_store(T, stride, m, n, snap + WARM_HDR_DOUBLES, lane);
+        WarmHdr* sh = reinterpret_cast<WarmHdr*>(snap);
+        if (lane <= m) sh->basis[lane] = S.basis[lane];
+        if (lane == 0) {
+            sh->n_blocks = A.n_blocks; sh->n_if = A.n_if; sh->stride = stride; sh->half = 0; sh->m = m;
+            sh->magic = WARM_MAGIC;
+        }
+    }
     lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane, m);
     w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas, m);
     *st_free = w <= feas;
@@ -758,22 +796,12 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
     }
 }
 
-// Persist rows 0..m (equilibrium + budget) of the LDS tableau.
-__device__ inline void lp_warm_store(const double* T, int stride, int m, int n_gen, double* dst, int lane) {
-    const int ncols = n_gen + 2 + m;
-    const int cells = (m + 1) * ncols;
-    for (int idx = lane; idx < cells; idx += WAVE) {
-        const int i = idx / ncols, q = idx - i * ncols;
-        dst[(size_t)i * stride + q] = T[i * stride + q];
-    }
-}
-
 // k_step's solve: both stability variants of the assembly A (A.n_blocks blocks, the last one new), continuing from the
 // environment's persisted tableau in `ws` when it matches the state (n_blocks - 1 blocks, n_if_old interfaces), and
 // persisting the result there when `keep`.  *warm_used reports which path produced the verdict.
 __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
                                 const WarmPre& W, double mu, double density, int lane, bool* st_frozen, bool* st_free,
-                                bool* error, bool* warm_used, int* diag = nullptr) {
+                                bool* error, bool* warm_used, int* diag = nullptr, double* snap = nullptr) {
     WarmHdr* hdr = reinterpret_cast<WarmHdr*>(ws);
     double* halves = ws + WARM_HDR_DOUBLES;
     *warm_used = false;
@@ -781,9 +809,10 @@ __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_
     if (A.n_if == 0) {                                 // stability.py:53-56: no edges -> stable iff no free node
         *st_frozen = nb == 1;
         *st_free = false;
-        if (lane == 0) hdr->magic = 0;
+        if (lane == 0) { hdr->magic = 0; if (snap) reinterpret_cast<WarmHdr*>(snap)->magic = 0; }
         return;
     }
+    if (snap && lane == 0) reinterpret_cast<WarmHdr*>(snap)->magic = 0;     // rewritten below when stage 1 succeeds
     const uint32_t all = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
     lp_row_map(S, all, lane);
     int m, n, stride;
@@ -808,8 +837,8 @@ __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_
             if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
             else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
         }
-        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots);
-        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots);
+        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap);
+        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap);
         if (diag) *diag = pivots * 4 + (in_lds ? 0 : 2) + attempt;     // pivots, global-memory tableau, second attempt
         if (!(warm && err)) { *error = err; *warm_used = warm; break; }
         warm = false;                                  // the continued tableau failed its check: solve from scratch
@@ -828,6 +857,32 @@ __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_
         hdr->magic = 0;
     }
     __syncthreads();
+}
+
+// is_action_stable_rbe continued from the env's snapshot (the stage-1 tableau k_step persisted for the current state):
+// the candidate is block A.n_blocks - 1, its contacts are the interfaces >= n_if_old.  The frozen block's rows stay
+// passive, the candidate's three rows are activated right away.  Returns false in *fits when the tableau (with
+// carriers) exceeds lds_cap doubles or the scratch's columns; *error when the verdict fails its check on the original
+// rows (the caller then solves from scratch).
+template <typename SC>
+__device__ inline bool rbe_candidate_warm(double* tab_lds, int lds_cap, int max_cols, SC& S, const AsmView& A, int n_if_old,
+                                          const WarmPre& W, const double* snap, double mu, double density, int lane,
+                                          bool* fits, bool* error, int* pivots) {
+    const int nb = A.n_blocks;                          // incl. the candidate
+    int m, n, stride;
+    int64_t cells;
+    lp_dims(nb, A.n_if, m, n, stride, cells, true);
+    *fits = cells <= lds_cap && n + 2 + m <= max_cols + 4 + 3 * MAXK;
+    if (!*fits) return false;
+    const uint32_t all = (1u << nb) - 1u;
+    lp_row_map(S, all, lane);
+    const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
+    lp_warm_prepare<true>(tab_lds, stride, m, n, snap + WARM_HDR_DOUBLES, W.stride, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
+    lp_activate_rows<true>(tab_lds, stride, m, m - 3, n, S, lane, m);
+    const double w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots, error, false, feas, m);
+    bool stable = w <= feas;
+    if (stable && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; stable = false; }
+    return stable;
 }
 
 }  // namespace bridges

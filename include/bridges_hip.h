@@ -36,6 +36,7 @@ extern "C" {
 #define BRIDGES_IMG 64          /* rasters are 64x64 (successor_dqn.py:585 default) */
 /* doubles of lp_ws per environment: 64 (header, basis) + 2 halves of (3*MAX_BLOCKS+2) rows x (4*MAX_IF + 2 + 3*MAX_BLOCKS + 1) columns */
 #define BRIDGES_LP_WS_DOUBLES (64 + 2 * (3 * BRIDGES_MAX_BLOCKS + 2) * (4 * BRIDGES_MAX_INTERFACES + 2 + 3 * BRIDGES_MAX_BLOCKS + 1))
+#define BRIDGES_LP_SNAP_DOUBLES (64 + (3 * BRIDGES_MAX_BLOCKS + 2) * (4 * BRIDGES_MAX_INTERFACES + 2 + 3 * BRIDGES_MAX_BLOCKS + 1))
 #define BRIDGES_CAND_WS_SLOTS 512
 
 /* One block shape: a convex (x,z) outline extruded along y.
@@ -144,6 +145,10 @@ typedef struct {
     int32_t* cand_counters;    /* [4] scratch: queue length, queue head */
     double* cand_ws;           /* [BRIDGES_CAND_WS_SLOTS, cand_ws_stride] scratch: tableaux too large for LDS */
     int64_t cand_ws_stride;    /* >= (3K+2)*(4*MAX_IF+3) */
+    double* lp_snap;           /* [E, lp_snap_stride] or NULL: per env the simplex tableau of "last block frozen" of its
+                                  current state, written by bridges_env_step; bridges_env_candidate_stability continues every
+                                  candidate's LP from it (NULL: candidates are solved from scratch) */
+    int64_t lp_snap_stride;    /* >= BRIDGES_LP_SNAP_DOUBLES */
 } bridges_env_buffers;
 
 typedef struct bridges_env bridges_env;

@@ -7,8 +7,13 @@ from bridges_hip.shapes import load_urdf
 from bridges_hip.vec_env import VecAssemblyGym
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = 0.8
-env = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0, i * H + H / 2) for i in range(4)],
-                     [(0.5, 0, 4 * H + H / 2)], max_steps=15, seed=0, debug=8, f32_rasters=False)
+if len(sys.argv) > 2 and sys.argv[2] == "hex":      # BASELINE.json configs[4]: hexagon, horizontal_bridge_setup(3), max_steps 15
+    sq, n = 0.6, 3
+    env = VecAssemblyGym(E, [load_urdf("shapes/hexagon.urdf")], [(i * sq, 0.0, sq / 2) for i in range(1, n + 1)],
+                         [(n * sq + 2.5 * sq, 0.0, sq / 2)], max_steps=15, seed=0, debug=8, f32_rasters=False)
+else:
+    env = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0, i * H + H / 2) for i in range(4)],
+                         [(0.5, 0, 4 * H + H / 2)], max_steps=15, seed=0, debug=8, f32_rasters=False)
 for _ in range(40):
     env.select_random(); env.step()
 for rep in range(3):
