@@ -25,7 +25,7 @@ def lp_ws_stride(max_blocks):
 
 # include/bridges_hip.h: BRIDGES_LP_WS_DOUBLES -- the per-env persistent tableau of the incremental simplex
 ENV_LP_WS_DOUBLES = 64 + 2 * (3 * MAX_BLOCKS + 2) * (4 * MAX_INTERFACES + 2 + 3 * MAX_BLOCKS + 1)
-CAND_WS_SLOTS = 512
+CAND_WS_SLOTS = 1024
 
 
 IMG = 64

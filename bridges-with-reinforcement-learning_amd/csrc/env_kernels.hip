@@ -800,7 +800,7 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
         } else {
             if (item >= total) return;
             ci = item;
-            if (!c.b.cand_mask[ci]) {
+            if (!c.b.cand_mask[ci] || (c.debug & 16)) {        // debug bit4: every wave leaves here (cost of the empty grid)
                 if (lane == 0) c.b.cand_stable[ci] = 0;
                 continue;
             }

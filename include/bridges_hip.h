@@ -37,7 +37,7 @@ extern "C" {
 /* doubles of lp_ws per environment: 64 (header, basis) + 2 halves of (3*MAX_BLOCKS+2) rows x (4*MAX_IF + 2 + 3*MAX_BLOCKS + 1) columns */
 #define BRIDGES_LP_WS_DOUBLES (64 + 2 * (3 * BRIDGES_MAX_BLOCKS + 2) * (4 * BRIDGES_MAX_INTERFACES + 2 + 3 * BRIDGES_MAX_BLOCKS + 1))
 #define BRIDGES_LP_SNAP_DOUBLES (64 + (3 * BRIDGES_MAX_BLOCKS + 2) * (4 * BRIDGES_MAX_INTERFACES + 2 + 3 * BRIDGES_MAX_BLOCKS + 1))
-#define BRIDGES_CAND_WS_SLOTS 512
+#define BRIDGES_CAND_WS_SLOTS 1024
 
 /* One block shape: a convex (x,z) outline extruded along y.
  * Replaces Shape.from_urdf / from_mesh / get_face_frame_2d
