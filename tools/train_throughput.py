@@ -23,6 +23,8 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--no_fused_adam", action="store_true")
 ap.add_argument("--miopen_search", action="store_true", help="let MIOpen benchmark its algorithms (one shape per run)")
 ap.add_argument("--channels_last", action="store_true")
+ap.add_argument("--shapes", default="trapezoid", choices=["trapezoid", "hexagon", "both"])
+ap.add_argument("--bridge_length", type=int, default=0, help="> 0: horizontal_bridge_setup(num_obstacles=N) instead of the tower")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 if a.miopen_search:
@@ -33,9 +35,14 @@ torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
 if a.channels_last:
     pol, tgt = pol.to(memory_format=torch.channels_last), tgt.to(memory_format=torch.channels_last)
-env = VecAssemblyGym(a.envs, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., i * H + H / 2) for i in range(a.tower)],
-                     [(0.5, 0, a.tower * H + H / 2)], max_steps=a.max_steps, seed=0, device=dev,
-                     f32_rasters=VecDQN.acting_needs_f32_rasters(pol))
+names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[a.shapes]
+if a.bridge_length:
+    sq, nn = 0.6, a.bridge_length
+    obstacles, targets = [(i * sq, 0.0, sq / 2) for i in range(1, nn + 1)], [(nn * sq + 2.5 * sq, 0.0, sq / 2)]
+else:
+    obstacles, targets = [(0.5, 0., i * H + H / 2) for i in range(a.tower)], [(0.5, 0, a.tower * H + H / 2)]
+env = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], obstacles, targets, max_steps=a.max_steps, seed=0,
+                     device=dev, f32_rasters=VecDQN.acting_needs_f32_rasters(pol), candidate_snapshots=False)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
 for i in range(a.warmup):
