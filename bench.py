@@ -20,7 +20,7 @@ the only communication is the barrier / max-reduce of the timing contract.
 Side numbers (never part of `value`) ride in the same JSON line under `other_modes`, each measured in
 a child process of its own: the two cheaper raster modes, the candidate-stability mask
 (`is_action_stable_rbe` over every valid candidate, LPs/s), BASELINE.json's config-5 simulator
-workload (hexagon, bridge span) and training in the loop for configs[1] and configs[2].
+workload (hexagon, bridge span) and training in the loop for configs[1], configs[2] and (one GPU's share of) configs[4].
 """
 import argparse
 import json
@@ -196,13 +196,18 @@ def side_modes(args):
     sim("config5_hexagon_bridge", ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15", "--groups", str(args.groups)])
     if os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
         tool = os.path.join(ROOT, "tools", "train_throughput.py")
+        n_ls = os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")
         for name, extra in (("train_config3_successor_mlp", ["--envs", "4096", "--tower", "4", "--max_steps", "15", "--model",
-                                                             "SuccessorMLP", "--loss", "mse_block_features"]),
+                                                             "SuccessorMLP", "--loss", "mse_block_features", "--locksteps", n_ls,
+                                                             "--warmup", "6"]),
                             ("train_config2_convnet", ["--envs", "1024", "--tower", "2", "--max_steps", "10", "--model",
-                                                       "ConvNet", "--loss", "mse_q_values"])):
+                                                       "ConvNet", "--loss", "mse_q_values", "--locksteps", n_ls, "--warmup", "6"]),
+                            # BASELINE.json configs[4] on one GPU: a lock-step is ~1.8 s (U-Net over ~10^5 candidate rows)
+                            ("train_config5_unet_hexagon", ["--envs", "4096", "--max_steps", "15", "--model", "UNet", "--loss",
+                                                            "mse_q_values+mse_block_features", "--shapes", "hexagon",
+                                                            "--bridge_length", "3", "--locksteps", "3", "--warmup", "3"])):
             try:
-                sub, err = _child_json([sys.executable, tool, "--locksteps", os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12"),
-                                        "--warmup", "6", *extra], 900)
+                sub, err = _child_json([sys.executable, tool, *extra], 900)
                 if sub is None:
                     out[name] = {"error": err}
                     continue
