@@ -33,14 +33,17 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_the_header():
     """ctypes mirrors vs the C compiler's view of the header."""
     from bridges_hip import abi
-    src = '#include <stdio.h>\n#include "bridges_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(bridges_shape), sizeof(bridges_task), sizeof(bridges_env_buffers));return 0;}\n'
+    src = ('#include <stdio.h>\n#include "bridges_hip.h"\nint main(){printf("%zu %zu %zu %ld %ld %d\\n", sizeof(bridges_shape), '
+           'sizeof(bridges_task), sizeof(bridges_env_buffers), (long)BRIDGES_LP_WS_DOUBLES, (long)BRIDGES_LP_SNAP_DOUBLES, '
+           'BRIDGES_CAND_WS_SLOTS);return 0;}\n')
     exe = os.path.join(ROOT, "tests", "_abi_sizes")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     try:
         out = subprocess.check_output([exe]).decode().split()
     finally:
         os.remove(exe)
-    assert [int(v) for v in out] == [ctypes.sizeof(abi.Shape), ctypes.sizeof(abi.Task), ctypes.sizeof(abi.EnvBuffers)]
+    assert [int(v) for v in out] == [ctypes.sizeof(abi.Shape), ctypes.sizeof(abi.Task), ctypes.sizeof(abi.EnvBuffers),
+                                     abi.ENV_LP_WS_DOUBLES, abi.ENV_LP_SNAP_DOUBLES, abi.CAND_WS_SLOTS]
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
@@ -264,3 +267,30 @@ def test_replay_buffer_checkpoint_is_plain_tensors_and_round_trips(tmp_path):
     torch.save(collections.deque([1, 2]), str(tmp_path / "legacy.pt"))
     with pytest.raises(Exception):
         ReplayBuffer().load(str(tmp_path / "legacy.pt"))
+
+
+def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
+    """`python bench.py --gpus 4` outside torchrun: the parent builds a torch.distributed.run command (one rank per GPU,
+    rendezvous on 127.0.0.1, its own arguments passed through) BEFORE importing torch, and exits with the child's code."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "9", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "9", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1"
