@@ -54,6 +54,26 @@ def soft_update_(target, policy, tau):
     return target
 
 
+def bias_relu_(x, bias):
+    """relu(x + bias[c]) in place on the NCHW output ``x`` [n, C, H, W] of a bias-free convolution (one pass)."""
+    L = abi.require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and bias.dtype == torch.float32
+    n, C, H, W = x.shape
+    abi.check(L.bridges_bias_relu(_ptr(x), _ptr(bias.contiguous()), n, C, H * W, _stream()), "bridges_bias_relu")
+    return x
+
+
+def bias_relu_pool2(x, bias):
+    """maxpool2(relu(x + bias[c])) of the NCHW output of a bias-free convolution in one pass -> [n, C, H/2, W/2]."""
+    L = abi.require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and bias.dtype == torch.float32
+    n, C, H, W = x.shape
+    out = torch.empty((n, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    abi.check(L.bridges_bias_relu_pool2(_ptr(x), _ptr(bias.contiguous()), _ptr(out), n, C, H, W, _stream()),
+              "bridges_bias_relu_pool2")
+    return out
+
+
 class FlatParameters:
     """All parameters and float buffers of a module re-pointed into ONE contiguous float32 device buffer, so the
     Polyak update of a 6.4 M-parameter SuccessorMLP is a single launch instead of one per state_dict key."""

@@ -505,4 +505,29 @@ int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, cons
     return BRIDGES_OK;
 }
 
+int bridges_bias_relu(float* x, const float* bias, int64_t n, int32_t C, int32_t hw, void* stream) {
+    if (n < 0 || C <= 0 || hw <= 0 || (hw & 3) || !x || !bias) return fail_arg("bridges_bias_relu");
+    if (((uintptr_t)x) & 15) return fail_arg("bias_relu: x must be 16-byte aligned");
+    if (n == 0) return BRIDGES_OK;
+    const int64_t n4 = n * C * (hw >> 2);
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_bias_relu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, n4, hw >> 2, C);
+    LAUNCH_CHECK("k_bias_relu");
+    return BRIDGES_OK;
+}
+
+int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64_t n, int32_t C, int32_t H, int32_t W,
+                            void* stream) {
+    if (n < 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || (H & 1) || !x || !bias || !out) return fail_arg("bridges_bias_relu_pool2");
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 7)) return fail_arg("bias_relu_pool2: x must be 16-byte, out 8-byte aligned");
+    if (n == 0) return BRIDGES_OK;
+    const int64_t items = n * C * (H >> 1) * (W >> 2);
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_bias_relu_pool2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, out, items, H, W, C);
+    LAUNCH_CHECK("k_bias_relu_pool2");
+    return BRIDGES_OK;
+}
+
 }  // extern "C"

@@ -143,4 +143,40 @@ __global__ __launch_bounds__(256) void k_sigmoid_dot(int n_rows, const float* __
     }
 }
 
+// ---- inference epilogues of the conv nets (robotoddler/models/cv.py: Conv2d -> ReLU [-> MaxPool2d(2)]) -------------
+// torch runs "+ bias", "relu" and "maxpool" as three passes over the activation tensor (9.3 GB of traffic per 2048
+// rows of the ConvNet, a third of its forward time); these do them in one.  Adding the channel's bias and clamping at
+// zero are monotone, so max(x_i) + b -> relu gives bit for bit what pool(relu(x_i + b)) gives.
+// x [n, C, hw] contiguous (NCHW), hw % 4 == 0; in place.
+__global__ __launch_bounds__(256) void k_bias_relu(float* __restrict__ x, const float* __restrict__ bias, int64_t n4,
+                                                   int hw4, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float b = bias[(i / hw4) % C];
+        float4 v = x4[i];
+        v.x = fmaxf(v.x + b, 0.f); v.y = fmaxf(v.y + b, 0.f); v.z = fmaxf(v.z + b, 0.f); v.w = fmaxf(v.w + b, 0.f);
+        x4[i] = v;
+    }
+}
+
+// out[nc, H/2, W/2] = relu(max over the 2x2 window of x[nc, H, W] + bias[c]); W % 4 == 0, H % 2 == 0.
+// One thread: 4 input columns of 2 rows -> 2 outputs.
+__global__ __launch_bounds__(256) void k_bias_relu_pool2(const float* __restrict__ x, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t n_items, int H, int W, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int w4 = W >> 2, h2 = H >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+        const int64_t q = i % w4, rest = i / w4;
+        const int64_t r = rest % h2, nc = rest / h2;
+        const float b = bias[nc % C];
+        const float* p = x + (nc * H + 2 * r) * W + 4 * q;
+        const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + W);
+        float2 o;
+        o.x = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y)) + b, 0.f);
+        o.y = fmaxf(fmaxf(fmaxf(a0.z, a0.w), fmaxf(a1.z, a1.w)) + b, 0.f);
+        *reinterpret_cast<float2*>(out + (nc * h2 + r) * (W >> 1) + 2 * q) = o;
+    }
+}
+
 }  // namespace bridges

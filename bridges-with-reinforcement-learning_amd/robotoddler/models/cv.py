@@ -4,12 +4,29 @@ Same module / parameter names (state_dicts are interchangeable) and the same for
 ``net(block_f, binary_f, action_f, reward_f, obstacle_f) -> (q, succ_block_f, succ_binary_f)``.
 ConvNet implements the 5-argument forward the training loop calls (reference cv.py:67-73, commented out at HEAD,
 where only the 2-argument form used by Policy.SFStability is live); both forms are supported here.
-The networks stay in PyTorch-ROCm (MIOpen / hipBLASLt); only the target construction and the soft update around
-them are hand-written HIP (bridges_td_target, bridges_soft_update).
+The networks stay in PyTorch-ROCm (MIOpen / hipBLASLt); hand-written HIP around them: the target construction and the
+soft update (bridges_td_target, bridges_soft_update), the bit-packed first layer and head of SuccessorMLP's acting forward,
+and -- for the inference passes (acting, targets: no autograd) of the conv nets -- the epilogue of every convolution:
+``+ bias -> ReLU [-> MaxPool2d(2)]`` in ONE pass over the activations (bridges_bias_relu, bridges_bias_relu_pool2) instead
+of torch's three, bit-identical to the module's own forward.
 """
 import torch
 from torch import nn
 import torch.nn.functional as F
+
+
+def _fused_inference(x):
+    """True when the fused epilogues apply: no autograd graph is being recorded, float32 tensors on the GPU."""
+    return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
+
+
+def _conv_relu(conv, x, pool=False):
+    """relu(conv(x)) [then 2x2 max-pool] with the bias / ReLU / pool epilogue as one HIP pass."""
+    from bridges_hip import dqn_ops
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups).contiguous()
+    if pool:
+        return dqn_ops.bias_relu_pool2(y, conv.bias)
+    return dqn_ops.bias_relu_(y, conv.bias)
 
 
 def _conv_pair(cin, cout):
@@ -25,6 +42,8 @@ class ConvBlock(nn.Module):
         self.layers = nn.Sequential(*_conv_pair(in_c, out_c), nn.MaxPool2d((2, 2)))
 
     def forward(self, inputs):
+        if _fused_inference(inputs) and inputs.shape[-1] % 8 == 0 and inputs.shape[-2] % 2 == 0:
+            return _conv_relu(self.layers[2], _conv_relu(self.layers[0], inputs), pool=True)
         return self.layers(inputs)
 
 
@@ -162,13 +181,14 @@ class UNet(nn.Module):
 
     def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
         x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1)
-        s1 = F.relu(self.e12(F.relu(self.e11(x))))
-        s2 = F.relu(self.e22(F.relu(self.e21(self.pool1(s1)))))
-        b = F.relu(self.e32(F.relu(self.e31(self.pool2(s2)))))
+        cr = _conv_relu if (_fused_inference(x) and x.shape[-1] % 16 == 0) else (lambda conv, t: F.relu(conv(t)))
+        s1 = cr(self.e12, cr(self.e11, x))
+        s2 = cr(self.e22, cr(self.e21, self.pool1(s1)))
+        b = cr(self.e32, cr(self.e31, self.pool2(s2)))
         u = torch.cat([self.upconv3(b), s2], dim=1)
-        u = F.relu(self.d32(F.relu(self.d31(u))))
+        u = cr(self.d32, cr(self.d31, u))
         u = torch.cat([self.upconv4(u), s1], dim=1)
-        u = F.relu(self.d42(F.relu(self.d41(u))))
+        u = cr(self.d42, cr(self.d41, u))
         out = self.outconv(u)
         if self.n_class == 2:
             out = out.softmax(dim=1)[:, 1]

@@ -276,6 +276,14 @@ int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* n
                       const uint8_t* done, float gamma, int32_t sf_dim, float* q_target, float* sf_target,
                       int32_t* argmax_row, void* stream);
 
+/* Inference epilogues of the conv Q-networks (robotoddler/models/cv.py:5-17, 41-73, 108-170: Conv2d -> ReLU
+ * [-> MaxPool2d(2)]), one pass instead of torch's three; bit-identical to relu(conv + bias) / maxpool(relu(conv + bias)).
+ * x [n, C, hw] f32 contiguous NCHW output of a bias-free convolution, updated in place (hw % 4 == 0). */
+int bridges_bias_relu(float* x, const float* bias, int64_t n, int32_t C, int32_t hw, void* stream);
+/* x [n, C, H, W] -> out [n, C, H/2, W/2] (W % 4 == 0, H % 2 == 0). */
+int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64_t n, int32_t C, int32_t H, int32_t W,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,3 +327,35 @@ def test_log_episode_reports_the_reference_numbers():
     assert info["num_steps"] == len(transitions) >= 1
     for k in want:
         assert info[k] == pytest.approx(want[k], rel=1e-5, abs=1e-7), k
+
+
+@pytest.mark.parametrize("model", ["ConvNet", "Policy"])
+def test_fused_conv_epilogues_equal_the_module_forward(model):
+    """Inference passes of the conv nets run every convolution bias-free and apply ``+ bias -> ReLU [-> MaxPool2d(2)]``
+    as one HIP pass (bridges_bias_relu / bridges_bias_relu_pool2): bit-identical to the plain torch forward (which the
+    same modules take whenever autograd records), on the ops alone and through ConvNet / Policy."""
+    from bridges_hip import dqn_ops
+    from robotoddler.models.cv import ConvNet, Policy
+    from robotoddler.utils.utils import init_weights
+    g = torch.Generator().manual_seed(3)
+    for (n, C, H, W) in ((5, 16, 64, 64), (3, 128, 8, 8), (2, 32, 16, 32)):
+        x = torch.randn(n, C, H, W, generator=g).to(DEV)
+        b = torch.randn(C, generator=g).to(DEV)
+        want = torch.relu(x + b[None, :, None, None])
+        assert torch.equal(dqn_ops.bias_relu_pool2(x, b), torch.nn.functional.max_pool2d(want, 2))
+        assert torch.equal(dqn_ops.bias_relu_(x.clone(), b), want)
+    torch.manual_seed(2)
+    net = (ConvNet(img_size=(64, 64)) if model == "ConvNet" else Policy()).to(DEV)
+    net.apply(init_weights)
+    net.eval()
+    n = 37
+    args = [(torch.rand(n, 1, 64, 64, generator=g) > 0.9).float().to(DEV), (torch.rand(n, 6, generator=g) > 0.5).float().to(DEV),
+            (torch.rand(n, 1, 64, 64, generator=g) > 0.95).float().to(DEV), torch.rand(n, 1, 64, 64, generator=g).to(DEV),
+            (torch.rand(n, 1, 64, 64, generator=g) > 0.9).float().to(DEV)]
+    with torch.no_grad():
+        fused = net(*args)
+    with torch.enable_grad():
+        plain = net(*args)
+    for a, bb in zip(fused, plain):
+        if a is not None:
+            assert torch.equal(a, bb.detach())
