@@ -185,7 +185,12 @@ int bridges_env_timing_begin(bridges_env* env, int32_t max_launches) {
     free_events(env);
     env->ev_start = new (std::nothrow) hipEvent_t[max_launches];
     env->ev_stop = new (std::nothrow) hipEvent_t[max_launches];
-    if (!env->ev_start || !env->ev_stop) return fail_arg("oom");
+    if (!env->ev_start || !env->ev_stop) {
+        delete[] env->ev_start;
+        delete[] env->ev_stop;
+        env->ev_start = env->ev_stop = nullptr;
+        return fail_arg("oom");
+    }
     for (int i = 0; i < max_launches; ++i) {
         HIP_TRY(hipEventCreate(&env->ev_start[i]));
         HIP_TRY(hipEventCreate(&env->ev_stop[i]));
