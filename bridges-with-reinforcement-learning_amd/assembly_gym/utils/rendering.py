@@ -6,13 +6,13 @@ import numpy as np
 from bridges_hip import ops
 
 
-def render_blocks_2d_bits(blocks, xlim, ylim):
+def render_blocks_2d_bits(blocks, xlim, ylim, img_size=(64, 64)):
     """Device bit raster (int64 [64]) of the union of the blocks."""
-    return ops.bits_or(ops.raster_bits(list(blocks), xlim, ylim))
+    return ops.bits_or(ops.raster_bits(list(blocks), xlim, ylim, img_size))
 
 
 def render_blocks_2d(blocks, xlim, ylim, img_size=(512, 512)):
-    if tuple(img_size) != (64, 64):
-        raise NotImplementedError("the HIP rasteriser renders 64x64 images (successor_dqn.py:585 default)")
-    bits = render_blocks_2d_bits(blocks, xlim, ylim)
-    return ops.bits_to_f32(bits)[0].cpu().numpy().astype(bool)
+    """Square images of up to 64 pixels (the training loop's default is 64x64, successor_dqn.py:585); the
+    reference's own default of 512x512 is only used by its plotting helpers and raises NotImplementedError here."""
+    bits = render_blocks_2d_bits(blocks, xlim, ylim, img_size)
+    return ops.crop(ops.bits_to_f32(bits), img_size)[0].cpu().numpy().astype(bool)

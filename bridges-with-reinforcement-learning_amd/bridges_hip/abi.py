@@ -57,7 +57,7 @@ class Task(C.Structure):
         ("n_shapes", C.c_int32), ("n_groups", C.c_int32),
         ("group_shape", C.c_int32 * MAX_GROUPS), ("group_face", C.c_int32 * MAX_GROUPS),
         ("n_ground", C.c_int32), ("n_offsets", C.c_int32), ("n_targets", C.c_int32), ("debug", C.c_int32),
-        ("env_id_base", C.c_int32), ("pad_", C.c_int32),
+        ("env_id_base", C.c_int32), ("img_size", C.c_int32),
         ("mu", C.c_double), ("density", C.c_double),
         ("floor_half_width", C.c_double), ("floor_depth", C.c_double),
         ("xlim", C.c_double * 2), ("ylim", C.c_double * 2),
@@ -170,6 +170,7 @@ def lib():
         "bridges_face_frames": [vp, i32, vp, vp, vp, vp],
         "bridges_contains_points": [vp, i32, vp, i32, vp, vp, vp],
         "bridges_raster": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_raster_sized": [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp],
         "bridges_bits_or": [i32, vp, vp, vp, vp],
         "bridges_bits_to_f32": [i32, vp, vp, vp],
         "bridges_bits_linear": [i32, vp, vp, vp, i32, vp, vp, vp, vp],
@@ -195,7 +196,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate", "bridges_env_set_raster_split",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
 )
 

@@ -75,8 +75,25 @@ def place(frame1, geom, face, ox, oy):
     return pose[0].cpu().numpy(), verts[0, :len(geom.verts)].cpu().numpy()
 
 
-def raster_bits(blocks, xlim, ylim):
-    """One bit raster per posed block: int64 [n,64] on the device (rendering.py:105-113 per block)."""
+def image_size(img_size):
+    """-> S of an S x S image the rasteriser renders (2 <= S <= 64, one wave lane per pixel column)."""
+    w, h = (int(v) for v in img_size)
+    if w != h or not 2 <= w <= 64:
+        raise NotImplementedError(f"the HIP rasteriser renders square images of 2..64 pixels, not {w}x{h} "
+                                  "(successor_dqn.py:585 default: 64x64)")
+    return w
+
+
+def crop(images, img_size):
+    """[..., 64, 64] canvas -> the [..., S, S] image in its top-left corner (no-op for 64x64)."""
+    S = image_size(img_size)
+    return images if S == 64 else images[..., :S, :S]
+
+
+def raster_bits(blocks, xlim, ylim, img_size=(64, 64)):
+    """One bit raster per posed block: int64 [n,64] on the device (rendering.py:105-113 per block).  For S x S
+    images with S < 64 the words / bits >= S are zero."""
+    S = image_size(img_size)
     L = abi.require_gpu()
     dev = device()
     n = len(blocks)
@@ -90,10 +107,10 @@ def raster_bits(blocks, xlim, ylim):
     tab = REGISTRY.device_table()
     v = torch.tensor(verts, dtype=torch.float64, device=dev)
     s = torch.tensor(ids, dtype=torch.int32, device=dev)
-    gx = torch.tensor(np.linspace(xlim[0], xlim[1], 64), dtype=torch.float64, device=dev)
-    gy = torch.tensor(np.linspace(ylim[1], ylim[0], 64), dtype=torch.float64, device=dev)
+    gx = torch.tensor(np.linspace(xlim[0], xlim[1], S), dtype=torch.float64, device=dev)
+    gy = torch.tensor(np.linspace(ylim[1], ylim[0], S), dtype=torch.float64, device=dev)
     bits = torch.empty((n, 64), dtype=torch.int64, device=dev)
-    abi.check(L.bridges_raster(tab, n, _ptr(v), _ptr(s), _ptr(gx), _ptr(gy), _ptr(bits), None, _stream()),
+    abi.check(L.bridges_raster_sized(tab, n, _ptr(v), _ptr(s), _ptr(gx), _ptr(gy), S, _ptr(bits), None, _stream()),
               "bridges_raster")
     return bits
 

@@ -65,15 +65,24 @@ class ShapeTable:
 
 
 def raster_posed(table, verts, shape_ids, grid_x, grid_y, want_bits=True, want_f32=False):
-    """bridges_raster on n posed outlines (verts [n,6,2] f64, shape_ids [n] i32, device tensors)."""
+    """bridges_raster_sized on n posed outlines (verts [n,6,2] f64, shape_ids [n] i32, device tensors); the image
+    size S = len(grid_x) <= 64, outputs on the 64-word / 64x64 canvas (image = top-left S x S corner)."""
     L = abi.require_gpu()
     n = int(verts.shape[0])
     dev = verts.device
+    size = int(grid_x.numel())
+    if int(grid_y.numel()) != size:
+        raise NotImplementedError("the HIP rasteriser renders square images")
     bits = torch.empty((n, 64), dtype=torch.int64, device=dev) if want_bits else None
     img = torch.empty((n, 64, 64), dtype=torch.float32, device=dev) if want_f32 else None
-    abi.check(L.bridges_raster(table.ptr, n, _ptr(verts), _ptr(shape_ids), _ptr(grid_x), _ptr(grid_y),
-                               _ptr(bits), _ptr(img), _stream()), "bridges_raster")
+    abi.check(L.bridges_raster_sized(table.ptr, n, _ptr(verts), _ptr(shape_ids), _ptr(grid_x), _ptr(grid_y), size,
+                                     _ptr(bits), _ptr(img), _stream()), "bridges_raster")
     return bits, img
+
+
+def check_img_size(img_size):
+    from .ops import image_size
+    return image_size(img_size)
 
 
 class VecAssemblyGym:
@@ -82,8 +91,7 @@ class VecAssemblyGym:
                  device="cuda:0", f32_rasters=True, a_max=None, img_size=(64, 64), debug=0, env_id_base=0,
                  sparse_raster_update=False, candidate_snapshots=True):
         L = abi.require_gpu()
-        if tuple(img_size) != (64, 64):
-            raise NotImplementedError("the HIP rasteriser is built for 64x64 images (successor_dqn.py:585 default)")
+        self.img = check_img_size(img_size)          # S; every image buffer stays a 64x64 canvas, see crop()
         self.L = L
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -121,8 +129,8 @@ class VecAssemblyGym:
         self.sparse_raster_update = bool(sparse_raster_update)
         # keep the "last block frozen" tableau of every env for candidate_stability_mask() (123 KB per env)
         self.candidate_snapshots = bool(candidate_snapshots)
-        self.grid_x = np.linspace(self.xlim[0], self.xlim[1], 64)          # rendering.py:108
-        self.grid_y = np.linspace(self.ylim[1], self.ylim[0], 64)
+        self.grid_x = np.linspace(self.xlim[0], self.xlim[1], self.img)    # rendering.py:108
+        self.grid_y = np.linspace(self.ylim[1], self.ylim[0], self.img)
         self._alloc()
         self._task_features()
         self._create()
@@ -186,13 +194,19 @@ class VecAssemblyGym:
         abi.check(self.L.bridges_bits_to_f32(1, _ptr(tbits), _ptr(timg), _stream()), "bridges_bits_to_f32")
         k1 = gaussian_kernel_1d(101, 16, dev)                              # successor_dqn.py:80-82
         kernel = (k1.unsqueeze(0) * k1.unsqueeze(1))
-        rm = torch.nn.functional.conv2d(timg.unsqueeze(0), kernel.unsqueeze(0).unsqueeze(0), padding=50)
-        self.buf["reward_map"].copy_(rm[0, 0])
+        S = self.img                                                       # the map of the S x S image, rest of the canvas 0
+        rm = torch.nn.functional.conv2d(timg[None, :, :S, :S].contiguous(), kernel.unsqueeze(0).unsqueeze(0), padding=50)
+        self.buf["reward_map"].zero_()
+        self.buf["reward_map"][:S, :S].copy_(rm[0, 0])
         oimg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
         abi.check(self.L.bridges_bits_to_f32(1, _ptr(self.buf["obstacle_bits"]), _ptr(oimg), _stream()),
                   "bridges_bits_to_f32")
-        self.obstacle_raster = oimg                                       # [1,64,64] f32
-        self.reward_features = self.buf["reward_map"].unsqueeze(0)        # [1,64,64] f32
+        self.obstacle_raster = self.crop(oimg)                            # [1,S,S] f32
+        self.reward_features = self.crop(self.buf["reward_map"].unsqueeze(0))   # [1,S,S] f32
+
+    def crop(self, images):
+        """[..., 64, 64] canvas -> the [..., S, S] image (a no-op view for the default S = 64)."""
+        return images if self.img == 64 else images[..., :self.img, :self.img]
 
     def _create(self):
         t = abi.Task()
@@ -217,8 +231,9 @@ class VecAssemblyGym:
         self._shape_arr = (abi.Shape * len(self.table_geoms))(*[g.to_struct() for g in self.table_geoms])
         self._xg = (C.c_double * len(self.x_discr_ground))(*self.x_discr_ground)
         self._off = (C.c_double * len(self.offset_values))(*self.offset_values)
-        self._gx = (C.c_double * 64)(*self.grid_x.tolist())
-        self._gy = (C.c_double * 64)(*self.grid_y.tolist())
+        t.img_size = self.img
+        self._gx = (C.c_double * self.img)(*self.grid_x.tolist())
+        self._gy = (C.c_double * self.img)(*self.grid_y.tolist())
         t.shapes = C.cast(self._shape_arr, C.POINTER(abi.Shape))
         dp = C.POINTER(C.c_double)
         t.x_ground, t.offsets = C.cast(self._xg, dp), C.cast(self._off, dp)
@@ -285,9 +300,9 @@ class VecAssemblyGym:
         abi.check(self.L.bridges_pose_block(self.table.ptr, E * K, _ptr(flat_shape), _ptr(self.buf["blk_pose"]),
                                             _ptr(self.buf["blk_verts"]), _stream()), "bridges_pose_block")
         bits = torch.empty((E * K, 64), dtype=torch.int64, device=self.device)
-        abi.check(self.L.bridges_raster(self.table.ptr, E * K, _ptr(self.buf["blk_verts"]), _ptr(flat_shape),
-                                        _ptr(self.grid_x_dev), _ptr(self.grid_y_dev), _ptr(bits), None, _stream()),
-                  "bridges_raster")
+        abi.check(self.L.bridges_raster_sized(self.table.ptr, E * K, _ptr(self.buf["blk_verts"]), _ptr(flat_shape),
+                                              _ptr(self.grid_x_dev), _ptr(self.grid_y_dev), self.img, _ptr(bits), None,
+                                              _stream()), "bridges_raster")
         start = torch.arange(E, dtype=torch.int32, device=self.device) * K
         ranges = torch.stack([start, start + self.buf["n_blocks"]], dim=1).contiguous()
         abi.check(self.L.bridges_bits_or(E, _ptr(ranges), _ptr(bits), _ptr(self.buf["state_bits"]), _stream()),

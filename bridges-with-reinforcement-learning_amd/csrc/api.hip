@@ -69,6 +69,7 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (t->n_ground < 0 || t->n_ground > 32 || t->n_offsets <= 0 || t->n_offsets > 8) return fail_arg("n_ground/n_offsets");
     if (t->n_targets < 0 || t->n_targets > BRIDGES_MAX_TARGETS) return fail_arg("n_targets");
     if (t->a_max <= 0) return fail_arg("a_max");
+    if (t->img_size != 0 && (t->img_size < 2 || t->img_size > BRIDGES_IMG)) return fail_arg("img_size must be 0 (= 64) or 2..64");
     if (buf->lp_ws_stride < (int64_t)BRIDGES_LP_WS_DOUBLES) return fail_arg("lp_ws_stride < BRIDGES_LP_WS_DOUBLES");
     static_assert(BRIDGES_LP_WS_DOUBLES == WARM_WS_DOUBLES, "header and device code disagree on the persistent tableau size");
     static_assert(BRIDGES_LP_SNAP_DOUBLES == WARM_HDR_DOUBLES + WARM_HALF, "header and device code disagree on the snapshot size");
@@ -92,8 +93,11 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     memcpy(host->shapes, t->shapes, sizeof(bridges_shape) * t->n_shapes);
     memcpy(host->x_ground, t->x_ground, sizeof(double) * t->n_ground);
     memcpy(host->offsets, t->offsets, sizeof(double) * t->n_offsets);
-    memcpy(host->grid_x, t->grid_x, sizeof(double) * IMG);
-    memcpy(host->grid_y, t->grid_y, sizeof(double) * IMG);
+    const int img = t->img_size ? t->img_size : IMG;
+    for (int i = 0; i < IMG; ++i) {                      // lanes / rows >= img repeat the last grid value (never inside)
+        host->grid_x[i] = t->grid_x[i < img ? i : img - 1];
+        host->grid_y[i] = t->grid_y[i < img ? i : img - 1];
+    }
     hipError_t e = hipMalloc((void**)&env->tt_dev, sizeof(TaskTable));
     if (e == hipSuccess) e = hipMemcpy(env->tt_dev, host, sizeof(TaskTable), hipMemcpyHostToDevice);
     delete host;
@@ -113,6 +117,7 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     c.debug = t->debug;
     c.env_id_base = t->env_id_base;
     c.n_shapes = t->n_shapes;
+    c.img = img;
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -389,14 +394,21 @@ static int grid_for_waves(int64_t n_items) {
     return (int)blocks;
 }
 
-int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
-                   const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream) {
+int bridges_raster_sized(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                         const double* grid_x, const double* grid_y, int32_t size, uint64_t* bits, float* img,
+                         void* stream) {
     if (n < 0 || !shapes_dev) return fail_arg("bridges_raster");
+    if (size < 2 || size > IMG) return fail_arg("bridges_raster: image size must be 2..64");
     if (n == 0) return BRIDGES_OK;
     hipLaunchKernelGGL(k_raster_generic, dim3(grid_for_waves(n)), dim3(256), 0, (hipStream_t)stream, shapes_dev, n,
-                       verts, shape_id, grid_x, grid_y, bits, img);
+                       verts, shape_id, grid_x, grid_y, (int)size, bits, img);
     LAUNCH_CHECK("k_raster_generic");
     return BRIDGES_OK;
+}
+
+int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                   const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream) {
+    return bridges_raster_sized(shapes_dev, n, verts, shape_id, grid_x, grid_y, IMG, bits, img, stream);
 }
 
 int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream) {

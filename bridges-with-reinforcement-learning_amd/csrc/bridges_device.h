@@ -61,19 +61,14 @@ __device__ __forceinline__ void align_place(const Frame2& f1, double c2x, double
 // Conservative image-row window of a block spanning z in [zmin, zmax]: one extra pixel row either side; outside it
 // every pixel fails some half-plane test by a margin of ~0.08 world units >> 1 ulp, so skipping the rows cannot
 // change a bit of the raster.  grid_y = np.linspace(ylim1, ylim0, 64) (row 0 = top).
-__device__ __forceinline__ void row_window2(double gy_first, double gy_last, double zmin, double zmax, int& r_lo, int& r_hi) {
-    const double ytop = gy_first, dy = (gy_first - gy_last) / (double)(IMG - 1);
+// n_rows = image height S <= 64 (gy_last = grid_y[S - 1]); images smaller than 64x64 live in the top-left S x S
+// corner of the 64x64 canvas.
+__device__ __forceinline__ void row_window2(double gy_first, double gy_last, int n_rows, double zmin, double zmax, int& r_lo, int& r_hi) {
+    const double ytop = gy_first, dy = (gy_first - gy_last) / (double)(n_rows - 1);
     r_lo = (int)floor((ytop - zmax) / dy) - 1;
     r_hi = (int)ceil((ytop - zmin) / dy) + 1;
     r_lo = r_lo < 0 ? 0 : r_lo;
-    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
-}
-__device__ __forceinline__ void row_window(const double* gy, double zmin, double zmax, int& r_lo, int& r_hi) {
-    const double ytop = gy[0], dy = (gy[0] - gy[IMG - 1]) / (double)(IMG - 1);
-    r_lo = (int)floor((ytop - zmax) / dy) - 1;
-    r_hi = (int)ceil((ytop - zmin) / dy) + 1;
-    r_lo = r_lo < 0 ? 0 : r_lo;
-    r_hi = r_hi > IMG - 1 ? IMG - 1 : r_hi;
+    r_hi = r_hi > n_rows - 1 ? n_rows - 1 : r_hi;
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -155,7 +150,7 @@ struct DevCtx {
     const TaskTable* tt;
     int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
     int32_t debug, env_id_base;     // debug bit0: skip the LPs (timing experiments only)
-    int32_t n_shapes, pad_;
+    int32_t n_shapes, img;            // img: image width = height S <= 64 (64 = the reference's default)
     int32_t group_shape[BRIDGES_MAX_GROUPS];
     int32_t group_face[BRIDGES_MAX_GROUPS];
     double mu, density, floor_hw, floor_depth;

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
     // everything the env id addresses is requested at once and staged in LDS (see k_step)
     if (lane < 32) xg_l[lane] = c.tt->x_ground[lane];
     if (lane < 8) offs_l[lane] = c.tt->offsets[lane];
-    if (lane < 2) gy_l[lane] = c.tt->grid_y[lane * (IMG - 1)];
+    if (lane < 2) gy_l[lane] = c.tt->grid_y[lane * (c.img - 1)];
     const int nb = c.b.n_blocks[e];
     const int ncand = c.b.n_cand[e];
     const size_t off = (size_t)c.b.cand_offset[e];
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
             }
 #undef PICK6
             int r_lo, r_hi;
-            row_window2(gy_l[0], gy_l[1], zmin, zmax, r_lo, r_hi);
+            row_window2(gy_l[0], gy_l[1], c.img, zmin, zmax, r_lo, r_hi);
             c.b.cand_rows[ci * 2 + 0] = r_lo | (r_hi << 8) | (sn.nv << 16) | ((inb ? 1 : 0) << 24);   // packed for the rasteriser
             c.b.cand_rows[ci * 2 + 1] = e;
         }
@@ -581,7 +581,7 @@ __device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, in
 // Rasterise one convex outline from its world face frames.  Lane = pixel column; returns the row masks with row r
 // in lane r.  `frames` = [nv][4] (centre.xz, normal.xz), gyv = this lane's grid_y value (lane r holds Y[r]).
 // If s_w != nullptr (LDS copy of the reward map) also accumulates sum(inside * reward_map) into *lin (per lane).
-__device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, int r_lo, int r_hi, double X, double gyv,
+__device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, int r_lo, int r_hi, int n_cols, double X, double gyv,
                                                   const float* s_w, double* lin, int lane) {
     double fr0 = 0.0, fr1 = 0.0, fr2 = 0.0, fr3 = 0.0;
     if (lane < nv) {
@@ -598,9 +598,10 @@ __device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, 
         txf[f] = (X - cxf) * nxf;
     }
     uint64_t mybits = 0ull;
+    const bool col_ok = lane < n_cols;         // images narrower than the 64-lane canvas: columns >= S stay empty
     for (int r = r_lo; r <= r_hi; ++r) {
         const double Y = readlane_d(gyv, r);
-        bool in = true;
+        bool in = col_ok;
 #pragma unroll
         for (int f = 0; f < MAXV; ++f) {
             if (f < nv) {
@@ -634,7 +635,7 @@ __device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, 
 
 // Same from world vertices (stand-alone operator): frames are derived first (oracle/raster.py contains_2d).
 __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, int nv, const int32_t* fa,
-                                                   const int32_t* fb, const double* gx, const double* gy, int lane) {
+                                                   const int32_t* fb, const double* gx, const double* gy, int size, int lane) {
     double cx = 0.0, cz = 0.0, nx = 0.0, nz = 0.0, myz = 0.0;
     if (lane < nv) {
         Frame2 fr = edge_frame(v[2 * fa[lane]], v[2 * fa[lane] + 1], v[2 * fb[lane]], v[2 * fb[lane] + 1]);
@@ -644,8 +645,9 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
     const double zmin = wave_min_d(lane < nv ? myz : 1e300);
     const double zmax = wave_max_d(lane < nv ? myz : -1e300);
     int r_lo, r_hi;
-    row_window(gy, zmin, zmax, r_lo, r_hi);
-    const double X = gx[lane];
+    row_window2(gy[0], gy[size - 1], size, zmin, zmax, r_lo, r_hi);
+    const bool col_ok = lane < size;
+    const double X = gx[col_ok ? lane : 0];
     double txf[MAXV], czf[MAXV], nzf[MAXV];
 #pragma unroll
     for (int f = 0; f < MAXV; ++f) {
@@ -657,7 +659,7 @@ __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, in
     uint64_t mybits = 0ull;
     for (int r = r_lo; r <= r_hi; ++r) {
         const double Y = gy[r];
-        bool in = true;
+        bool in = col_ok;
 #pragma unroll
         for (int f = 0; f < MAXV; ++f) {
             if (f < nv) {
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c, int item_begin, int it
             double linp = 0.0;
             uint64_t bits = 0ull;
             if (!(c.debug & 2))
-                bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, c.tt->grid_x[lane], c.tt->grid_y[lane],
+                bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, c.img, c.tt->grid_x[lane], c.tt->grid_y[lane],
                                      c.b.reward_map, &linp, lane);
             const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | c.b.obstacle_bits[lane];
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;

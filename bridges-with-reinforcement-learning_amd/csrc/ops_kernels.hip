@@ -131,13 +131,13 @@ __global__ void k_contains_points(const bridges_shape* shapes, int shape_id, con
 // K4: one wave per posed outline (world vertices in shape-vertex order).
 __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* shapes, int n, const double* verts,
                                                         const int32_t* shape_id, const double* gx, const double* gy,
-                                                        uint64_t* bits, float* img) {
+                                                        int size, uint64_t* bits, float* img) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     for (int it = wave; it < n; it += nwaves) {
         const bridges_shape& sh = shapes[shape_id[it]];
-        uint64_t b = raster_outline(verts + (size_t)it * MAXV * 2, sh.nv, sh.fa, sh.fb, gx, gy, lane);
+        uint64_t b = raster_outline(verts + (size_t)it * MAXV * 2, sh.nv, sh.fa, sh.fb, gx, gy, size, lane);
         if (bits) bits[(size_t)it * IMG + lane] = b;
         if (img) write_f32_image(img + (size_t)it * IMG * IMG, b, lane);
     }

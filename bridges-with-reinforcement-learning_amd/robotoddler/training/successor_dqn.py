@@ -43,34 +43,31 @@ Transition = namedtuple('Transition',
                          'next_reward_features', 'next_obstacle_features', 'td_error'))
 
 
-def _check_img(img_size):
-    if tuple(img_size) != (64, 64):
-        raise NotImplementedError("the HIP rasteriser renders 64x64 images")
+def _image(bits, img_size):
+    """bit raster(s) -> f32 [n, S, S] (contiguous)."""
+    return ops.crop(ops.bits_to_f32(bits), img_size).contiguous()
 
 
 # ---- feature extraction (successor_dqn.py:47-94) ---------------------------------------------------------------
 def get_state_features(observation, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
-    _check_img(img_size)
     binary = [observation['stable'], observation['collision'], observation['collision_block'],
               observation['collision_obstacle'], observation['collision_floor'], observation['collision_boundary']]
-    image = ops.bits_to_f32(render_blocks_2d_bits(observation['blocks'], xlim, ylim))      # [1,64,64] f32
+    image = _image(render_blocks_2d_bits(observation['blocks'], xlim, ylim, img_size), img_size)      # [1,S,S] f32
     return image.to(device), torch.tensor(binary, dtype=torch.float32, device=image.device).to(device)
 
 
 def get_task_features(obs, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
-    _check_img(img_size)
     cube = Shape(urdf_file='shapes/cube06.urdf')
     target_blocks = [Block(shape=cube, position=target) for target in obs['targets']]
-    reward = ops.bits_to_f32(render_blocks_2d_bits(target_blocks, xlim, ylim))[0]
+    reward = _image(render_blocks_2d_bits(target_blocks, xlim, ylim, img_size), img_size)[0]
     reward = convolve_with_gaussian(reward, 101, 16)                                      # successor_dqn.py:80-82
-    obstacle = ops.bits_to_f32(render_blocks_2d_bits(obs['obstacle_blocks'], xlim, ylim))
+    obstacle = _image(render_blocks_2d_bits(obs['obstacle_blocks'], xlim, ylim, img_size), img_size)
     return reward.unsqueeze(0).to(device), obstacle.to(device)
 
 
 def get_action_features(env, actions, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
-    _check_img(img_size)
     blocks = [env.create_block(action) for action in actions]
-    return ops.bits_to_f32(ops.raster_bits(blocks, xlim, ylim)).unsqueeze(1).to(device)   # [A,1,64,64]
+    return _image(ops.raster_bits(blocks, xlim, ylim, img_size), img_size).unsqueeze(1).to(device)   # [A,1,S,S]
 
 
 # ---- policies (successor_dqn.py:98-132) -------------------------------------------------------------------------
@@ -94,6 +91,8 @@ class EpsilonGreedy:
         if step_index >= len(self.step_images):            # the reference indexes past max_steps=10 (latent IndexError)
             self.step_images += [torch.zeros(64, 64, device=self.device) for _ in range(step_index + 1 - len(self.step_images))]
         feats = action_features.squeeze(1).to(self.device)
+        if self.step_images[step_index].shape != feats.shape[-2:]:       # --image_size other than the 64x64 default
+            self.step_images[step_index] = torch.zeros(feats.shape[-2:], device=self.device)
         join = torch.sum(self.step_images[step_index] * feats, dim=(-1, -2))
         sel = torch.argmin(join).item()
         self.step_images[step_index] += feats[sel]

@@ -48,12 +48,13 @@ class VecDQN:
         self.sample_gen = torch.Generator(device=self.device).manual_seed(1234567 + seed)
         self.explore_gen = torch.Generator(device=self.device).manual_seed(7654321 + seed * 1000 + rank)
         self.epsilon, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
-        self.step_images = torch.zeros((env.K + 1, 64, 64), dtype=torch.float32, device=self.device)
+        self.step_images = torch.zeros((env.K + 1, env.img, env.img), dtype=torch.float32, device=self.device)
         # scratch env used to rebuild the candidate sets of sampled next states (see _replay_env)
         self.replay_env = VecAssemblyGym(batch_size, env.shapes, env.obstacles, env.targets, max_steps=env.max_steps,
                                          mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
                                          ylim=env.ylim, x_discr_ground=env.x_discr_ground,
-                                         offset_values=env.offset_values, device=self.device, a_max=env.a_max)
+                                         offset_values=env.offset_values, device=self.device, a_max=env.a_max,
+                                         img_size=(env.img, env.img))
         self.mse = torch.nn.MSELoss()
         for g in optimizer.param_groups:                # step counter on the device: the train step is graph-captured
             if 'capturable' in g:
@@ -81,8 +82,8 @@ class VecDQN:
     # ------------------------------------------------------------------ features of the rows a net is fed
     def _row_features(self, env, idx, row_env, stable_flag):
         n = idx.numel()
-        block = env.state_raster[row_env].unsqueeze(1)
-        action = env.cand_raster[idx].unsqueeze(1)
+        block = env.crop(env.state_raster[row_env]).unsqueeze(1)         # crop: no-op for the 64x64 default
+        action = env.crop(env.cand_raster[idx]).unsqueeze(1)
         binary = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
         binary[:, 0] = stable_flag[row_env].float()
         reward = env.reward_features.unsqueeze(0).expand(n, -1, -1, -1)
@@ -92,8 +93,10 @@ class VecDQN:
     @staticmethod
     def _factored(net):
         """Acting through the factored SuccessorMLP forward on bit-packed rasters (BRIDGES_FACTORED_ACT=0: the plain
-        module forward on f32 rasters)."""
-        return hasattr(net, "q_from_first_layer") and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0"
+        module forward on f32 rasters).  The bit-packed first layer is built for 64x64 images; other --image_size
+        values act through the module forward."""
+        return (hasattr(net, "q_from_first_layer") and tuple(getattr(net, "img_size", (64, 64))) == (64, 64)
+                and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0")
 
     @classmethod
     def acting_needs_f32_rasters(cls, net):
@@ -173,7 +176,7 @@ class VecDQN:
                 counts_t[:, :ks] = self.step_images.reshape(ks, px).T
                 join = ops.bits_linear(env.cand_bits, counts_t, bits_row=idx).gather(1, step_of_row[:, None])[:, 0]
             else:
-                join = (self.step_images[step_of_row] * env.cand_raster[idx]).sum(dim=(1, 2))
+                join = (self.step_images[step_of_row] * env.crop(env.cand_raster[idx])).sum(dim=(1, 2))
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
             nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
             _, _, arg_q = dqn_ops.td_target(seg, q.contiguous().float(), zeros, nodone, 1.0)       # segmented argmax
@@ -185,7 +188,7 @@ class VecDQN:
             ex = explore & has
             if ex.any():
                 rows = sel_row[ex]
-                self.step_images.index_add_(0, step_of_row[rows], ops.bits_to_f32(env.cand_bits[idx[rows]]))
+                self.step_images.index_add_(0, step_of_row[rows], env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])))
             sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
             self._q_sel = torch.where(has, q.float()[sel_row.clamp(max=idx.numel() - 1)], self._q_sel)
         else:
@@ -205,7 +208,8 @@ class VecDQN:
             self.replay_env = VecAssemblyGym(n_states, env.shapes, env.obstacles, env.targets, max_steps=env.max_steps,
                                              mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
                                              ylim=env.ylim, x_discr_ground=env.x_discr_ground,
-                                             offset_values=env.offset_values, device=self.device, a_max=env.a_max)
+                                             offset_values=env.offset_values, device=self.device, a_max=env.a_max,
+                                         img_size=(env.img, env.img))
         return self.replay_env
 
     @torch.no_grad()
@@ -226,8 +230,8 @@ class VecDQN:
         # prefix of its block list, so its raster comes out of the same per-block bit rasters
         renv.load_states(nnb, nshape, npose, nocc)
         bits_s = renv.prefix_state_bits(nb)
-        block_f = ops.bits_to_f32(bits_s).unsqueeze(1)
-        action_f = ops.bits_to_f32(renv.state_bits & ~bits_s).unsqueeze(1)                     # s' minus s = the new block
+        block_f = renv.crop(ops.bits_to_f32(bits_s)).unsqueeze(1)
+        action_f = renv.crop(ops.bits_to_f32(renv.state_bits & ~bits_s)).unsqueeze(1)         # s' minus s = the new block
         idx, row_env = renv.valid_rows()
         seg, counts = self._segments(row_env, E, self.device)
         done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)
@@ -275,7 +279,7 @@ class VecDQN:
         train step is exactly one graph launch (eager PyTorch needs ~60 launches of a few microseconds of work each
         and is bound by their launch latency)."""
         B, dev = self.B, self.device
-        px = (64, 64)
+        px = (self.env.img, self.env.img)
         st = dict(block=torch.zeros((n_max * B, 1, *px), device=dev), binary=torch.zeros((n_max * B, 6), device=dev),
                   action=torch.zeros((n_max * B, 1, *px), device=dev), q=torch.zeros(n_max * B, device=dev),
                   sf=torch.zeros((n_max * B, px[0] * px[1]), device=dev) if use_sf else None,
@@ -434,7 +438,8 @@ def run_vectorised(args, device):
     policy_net, target_net = make_nets(args, device)
     env = VecAssemblyGym(args['num_envs'], geoms, obstacles, targets, max_steps=args['max_steps'],
                          seed=seed * 1000003 + rank, device=device, env_id_base=rank * args['num_envs'],
-                         f32_rasters=VecDQN.acting_needs_f32_rasters(policy_net))
+                         f32_rasters=VecDQN.acting_needs_f32_rasters(policy_net),
+                         img_size=args.get('image_size') or (64, 64))
     opt = torch.optim.Adam(policy_net.parameters(), lr=args['learning_rate'], fused=True)    # one launch for all tensors
     capacity = max(args['replay_buffer_capacity'], 4 * args['num_envs'] * world)
     agent = VecDQN(policy_net, target_net, opt, env, capacity, args['batch_size'], args['gamma'], args['tau'],

@@ -73,7 +73,9 @@ typedef struct {
     int32_t n_targets;
     int32_t debug;             /* 0; bit0 = skip the LPs (kernel timing experiments only) */
     int32_t env_id_base;       /* global id of env 0 (policy RNG stream = seed, env_id_base + e) */
-    int32_t pad_;
+    int32_t img_size;          /* S of the S x S images (--image_size, successor_dqn.py:585); 0 = 64.  S < 64: every
+                                  image buffer keeps its 64x64 / 64-word layout and the image is its top-left S x S
+                                  corner (the rest is zero) */
     double mu, density;        /* assembly_env.py:164 */
     double floor_half_width;   /* assembly_env.py:290-296 */
     double floor_depth;
@@ -83,8 +85,8 @@ typedef struct {
     const bridges_shape* shapes;   /* HOST pointer, n_shapes entries (copied) */
     const double* x_ground;        /* HOST, n_ground */
     const double* offsets;         /* HOST, n_offsets */
-    const double* grid_x;          /* HOST, 64: np.linspace(xlim0, xlim1, 64) */
-    const double* grid_y;          /* HOST, 64: np.linspace(ylim1, ylim0, 64) */
+    const double* grid_x;          /* HOST, S: np.linspace(xlim0, xlim1, S) */
+    const double* grid_y;          /* HOST, S: np.linspace(ylim1, ylim0, S) */
 } bridges_task;
 
 /* Caller-owned device buffers of a vectorised environment.  E = n_envs,
@@ -222,6 +224,11 @@ int bridges_contains_points(const bridges_shape* shapes_dev, int32_t shape_id, c
  * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */
 int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
                    const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream);
+/* The same for S x S images, 2 <= S <= 64 (render_blocks_2d's img_size argument, rendering.py:105): grid_x/grid_y
+ * hold S values; the outputs keep the 64-word / 64x64 layout, the image is the top-left S x S corner, the rest 0. */
+int bridges_raster_sized(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                         const double* grid_x, const double* grid_y, int32_t size, uint64_t* bits, float* img,
+                         void* stream);
 /* OR-reduce groups of bit rasters: out[g] = OR bits[ranges[g][0] .. ranges[g][1]);  ranges int32 [n_groups,2]. */
 int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream);
 /* bit raster -> f32 image. */

@@ -121,8 +121,41 @@ def test_render_and_stabilities_freezing_match_oracle():
         assert env.stabilities_freezing() == og.stabilities_freezing()
         img = render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10), img_size=(64, 64))
         assert np.array_equal(img, og.state_raster())
+        for size in (48, 16):                                   # render_blocks_2d's img_size argument, S <= 64
+            from oracle import raster as o_raster
+            small = render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10), img_size=(size, size))
+            assert small.shape == (size, size)
+            assert np.array_equal(small, o_raster.render_blocks_2d(og.blocks, (-3, 7), (0, 10), (size, size)))
         for b, ob in zip(obs["blocks"], og.blocks):
             assert np.array_equal(b.verts_2d, np.array(ob.verts))
+
+
+def test_feature_functions_at_a_smaller_image_size():
+    """get_state_features / get_task_features / get_action_features with --image_size 32x32 (successor_dqn.py:47-94,
+    585) against the numpy oracle rendered at that size."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import Action, AssemblyGym, bridge_setup, sparse_reward
+    from oracle import raster as o_raster
+    from oracle.env import OracleGym
+    from oracle.env import bridge_setup as o_bridge_setup
+    from robotoddler.training.successor_dqn import get_action_features, get_state_features, get_task_features
+    size, lim = (32, 32), dict(xlim=(-3, 7), ylim=(0, 10))
+    env = AssemblyGym(**bridge_setup(num_stories=2), reward_fct=sparse_reward, restrict_2d=True, max_steps=10,
+                      assembly_env=AssemblyEnv(render=False))
+    og = OracleGym(**o_bridge_setup(num_stories=2), max_steps=10, img_size=size)
+    obs, _ = env.reset()
+    obs, *_ = env.step(Action(-1, 0, 0, 3, -1.3333333333333335, 0.0))
+    og.step((-1, 0, 0, 3, -1.3333333333333335, 0.0))
+    image, binary = get_state_features(obs, img_size=size, **lim)
+    assert tuple(image.shape) == (1, 32, 32) and np.array_equal(image[0].cpu().numpy().astype(bool), og.state_raster())
+    reward, obstacle = get_task_features(obs, img_size=size, **lim)
+    np.testing.assert_allclose(reward[0].cpu().numpy(), og.reward_map, rtol=1e-5, atol=1e-7)
+    assert np.array_equal(obstacle[0].cpu().numpy().astype(bool), og.obstacle_raster)
+    cand = og.candidates()
+    actions = [Action(*a) for a in cand["actions"]]
+    feats = get_action_features(env, actions, img_size=size, **lim)
+    assert tuple(feats.shape) == (len(actions), 1, 32, 32)
+    assert np.array_equal(feats[:, 0].cpu().numpy().astype(bool), cand["rasters"])
 
 
 def test_contains_2d_points_and_scripted_rollout():

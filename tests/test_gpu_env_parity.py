@@ -16,6 +16,15 @@ def bits_to_bool(bits_row):
     return ((u[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
 
 
+def canvas_equals(bits_row, image):
+    """The 64x64 canvas of ``bits_row`` holds the S x S ``image`` in its top-left corner and nothing else."""
+    canvas = bits_to_bool(bits_row)
+    h, w = image.shape
+    ref = np.zeros((64, 64), dtype=bool)
+    ref[:h, :w] = image
+    return np.array_equal(canvas, ref)
+
+
 class _ShapeSpec:
     """A shape with the reference's optional face restrictions (gym_env.py:82-88 hard_tower_setup)."""
 
@@ -62,11 +71,11 @@ def compare_candidates(vec, oracles, check_f32=True):
             assert tuple(pose[off[e] + i]) == (b.pos[0], b.pos[1], b.cs[0], b.cs[1]), (e, i)
             nv = len(b.verts)
             assert np.array_equal(verts[off[e] + i, :nv], np.array(b.verts)), (e, i)
-            assert np.array_equal(bits_to_bool(bits[off[e] + i]), c["rasters"][i]), (e, i)
+            assert canvas_equals(bits[off[e] + i], c["rasters"][i]), (e, i)
         assert np.array_equal(mask[sl].astype(bool), c["mask"]), e
         assert nvalid[e] == int(c["mask"].sum())
         np.testing.assert_allclose(lin[sl], c["lin_reward"], rtol=1e-5, atol=1e-6)
-        assert np.array_equal(bits_to_bool(sbits[e]), c["state"]), e
+        assert canvas_equals(sbits[e], c["state"]), e
     if check_f32 and vec.cand_raster is not None:
         total = int(off[-1])
         img = vec.cand_raster[:total].cpu().numpy()
@@ -128,6 +137,31 @@ def test_tower_lockstep_parity(tower_height, max_steps):
     st = vec.read_stats()
     assert st["lp_errors"] == 0 and st["if_overflow"] == 0
     assert st["env_steps"] == n
+
+
+@pytest.mark.parametrize("size", [32, 17])
+def test_smaller_image_sizes_parity(size):
+    """--image_size S x S with S < 64 (successor_dqn.py:585): every image is the top-left S x S corner of the 64x64
+    canvas the kernels write, bit-exact with the numpy oracle rendered at that size (rasters, overlap masks, linear
+    rewards against the S x S reward map), and the rest of the canvas stays zero."""
+    E, seed = 24, 5
+    vec, oracles = make_pair(dict(num_stories=3), bridge_setup, E, 12, seed, ["trapezoid"], img_size=(size, size))
+    g = oracles[0].gym
+    assert canvas_equals(vec.obstacle_bits.cpu().numpy(), g.obstacle_raster)
+    assert tuple(vec.reward_features.shape) == (1, size, size) and tuple(vec.obstacle_raster.shape) == (1, size, size)
+    np.testing.assert_allclose(vec.reward_features[0].cpu().numpy(), g.reward_map, rtol=1e-5, atol=1e-7)
+    rm = vec.reward_map.cpu().numpy()
+    assert not rm[size:].any() and not rm[:, size:].any()
+    n = run_lockstep_parity(vec, oracles, seed, n_lock=14)
+    assert n > E * 6
+    total = vec.total_candidates()
+    img = vec.crop(vec.cand_raster[:total])
+    assert tuple(img.shape[1:]) == (size, size)
+    assert float(vec.cand_raster[:total].sum()) == float(img.sum())          # nothing outside the corner
+    with pytest.raises(NotImplementedError):
+        make_pair(dict(num_stories=2), bridge_setup, 2, 5, 0, ["trapezoid"], img_size=(128, 128))
+    with pytest.raises(NotImplementedError):
+        make_pair(dict(num_stories=2), bridge_setup, 2, 5, 0, ["trapezoid"], img_size=(64, 32))
 
 
 def test_sparse_raster_update_gives_the_same_images():

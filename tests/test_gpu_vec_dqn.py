@@ -52,7 +52,9 @@ HEX_BRIDGE = ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"
                                              ("ConvNet", "mse_q_values", TOWER2),
                                              ("UNet", "mse_block_features", TOWER2),
                                              ("UNet", "mse_q_values+mse_block_features", HEX_BRIDGE),
-                                             ("SuccessorMLP", "mse_q_values", TOWER2 + ["--prioritized_replay"])])
+                                             ("SuccessorMLP", "mse_q_values", TOWER2 + ["--prioritized_replay"]),
+                                             ("SuccessorMLP", "mse_q_values+mse_block_features", TOWER2 + ["--image_size", "32x32"]),
+                                             ("ConvNet", "mse_q_values", TOWER2 + ["--image_size", "32x32"])])
 def test_vectorised_training_runs(model, loss, task):
     from robotoddler.training.successor_dqn import build_parser, main
     hist = main(["--model", model, "--loss_function", loss, *task, "--num_envs", "64", "--num_episodes", "150",
@@ -238,7 +240,7 @@ def test_vectorised_loop_writes_reference_layout_checkpoints(tmp_path):
     assert blob["records"].shape[0] > 0
 
 
-@pytest.mark.parametrize("extra", [[], ["--prioritized_replay"]])
+@pytest.mark.parametrize("extra", [[], ["--prioritized_replay"], ["--image_size", "32x32"]])
 def test_single_env_reference_loop_runs(extra):
     from robotoddler.training.successor_dqn import main
     hist = main(["--model", "SuccessorMLP", "--loss_function", "mse_q_values+mse_block_features", "--tower_height", "2",
