@@ -40,12 +40,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 PMC_FILE = os.path.join("profiles", "r02_pmc_k_raster.json")
 
 
-def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4):
+def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4, f32_rasters=True):
     """bytes one lock-step must move for `n_envsteps_units` environments holding
-    sum_blocks blocks and sum_cand raw candidates in total (f32 rasters as the reference surfaces them)."""
+    sum_blocks blocks and sum_cand raw candidates in total (f32 rasters as the reference surfaces them; with
+    f32_rasters=False the images exist only as 64 x u64 row masks, 512 B each)."""
     A, k, E = float(sum_cand), float(sum_blocks), float(n_envsteps_units)
-    return (4 * 64 * 64 * (A + E)          # action + state rasters written
-            + 2 * 4 * 64 * 64 * E          # state + obstacle rasters read for the overlap test
+    px = 4 * 64 * 64 if f32_rasters else 8 * 64
+    return (px * (A + E)                   # action + state rasters written
+            + 2 * px * E                   # state + obstacle rasters read for the overlap test
             + 8 * 2 * V * (k + A)          # vertex reads, f64
             + 24 * (k + A)                 # poses
             + 16 * A + A + 4 * A           # candidate descriptors, mask, lin_reward
@@ -357,7 +359,7 @@ def main():
             traffic_ratio = pm["hbm_bytes_per_launch"] / pm["algorithmic_bytes_per_launch"]
         except Exception:
             traffic_ratio = None
-        alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units, V)
+        alg = algorithmic_bytes(d["sum_cand"], d["sum_blocks"], units, V, f32_rasters=not args.no_f32_rasters)
         per_launch = alg / max(n_launch, 1)
         avg_ms = raster_ms / max(n_launch, 1)
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -409,6 +411,17 @@ def main():
                 "whole_step_GBps": alg / dt / 1e9,
             },
         }
+        if args.no_f32_rasters:
+            out["roofline"]["traffic"] = None        # the PMC ratio was taken on the f32 rasteriser
+            out["roofline"]["note"] = ("bit-packed mode: 512 B per image, the rasteriser is bound by its f64 half-plane "
+                                       "tests, not by HBM; frac is reported for completeness only")
+        if args.sparse_raster_update:
+            # the kernel stores only the row groups that hold or held pixels, so bytes-of-the-full-rewrite over its
+            # launch time is not a bandwidth: no roofline figure is claimed for this mode
+            out["roofline"] = {"bound": "hbm", "kernel": "k_raster", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": None, "traffic": None, "avg_launch_ms": avg_ms, "launches": n_launch,
+                               "note": "sparse row-group update stores fewer bytes than the full rewrite the §8(d) "
+                                       "formula counts; stored bytes are not counted in this run"}
         if cand_mode:
             torch.cuda.synchronize()
             ms = sum(a.elapsed_time(b) for a, b in cand_ev)
