@@ -8,6 +8,7 @@
 #include "env_kernels.hip"
 #include "ops_kernels.hip"
 #include "dqn_kernels.hip"
+#include "mlp_kernels.hip"
 
 using namespace bridges;
 
@@ -544,6 +545,103 @@ int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_bias_relu_pool2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, out, items, H, W, C);
     LAUNCH_CHECK("k_bias_relu_pool2");
+    return BRIDGES_OK;
+}
+
+// ---- small-batch MLP training step (mlp_kernels.hip) ------------------------------------------------------------
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, const float* W, const float* bias,
+                           int32_t relu, float* y, float* ws, int64_t ws_floats, void* stream) {
+    if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !x || !W || !bias || !y) return fail_arg("bridges_linear_forward: rows must be a positive multiple of 32");
+    const int n_tiles = ceil_div(N, 32), m_tiles = rows / 32;
+    // enough workgroups to fill the chip; a split holds at least 64 k values and its partial sums must fit in ws
+    // (a short K or enough output tiles: one launch, no partial sums)
+    int splits = (K <= 512 || n_tiles * m_tiles >= 128) ? 1 : ceil_div(512, n_tiles * m_tiles);
+    const int max_by_k = ceil_div(K, 64);
+    if (splits > max_by_k) splits = max_by_k;
+    const int64_t per_split = (int64_t)rows * N;
+    if (!ws || (int64_t)splits * per_split > ws_floats) splits = ws ? (int)(ws_floats / per_split) : 1;
+    if (splits < 1) splits = 1;
+    int kchunk = ceil_div(ceil_div(K, splits), 32) * 32;
+    splits = ceil_div(K, kchunk);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_lin_fwd, dim3(n_tiles, splits, m_tiles), dim3(256), 0, st, K, N, kchunk, x, W, bias, relu, y,
+                       splits > 1 ? ws : (float*)nullptr);
+    LAUNCH_CHECK("k_lin_fwd");
+    if (splits > 1) {
+        int blocks = ceil_div(rows * N, 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_lin_fwd_finish, dim3(blocks), dim3(256), 0, st, rows, N, splits, ws, bias, relu, y);
+        LAUNCH_CHECK("k_lin_fwd_finish");
+    }
+    return BRIDGES_OK;
+}
+
+int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                            float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                            void* stream) {
+    if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !dz || !a_in || !W || !dW || !db) return fail_arg("bridges_linear_backward");
+    const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32), m_tiles = rows / 32;
+    int per_job = ceil_div(n_ntiles * n_ktiles, 1024);           // k tiles per dW job: ~1024 jobs on the big layers
+    if (per_job < 4) per_job = 4;                                 // one tile per wave at least
+    const int n_dw_jobs = n_ntiles * ceil_div(n_ktiles, per_job);
+    int nsplit = 0, nchunk = 0, n_dx_jobs = 0;
+    if (dz_below) {
+        if (!ws) return fail_arg("bridges_linear_backward: workspace needed for the input gradient");
+        nsplit = (N <= 512) ? 1 : ceil_div(256, n_ktiles * m_tiles);
+        const int max_by_n = ceil_div(N, 64);
+        if (nsplit > max_by_n) nsplit = max_by_n;
+        const int64_t per_split = (int64_t)rows * K;
+        if ((int64_t)nsplit * per_split > ws_floats) nsplit = (int)(ws_floats / per_split);
+        if (nsplit < 1) return fail_arg("bridges_linear_backward: workspace too small");
+        nchunk = ceil_div(ceil_div(N, nsplit), 32) * 32;
+        nsplit = ceil_div(N, nchunk);
+        n_dx_jobs = n_ktiles * nsplit * m_tiles;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // one split: the input gradient goes straight to dz_below (masked), no partial sums
+    hipLaunchKernelGGL(k_lin_bwd, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
+                       !dz_below ? (float*)nullptr : (nsplit == 1 ? dz_below : ws), nsplit == 1 ? act_below : (const float*)nullptr,
+                       n_dw_jobs, per_job, nsplit, nchunk);
+    LAUNCH_CHECK("k_lin_bwd");
+    if (dz_below && nsplit > 1) {
+        int blocks = ceil_div(rows * K, 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_lin_dx_finish, dim3(blocks), dim3(256), 0, st, rows, K, nsplit, ws, act_below, dz_below);
+        LAUNCH_CHECK("k_lin_dx_finish");
+    }
+    return BRIDGES_OK;
+}
+
+int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
+                      const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
+                      float* x, void* stream) {
+    if (batch <= 0 || rows < batch || (rows & 31) || px <= 0 || nf < 0 || !counter || !block_all || !action_all || !reward || !obstacle || !x)
+        return fail_arg("bridges_mlp_input");
+    int blocks = ceil_div(rows * (4 * px + nf), 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_mlp_input, dim3(blocks), dim3(256), 0, (hipStream_t)stream, batch, rows, px, nf, counter, block_all,
+                       action_all, binary_all, reward, obstacle, x);
+    LAUNCH_CHECK("k_mlp_input");
+    return BRIDGES_OK;
+}
+
+int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* y, const float* reward,
+                           const int64_t* counter, const float* q_target_all, const float* sf_target_all, int32_t use_q,
+                           int32_t use_sf, float* dy, float* loss_rows, float* q_out, float* losses, int32_t n_losses,
+                           int64_t* counter_inc, void* stream) {
+    if (batch <= 0 || rows < batch || px <= 0 || nf < 0 || !y || !reward || !counter || !dy || !loss_rows || !q_out)
+        return fail_arg("bridges_successor_loss");
+    if ((use_q && !q_target_all) || (use_sf && !sf_target_all)) return fail_arg("bridges_successor_loss: target missing");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_successor_loss, dim3(rows), dim3(LOSS_THREADS), 0, st, batch, px, nf, y, reward, counter, q_target_all,
+                       sf_target_all, use_q, use_sf, dy, loss_rows, q_out);
+    LAUNCH_CHECK("k_successor_loss");
+    if (losses && counter_inc) {
+        hipLaunchKernelGGL(k_loss_log, dim3(1), dim3(64), 0, st, batch, loss_rows, losses, n_losses, counter_inc);
+        LAUNCH_CHECK("k_loss_log");
+    }
     return BRIDGES_OK;
 }
 

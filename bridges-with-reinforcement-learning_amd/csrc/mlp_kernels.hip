@@ -1,0 +1,426 @@
+// K9: one optimiser step of SuccessorMLP at replay-batch size (robotoddler/models/cv.py:76-105 forward,
+// robotoddler/training/successor_dqn.py:157-235 train_policy_net) as a handful of launches.
+//
+// At batch 32 every layer is a skinny GEMM ([32 x K] . [K x N]): the weights are streamed exactly once per pass and the
+// work per weight is 2 * 32 flops -- 16 flop/B, more than the vector ALUs deliver at HBM speed, so the products run on
+// the f32 matrix cores (v_mfma_f32_32x32x2_f32: the 32 batch rows ARE the M side of the tile).  The library GEMMs torch
+// picks for these shapes use 16 workgroups for the 16.8 MB first layer (48 us against 3.4 us of weight traffic) and
+// one optimiser step is ~65 launches of ~5 us each; here it is ~25.
+//
+// Operand maps (cdna_hip_programming.md, "Fragment layout"): lane l supplies A[row = l & 31][k = l >> 5] and
+// B[k = l >> 5][col = l & 31]; the accumulator register r of lane l is C[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)]
+// [col = l & 31].  The k order inside a tile is free as long as A and B agree, which lets every lane fetch 16 B.
+#include "bridges_device.h"
+
+namespace bridges {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));       // rows of K = 4 px + 6 floats are only 8-B aligned
+
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Sum of p[s * stride], s < n, eight loads in flight (a dependent chain of n loads costs n memory latencies); the order of
+// the additions is fixed, so the result is reproducible.
+__device__ __forceinline__ float split_sum(const float* __restrict__ p, size_t stride, int n) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int s = 0;
+    for (; s + 8 <= n; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += v[u];
+    }
+    for (int u = 0; s + u < n; ++u) acc[u] += p[(size_t)(s + u) * stride];
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+// Waves 1..3 of a workgroup hand their 32x32 accumulators to wave 0 (fixed summation order: deterministic).
+__device__ __forceinline__ void reduce_to_wave0(f32x16& acc, float (*red)[16][64], int wave, int lane) {
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward: out[m][n] = sum_k x[m][k] * W[n][k] over the K range of this workgroup's split.
+// grid = (ceil(N / 32), splits, rows / 32), 4 waves share the K range.  splits == 1: y = act(out + bias) directly,
+// else part[split][m][n] = out and k_lin_fwd_finish adds the splits up.
+__global__ __launch_bounds__(256) void k_lin_fwd(int K, int N, int kchunk, const float* __restrict__ x,
+                                                 const float* __restrict__ W, const float* __restrict__ bias, int relu,
+                                                 float* __restrict__ y, float* __restrict__ part) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 32, split = blockIdx.y, m0 = blockIdx.z * 32;
+    const int rows = gridDim.z * 32;
+    const int kbeg = split * kchunk;
+    const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+    const int kq = ((kend - kbeg + 31) / 32) * 8;                 // k values per wave, a multiple of 8
+    const int wbeg = kbeg + wave * kq;
+    const int wend = (wbeg + kq < kend) ? wbeg + kq : kend;
+    const int row = lane & 31, half = lane >> 5;
+    const int nrow = (n0 + row < N) ? n0 + row : N - 1;           // columns >= N are computed on a valid row, never stored
+    const float* xp = x + (size_t)(m0 + row) * K + 4 * half;
+    const float* wp = W + (size_t)nrow * K + 4 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int k0 = wbeg;
+    for (; k0 + 64 <= wend; k0 += 64) {                           // 16 loads in flight, then 32 MFMAs
+        f4u a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f4u*>(xp + k0 + 8 * u);
+            b[u] = *reinterpret_cast<const f4u*>(wp + k0 + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = mfma32(a[u].x, b[u].x, acc);
+            acc = mfma32(a[u].y, b[u].y, acc);
+            acc = mfma32(a[u].z, b[u].z, acc);
+            acc = mfma32(a[u].w, b[u].w, acc);
+        }
+    }
+    for (; k0 + 8 <= wend; k0 += 8) {
+        const f4u a = *reinterpret_cast<const f4u*>(xp + k0);
+        const f4u b = *reinterpret_cast<const f4u*>(wp + k0);
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+    }
+    if (k0 < wend) {                                              // fewer than 8 k values left
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + 4 * half + j;
+            const bool ok = kk < wend;
+            const float a = ok ? xp[k0 + j] : 0.f;
+            const float b = ok ? wp[k0 + j] : 0.f;
+            acc = mfma32(a, b, acc);
+        }
+    }
+    reduce_to_wave0(acc, red, wave, lane);
+    if (wave == 0) {
+        const int n = n0 + row;
+        if (n < N) {
+            const float bv = part ? 0.f : bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + mfma_row(r, lane);
+                if (part) {
+                    part[((size_t)split * rows + m) * N + n] = acc[r];
+                } else {
+                    float v = acc[r] + bv;
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    y[(size_t)m * N + n] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lin_fwd_finish(int rows, int N, int splits, const float* __restrict__ part,
+                                                        const float* __restrict__ bias, int relu, float* __restrict__ y) {
+    const size_t total = (size_t)rows * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = split_sum(part + i, total, splits) + bias[i % N];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of one Linear layer, both products in one launch.  dz [rows][N] = gradient at the layer's pre-activation.
+//   jobs [0, n_dw_jobs): dW[n][k] = sum_b dz[b][n] * a[b][k] (32x32 tiles, the batch is the reduction); the jobs of
+//     the first k group also write db[n] = sum_b dz[b][n].
+//   jobs [n_dw_jobs, ...): dxpart[split][b][k] = sum_{n in split} dz[b][n] * W[n][k]  (k_lin_dx_finish adds the splits
+//     and applies the ReLU mask of the layer below; with one split act_mask is given and the masked sum is final).
+__global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const float* __restrict__ dz,
+                                                 const float* __restrict__ a, const float* __restrict__ W,
+                                                 float* __restrict__ dW, float* __restrict__ db,
+                                                 float* __restrict__ dxpart, const float* __restrict__ act_mask,
+                                                 int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, half = lane >> 5;
+    const int n_ntiles = (N + 31) / 32, n_ktiles = (K + 31) / 32;
+    int job = blockIdx.x;
+    if (job < n_dw_jobs) {
+        const int nt = job % n_ntiles, kg = job / n_ntiles;
+        const int n0 = nt * 32;
+        const int ncol = (n0 + row < N) ? n0 + row : N - 1;
+        const int kt_end = ((kg + 1) * ktiles_per_job < n_ktiles) ? (kg + 1) * ktiles_per_job : n_ktiles;
+        int kt = kg * ktiles_per_job + wave;
+        const bool want_db = (kg == 0 && wave == 0);
+        if (rows == 32) {
+            // the common case (one batch tile): A fragments once per wave, B fragments of the next tile in flight while
+            // this tile's MFMAs and stores run
+            float av[16], bv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) av[t] = dz[(size_t)(2 * t + half) * N + ncol];
+            if (want_db) {
+                float sdb = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sdb += av[t];            // rows 2t + half; the other half sits 32 lanes away
+                sdb += __shfl_xor(sdb, 32);
+                if (half == 0 && n0 + row < N) db[n0 + row] = sdb;
+            }
+            if (kt < kt_end) {
+                const int kcol = (kt * 32 + row < K) ? kt * 32 + row : K - 1;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) bv[t] = a[(size_t)(2 * t + half) * K + kcol];
+            }
+            for (; kt < kt_end; kt += 4) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = mfma32(av[t], bv[t], acc);
+                const int k = kt * 32 + row;
+                if (kt + 4 < kt_end) {
+                    const int kcol = ((kt + 4) * 32 + row < K) ? (kt + 4) * 32 + row : K - 1;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) bv[t] = a[(size_t)(2 * t + half) * K + kcol];
+                }
+                if (k < K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = n0 + mfma_row(r, lane);
+                        if (n < N) dW[(size_t)n * K + k] = acc[r];
+                    }
+                }
+            }
+            return;
+        }
+        if (want_db && half == 0 && n0 + row < N) {
+            float sdb = 0.f;
+            for (int b = 0; b < rows; ++b) sdb += dz[(size_t)b * N + n0 + row];
+            db[n0 + row] = sdb;
+        }
+        for (; kt < kt_end; kt += 4) {
+            const int k0 = kt * 32;
+            const int kcol = (k0 + row < K) ? k0 + row : K - 1;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int mb = 0; mb < rows; mb += 32) {
+                float av[16], bv[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const size_t b = (size_t)(mb + 2 * t + half);
+                    av[t] = dz[b * N + ncol];                     // A[i = n][kk = b]
+                    bv[t] = a[b * K + kcol];                      // B[kk = b][j = k]
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = mfma32(av[t], bv[t], acc);
+            }
+            const int k = k0 + row;
+            if (k < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + mfma_row(r, lane);
+                    if (n < N) dW[(size_t)n * K + k] = acc[r];
+                }
+            }
+        }
+        return;
+    }
+    job -= n_dw_jobs;
+    const int kt = job % n_ktiles, split = (job / n_ktiles) % nsplit, mt = job / (n_ktiles * nsplit);
+    const int k0 = kt * 32, m0 = mt * 32;
+    const int kcol = (k0 + row < K) ? k0 + row : K - 1;
+    const int nbeg = split * nchunk;
+    const int nend = (nbeg + nchunk < N) ? nbeg + nchunk : N;
+    const int nq = ((nend - nbeg + 31) / 32) * 8;
+    const int wbeg = nbeg + wave * nq;
+    const int wend = (wbeg + nq < nend) ? wbeg + nq : nend;
+    const float* dzp = dz + (size_t)(m0 + row) * N + 4 * half;   // A[i = b][kk = n]
+    const float* wp = W + (size_t)(4 * half) * K + kcol;          // B[kk = n][j = k]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int n = wbeg;
+    for (; n + 32 <= wend; n += 32) {
+        f4u av[4];
+        float bv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = *reinterpret_cast<const f4u*>(dzp + n + 8 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][j] = wp[(size_t)(n + 8 * u + j) * K];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = mfma32(av[u].x, bv[u][0], acc);
+            acc = mfma32(av[u].y, bv[u][1], acc);
+            acc = mfma32(av[u].z, bv[u][2], acc);
+            acc = mfma32(av[u].w, bv[u][3], acc);
+        }
+    }
+    for (; n < wend; n += 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + 4 * half + j;
+            const bool ok = nn < wend;
+            const float av = ok ? dzp[n + j] : 0.f;
+            const float bv = ok ? wp[(size_t)(n + j) * K] : 0.f;
+            acc = mfma32(av, bv, acc);
+        }
+    }
+    reduce_to_wave0(acc, red, wave, lane);
+    if (wave == 0 && k0 + row < K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mfma_row(r, lane);
+            const size_t o = ((size_t)split * rows + m) * K + k0 + row;
+            float v = acc[r];
+            if (act_mask && !(act_mask[o] > 0.f)) v = 0.f;       // single split: dxpart IS dz of the layer below
+            dxpart[o] = v;
+        }
+    }
+}
+
+// dz_below[b][k] = (sum over splits of dxpart) masked by the ReLU of the layer below (act = its output, > 0 passes).
+__global__ __launch_bounds__(256) void k_lin_dx_finish(int rows, int K, int nsplit, const float* __restrict__ dxpart,
+                                                       const float* __restrict__ act, float* __restrict__ dz_below) {
+    const size_t total = (size_t)rows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = split_sum(dxpart + i, total, nsplit);
+        if (act && !(act[i] > 0.f)) v = 0.f;
+        dz_below[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Input rows of one replay batch: x[b] = [block | action | reward | obstacle | binary] (cv.py:100-103) for the batch
+// `*counter` of the static per-call arrays (block_all / action_all [n][px], binary_all [n][nf]); rows >= batch are 0.
+__global__ __launch_bounds__(256) void k_mlp_input(int batch, int rows, int px, int nf, const int64_t* __restrict__ counter,
+                                                   const float* __restrict__ block_all, const float* __restrict__ action_all,
+                                                   const float* __restrict__ binary_all, const float* __restrict__ reward,
+                                                   const float* __restrict__ obstacle, float* __restrict__ x) {
+    const int K = 4 * px + nf;
+    const size_t total = (size_t)rows * K;
+    const size_t base = (size_t)(*counter) * batch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / K), c = (int)(i % K);
+        float v = 0.f;
+        if (b < batch) {
+            const size_t src = base + b;
+            if (c < px) v = block_all[src * px + c];
+            else if (c < 2 * px) v = action_all[src * px + (c - px)];
+            else if (c < 3 * px) v = reward[c - 2 * px];
+            else if (c < 4 * px) v = obstacle[c - 3 * px];
+            else v = binary_all[src * nf + (c - 4 * px)];
+        }
+        x[i] = v;
+    }
+}
+
+// Head and loss (cv.py:104-108, successor_dqn.py:215-232): y [rows][2 px + 2 nf] = (psi0 | psi1 | binary part).
+//   q[b]   = sum_j softmax(psi0, psi1)[1][j] * reward[j]            (softmax over the two channels = sigmoid(psi1 - psi0))
+//   loss   = [use_q] mean_b (q - q_t)^2 + [use_sf] mean_b mean_j (psi0 - sf_t)^2
+//   dy     = d loss / d y.  One workgroup per batch row: the q reduction and the gradient that needs it stay together.
+#define LOSS_THREADS 1024
+#define LOSS_CACHE 4                    // pixels per thread kept in registers between the two passes (64x64 / 1024)
+__global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int px, int nf, const float* __restrict__ y,
+                                                                 const float* __restrict__ reward,
+                                                                 const int64_t* __restrict__ counter,
+                                                                 const float* __restrict__ q_target_all,
+                                                                 const float* __restrict__ sf_target_all, int use_q,
+                                                                 int use_sf, float* __restrict__ dy,
+                                                                 float* __restrict__ loss_rows, float* __restrict__ q_out) {
+    __shared__ double s_q[LOSS_THREADS / 64], s_l[LOSS_THREADS / 64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int N = 2 * px + 2 * nf;
+    float* dyr = dy + (size_t)b * N;
+    if (b >= batch) {
+        for (int j = t; j < N; j += LOSS_THREADS) dyr[j] = 0.f;
+        if (t == 0) { loss_rows[b] = 0.f; q_out[b] = 0.f; }
+        return;
+    }
+    const float* yr = y + (size_t)b * N;
+    const size_t src = (size_t)(*counter) * batch + b;
+    const float* sft = use_sf ? sf_target_all + src * px : nullptr;
+    // pass 1: q = sum_j sigmoid(psi1 - psi0) * reward, squared error of psi0; f64 sums (their order does not matter then)
+    float sig[LOSS_CACHE], rw[LOSS_CACHE], err[LOSS_CACHE];
+    double qs = 0.0, ls = 0.0;
+#pragma unroll
+    for (int i = 0; i < LOSS_CACHE; ++i) {
+        const int j = t + i * LOSS_THREADS;
+        sig[i] = 0.f; rw[i] = 0.f; err[i] = 0.f;
+        if (j < px) {
+            const float p0 = yr[j], p1 = yr[px + j];
+            sig[i] = 1.f / (1.f + expf(p0 - p1));
+            rw[i] = reward[j];
+            if (use_sf) err[i] = p0 - sft[j];
+            qs += (double)(sig[i] * rw[i]);
+            ls += (double)(err[i] * err[i]);
+        }
+    }
+    for (int j = t + LOSS_CACHE * LOSS_THREADS; j < px; j += LOSS_THREADS) {      // images larger than the cache
+        const float p0 = yr[j], p1 = yr[px + j];
+        const float sg = 1.f / (1.f + expf(p0 - p1));
+        qs += (double)(sg * reward[j]);
+        if (use_sf) { const float e = p0 - sft[j]; ls += (double)(e * e); }
+    }
+    qs = wave_sum_d(qs);
+    ls = wave_sum_d(ls);
+    if (lane == 0) { s_q[wave] = qs; s_l[wave] = ls; }
+    __syncthreads();
+    double qd = 0.0, ld = 0.0;
+    for (int w = 0; w < LOSS_THREADS / 64; ++w) { qd += s_q[w]; ld += s_l[w]; }
+    const float q = (float)qd, lsf = (float)ld;
+    const float inv_b = 1.f / (float)batch;
+    const float dq = use_q ? 2.f * (q - q_target_all[src]) * inv_b : 0.f;
+    const float csf = 2.f * inv_b / (float)px;
+    // pass 2: d loss / d psi
+#pragma unroll
+    for (int i = 0; i < LOSS_CACHE; ++i) {
+        const int j = t + i * LOSS_THREADS;
+        if (j < px) {
+            const float g1 = dq * rw[i] * (sig[i] * (1.f - sig[i]));
+            dyr[px + j] = g1;
+            dyr[j] = use_sf ? csf * err[i] - g1 : -g1;
+        }
+    }
+    for (int j = t + LOSS_CACHE * LOSS_THREADS; j < px; j += LOSS_THREADS) {
+        const float p0 = yr[j], p1 = yr[px + j];
+        const float sg = 1.f / (1.f + expf(p0 - p1));
+        const float g1 = dq * reward[j] * (sg * (1.f - sg));
+        dyr[px + j] = g1;
+        dyr[j] = use_sf ? csf * (p0 - sft[j]) - g1 : -g1;
+    }
+    for (int j = 2 * px + t; j < N; j += LOSS_THREADS) dyr[j] = 0.f;
+    if (t == 0) {
+        float l = 0.f;
+        if (use_q) { const float d = q - q_target_all[src]; l += d * d * inv_b; }
+        if (use_sf) l += lsf * inv_b / (float)px;
+        loss_rows[b] = l;
+        q_out[b] = q;
+    }
+}
+
+// losses[*counter] = sum_b loss_rows[b]; ++*counter.
+__global__ void k_loss_log(int batch, const float* __restrict__ loss_rows, float* __restrict__ losses, int n_losses,
+                           int64_t* __restrict__ counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float l = 0.f;
+        for (int b = 0; b < batch; ++b) l += loss_rows[b];
+        const int64_t c = *counter;
+        if (c >= 0 && c < n_losses) losses[c] = l;
+        *counter = c + 1;
+    }
+}
+
+}  // namespace bridges

@@ -288,6 +288,16 @@ class VecDQN:
                   lane=torch.arange(B, device=dev), iota=torch.arange(n_max, device=dev), n_max=n_max, use_sf=use_sf)
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
+        st["fused"] = self._fused_step_enabled()
+
+        def body_fused():
+            # forward, losses and backward of the MLP as ~20 hand-written launches on the f32 matrix cores
+            # (bridges_hip/mlp_ops.py, csrc/mlp_kernels.hip) instead of ~60 library / element-wise ones; the gradients land
+            # in the parameters' .grad, the optimiser is torch's fused Adam as before.  Same losses as _loss.
+            n = n_max * B
+            st["step"].launch(st["counter"], st["block"].view(n, -1), st["action"].view(n, -1), st["binary"], st["reward"],
+                              st["obstacle"], st["q"], st["sf"], st["losses"])
+            self.opt.step()
 
         def body():
             idx = st["lane"] + st["counter"] * B
@@ -309,11 +319,24 @@ class VecDQN:
 
         self.policy_net.train()
         self.opt.zero_grad(set_to_none=True)
+        if st["fused"]:
+            from bridges_hip.mlp_ops import FusedSuccessorStep
+            st["step"] = FusedSuccessorStep(self.policy_net, B, 'mse_q_values' in self.loss_parts, use_sf)
+            st["reward"] = self.env.reward_features.reshape(-1).contiguous()
+            st["obstacle"] = self.env.obstacle_raster.reshape(-1).contiguous()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            body()
+            body_fused() if st["fused"] else body()
         st["graph"] = graph
         return st
+
+    def _fused_step_enabled(self):
+        """The hand-written training step applies to SuccessorMLP with the two MSE losses of the CLI
+        (BRIDGES_FUSED_MLP_STEP=0: the autograd step inside the graph, as before)."""
+        from robotoddler.models.cv import SuccessorMLP
+        return (isinstance(self.policy_net, SuccessorMLP) and os.environ.get("BRIDGES_FUSED_MLP_STEP", "1") != "0"
+                and set(self.loss_parts) <= {'mse_q_values', 'mse_block_features'}
+                and all(p.dtype == torch.float32 for p in self.policy_net.parameters()))
 
     def _train_graph(self, n_steps, use_sf):
         """The captured train step, or None (eager).  Default: on for SuccessorMLP, whose step has no multi-workgroup

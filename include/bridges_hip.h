@@ -291,6 +291,35 @@ int bridges_bias_relu(float* x, const float* bias, int64_t n, int32_t C, int32_t
 int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64_t n, int32_t C, int32_t H, int32_t W,
                             void* stream);
 
+/* ---- one optimiser step of SuccessorMLP at replay-batch size (robotoddler/models/cv.py:76-105;
+ * train_policy_net, robotoddler/training/successor_dqn.py:157-235: forward, MSE losses, backward) on the f32 matrix
+ * cores.  All tensors f32, row-major, contiguous; `rows` = the batch padded to a multiple of 32 (padding rows zero).
+ * `ws` = scratch for split partial sums (ws_floats floats; the split count adapts to it). */
+/* y [rows,N] = act(x [rows,K] . W [N,K]^T + bias), act = ReLU if relu else identity (nn.Linear [+ nn.ReLU], cv.py:20-38). */
+int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, const float* W, const float* bias,
+                           int32_t relu, float* y, float* ws, int64_t ws_floats, void* stream);
+/* Backward of the same layer from dz [rows,N] (gradient at its pre-activation) and its input a_in [rows,K]:
+ * dW [N,K] = dz^T . a_in, db [N] = column sums of dz, and -- unless dz_below is NULL (first layer) --
+ * dz_below [rows,K] = (dz . W) masked by act_below > 0 (act_below = the ReLU output that was this layer's input; NULL =
+ * no mask). */
+int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                            float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                            void* stream);
+/* Input rows of replay batch *counter: x [rows, 4 px + nf] = [block | action | reward | obstacle | binary]
+ * (cv.py:100-103) from block_all / action_all [n,px], binary_all [n,nf] (row *counter * batch + b), reward / obstacle [px]. */
+int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
+                      const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
+                      float* x, void* stream);
+/* Head + loss + its gradient (cv.py:104-108; successor_dqn.py:215-232): y [rows, 2 px + 2 nf] = (psi0 | psi1 | binary),
+ * q = sum_j softmax(psi)[1][j] * reward[j], loss = [use_q] mean (q - q_target)^2 + [use_sf] mean (psi0 - sf_target)^2
+ * with the targets of batch *counter (q_target_all [n], sf_target_all [n,px]).  Writes dy [rows, 2 px + 2 nf],
+ * loss_rows [rows] (per-row share of the loss), q_out [rows]; if losses != NULL: losses[*counter_inc] = sum of
+ * loss_rows and ++*counter_inc (the step counter that selects the next batch). */
+int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* y, const float* reward,
+                           const int64_t* counter, const float* q_target_all, const float* sf_target_all, int32_t use_q,
+                           int32_t use_sf, float* dy, float* loss_rows, float* q_out, float* losses, int32_t n_losses,
+                           int64_t* counter_inc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

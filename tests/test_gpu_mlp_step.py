@@ -1,0 +1,141 @@
+"""GPU: the hand-written SuccessorMLP training step (csrc/mlp_kernels.hip: skinny GEMMs on the f32 matrix cores, head +
+loss + gradient, backward) against torch -- the linear layers against float64 products, the whole step against
+autograd on the module's own forward (robotoddler/models/cv.py:76-105) and the losses of train_policy_net
+(successor_dqn.py:215-232).  Tolerance: 1e-5 relative to the largest entry (BASELINE.json: float features / losses)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    b = b.double()
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("rows,K,N", [(32, 16390, 256), (32, 256, 8204), (32, 256, 128), (64, 70, 33), (32, 1030, 40),
+                                      (32, 64, 128), (96, 523, 257)])
+def test_linear_forward_and_backward_match_float64_products(rows, K, N):
+    from bridges_hip import mlp_ops
+    g = torch.Generator(device=DEV).manual_seed(rows * 7 + K + N)
+    x = torch.randn(rows, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / np.sqrt(K)
+    b = torch.randn(N, device=DEV, generator=g)
+    ws = torch.empty(1 << 20, device=DEV)
+    for relu in (False, True):
+        y = mlp_ops.linear_forward(x, w, b, relu, ws=ws)
+        ref = x.double() @ w.double().T + b.double()
+        ref = ref.clamp_min(0) if relu else ref
+        assert rel_err(y, ref) < 2e-6, (relu, rel_err(y, ref))
+    # a workspace too small for the preferred split count still gives the same numbers
+    y_small = mlp_ops.linear_forward(x, w, b, False, ws=torch.empty(rows * N * 2, device=DEV))
+    assert rel_err(y_small, x.double() @ w.double().T + b.double()) < 2e-6
+    dz = torch.randn(rows, N, device=DEV, generator=g)
+    act = torch.randn(rows, K, device=DEV, generator=g)                  # stands for the ReLU output below
+    dW, db, below = mlp_ops.linear_backward(dz, x, w, act_below=act, ws=ws)
+    assert rel_err(dW, dz.double().T @ x.double()) < 2e-6
+    assert rel_err(db, dz.double().sum(0)) < 2e-6
+    ref_below = (dz.double() @ w.double()) * (act > 0)
+    assert rel_err(below, ref_below) < 2e-6
+    assert bool((below[act <= 0] == 0).all())
+    dW2, db2, none = mlp_ops.linear_backward(dz, x, w, need_input_grad=False, ws=ws)
+    assert none is None and torch.equal(dW2, dW) and torch.equal(db2, db)      # deterministic
+
+
+def make_net(hidden=(256, 128, 64, 128, 256), size=64, seed=0):
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.utils.utils import init_weights
+    torch.manual_seed(seed)
+    net = SuccessorMLP(img_size=(size, size), hidden_dims=list(hidden)).to(DEV)
+    net.apply(init_weights)
+    return net
+
+
+def make_batch(n, size, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    px = size * size
+    block = (torch.rand(n, 1, size, size, device=DEV, generator=g) < 0.05).float()
+    action = (torch.rand(n, 1, size, size, device=DEV, generator=g) < 0.01).float()
+    binary = (torch.rand(n, 6, device=DEV, generator=g) < 0.5).float()
+    reward = torch.rand(1, size, size, device=DEV, generator=g)
+    obstacle = (torch.rand(1, size, size, device=DEV, generator=g) < 0.03).float()
+    q_t = torch.randn(n, device=DEV, generator=g) * 3
+    sf_t = torch.rand(n, px, device=DEV, generator=g)
+    return block, action, binary, reward, obstacle, q_t, sf_t
+
+
+def autograd_step(net, batch, rows, use_q, use_sf):
+    block, action, binary, reward, obstacle, q_t, sf_t = batch
+    B = rows.stop - rows.start
+    for p in net.parameters():
+        p.grad = None
+    q, sf, _ = net(block[rows], binary[rows], action[rows], reward.unsqueeze(0).expand(B, -1, -1, -1),
+                   obstacle.unsqueeze(0).expand(B, -1, -1, -1))
+    mse = torch.nn.MSELoss()
+    loss = 0.
+    if use_q:
+        loss = loss + mse(q, q_t[rows])
+    if use_sf:
+        loss = loss + mse(sf[:, 0].reshape(B, -1), sf_t[rows])
+    loss.backward()
+    return float(loss.detach()), q.detach(), [p.grad.clone() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("B,size,hidden,use_q,use_sf", [(32, 64, (256, 128, 64, 128, 256), True, True),
+                                                        (32, 64, (256, 128, 64, 128, 256), False, True),
+                                                        (16, 64, (256, 128, 64, 128, 256), True, False),
+                                                        (4, 64, (128, 64, 128), True, True),
+                                                        (48, 32, (96, 40), True, True)])
+def test_fused_step_matches_autograd(B, size, hidden, use_q, use_sf):
+    from bridges_hip.mlp_ops import FusedSuccessorStep
+    net = make_net(hidden, size, seed=B)
+    n_batches = 3
+    batch = make_batch(n_batches * B, size, seed=B + size)
+    block, action, binary, reward, obstacle, q_t, sf_t = batch
+    refs = [autograd_step(net, batch, slice(i * B, (i + 1) * B), use_q, use_sf) for i in range(n_batches)]
+    for p in net.parameters():
+        p.grad = None
+    fused = FusedSuccessorStep(net, B, use_q, use_sf)
+    counter = torch.zeros((), dtype=torch.int64, device=DEV)
+    losses = torch.zeros(n_batches, device=DEV)
+    px = size * size
+    for i in range(n_batches):
+        fused.launch(counter, block.reshape(-1, px), action.reshape(-1, px), binary, reward.reshape(px).contiguous(),
+                     obstacle.reshape(px).contiguous(), q_t, sf_t, losses)
+        loss_ref, q_ref, grads_ref = refs[i]
+        assert int(counter) == i + 1
+        assert abs(float(losses[i]) - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref)), (i, float(losses[i]), loss_ref)
+        assert rel_err(fused.q[:B], q_ref) < 1e-5
+        for p, gref in zip(net.parameters(), grads_ref):
+            assert rel_err(p.grad, gref) < 1e-5, (i, tuple(p.shape), rel_err(p.grad, gref))
+
+
+def test_three_adam_steps_follow_the_autograd_run():
+    """Three optimiser steps (fused Adam) fed by the hand-written backward against three fed by autograd."""
+    from bridges_hip.mlp_ops import FusedSuccessorStep
+    B, size = 32, 64
+    batch = make_batch(3 * B, size, seed=11)
+    block, action, binary, reward, obstacle, q_t, sf_t = batch
+    px = size * size
+    net_a, net_b = make_net(seed=3), make_net(seed=3)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-3, fused=True)
+    opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-3, fused=True)
+    losses_a = []
+    for i in range(3):
+        loss, _, grads = autograd_step(net_a, batch, slice(i * B, (i + 1) * B), True, True)
+        opt_a.step()
+        losses_a.append(loss)
+    fused = FusedSuccessorStep(net_b, B, True, True)
+    counter = torch.zeros((), dtype=torch.int64, device=DEV)
+    losses_b = torch.zeros(3, device=DEV)
+    for i in range(3):
+        fused.launch(counter, block.reshape(-1, px), action.reshape(-1, px), binary, reward.reshape(px).contiguous(),
+                     obstacle.reshape(px).contiguous(), q_t, sf_t, losses_b)
+        opt_b.step()
+    np.testing.assert_allclose(losses_b.cpu().numpy(), np.array(losses_a), rtol=2e-5)
+    # Adam divides by sqrt(v): where a gradient entry is rounding noise its first updates are +-lr whatever its size, so
+    # the parameters of two correct float32 runs agree to ~lr * 1e-2 only, not to 1e-5 (the gradients themselves do)
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert rel_err(pb.detach(), pa.detach()) < 2e-4

@@ -182,6 +182,7 @@ def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, lockste
     args = vars(build_parser().parse_args(["--model", model]))
     dev = torch.device("cuda")
     out = {}
+    monkeypatch.setenv("BRIDGES_FUSED_MLP_STEP", "0")       # the autograd step in both modes (the hand-written one: below)
     for mode in ("1", "0"):
         monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", mode)
         env = make_env(E, seed=7, tower=4 if E > 64 else 2, max_steps=15 if E > 64 else 10)
@@ -204,6 +205,39 @@ def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, lockste
     diff = float((out["1"][1] - out["0"][1]).abs().max())
     print(f"max |weight difference| graph vs eager after {n_steps * locksteps} steps: {diff:.3e}")
     assert torch.allclose(out["1"][1], out["0"][1], rtol=1e-4, atol=atol), diff
+
+
+@pytest.mark.parametrize("loss,E,n_steps", [("mse_q_values+mse_block_features", 64, 3), ("mse_block_features", 4096, 25),
+                                            ("mse_q_values", 64, 5)])
+def test_hand_written_mlp_step_in_the_graph_follows_the_autograd_graph(loss, E, n_steps, monkeypatch):
+    """The captured train step with the hand-written forward / loss / backward (bridges_hip/mlp_ops.py) against the
+    captured autograd step.  Two identically seeded agents run two lock-steps eagerly (bit-identical), the third
+    lock-step's optimiser steps go through the respective graph on the same ring, the same sampled batches and the
+    same weights: the logged losses agree to 1e-4 relative.  The weights agree to Adam's sensitivity: a gradient entry
+    that is rounding noise moves its weight by up to lr per step in either run."""
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev, lr = torch.device("cuda"), 1e-4
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("BRIDGES_FUSED_MLP_STEP", fused)
+        env = make_env(E, seed=7, tower=4 if E > 64 else 2, max_steps=15 if E > 64 else 10)
+        torch.manual_seed(11)
+        pol, tgt = make_nets(args, dev)
+        agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=lr, fused=True), env, 100000, 32 if E > 64 else 16,
+                       0.95, 0.01, loss, seed=2)
+        losses = [agent.lockstep(n_steps)[0] for _ in range(3)]
+        assert agent._graph_state is not None and agent._graph_state["fused"] == (fused == "1")
+        out[fused] = (losses, torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu())
+    for k in range(2):
+        assert out["1"][0][k] == out["0"][0][k]                                    # eager lock-steps: the same bits
+    a, b = np.array(out["1"][0][2]), np.array(out["0"][0][2])
+    assert len(a) == n_steps and (a >= 0).all()
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-7)
+    diff = (out["1"][1] - out["0"][1]).abs()
+    print(f"weights after {n_steps} graph steps: max |diff| {float(diff.max()):.3e}, mean {float(diff.mean()):.3e}")
+    assert float(diff.max()) <= 2 * n_steps * lr and float(diff.mean()) < 0.02 * lr
 
 
 def test_graph_is_recaptured_when_a_call_brings_more_batches(monkeypatch):

@@ -1,0 +1,94 @@
+"""Times one SuccessorMLP optimiser step at batch 32 (BASELINE.json configs[2] shape: 64x64 images, hidden
+256-128-64-128-256) as a replayed HIP graph: the hand-written forward / loss / backward (bridges_hip/mlp_ops.py) + torch's
+fused Adam, against the autograd step + fused Adam.  Under rocprofv3 --kernel-trace the kernel list of either is visible.
+Usage: python tools/mlp_step_bench.py [--autograd] [--replays 400] [--batch 32]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--autograd", action="store_true")
+    ap.add_argument("--replays", type=int, default=400)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-adam", action="store_true")
+    args = ap.parse_args()
+    from bridges_hip.mlp_ops import FusedSuccessorStep
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.utils.utils import init_weights
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    size, B, n_b = 64, args.batch, 25
+    px = size * size
+    net = SuccessorMLP(img_size=(size, size), hidden_dims=[256, 128, 64, 128, 256]).to(dev)
+    net.apply(init_weights)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, capturable=True)
+    n = n_b * B
+    block = (torch.rand(n, 1, size, size, device=dev) < 0.05).float()
+    action = (torch.rand(n, 1, size, size, device=dev) < 0.01).float()
+    binary = (torch.rand(n, 6, device=dev) < 0.5).float()
+    reward, obstacle = torch.rand(1, size, size, device=dev), (torch.rand(1, size, size, device=dev) < 0.03).float()
+    q_t, sf_t = torch.randn(n, device=dev), torch.rand(n, px, device=dev)
+    counter = torch.zeros((), dtype=torch.int64, device=dev)
+    losses = torch.zeros(n_b, device=dev)
+    lane = torch.arange(B, device=dev)
+
+    def autograd_body():
+        idx = lane + counter * B
+        q, sf, _ = net(block.index_select(0, idx), binary.index_select(0, idx), action.index_select(0, idx),
+                       reward.unsqueeze(0).expand(B, -1, -1, -1), obstacle.unsqueeze(0).expand(B, -1, -1, -1))
+        loss = ((q - q_t.index_select(0, idx)) ** 2).mean() + ((sf[:, 0].reshape(B, -1) - sf_t.index_select(0, idx)) ** 2).mean(dim=1).mean()
+        loss.backward()
+        if not args.no_adam:
+            opt.step()
+        counter.add_(1)
+
+    # eager steps first: optimiser state, library workspaces
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        autograd_body()
+    counter.zero_()
+    opt.zero_grad(set_to_none=True)
+    if args.autograd:
+        body = autograd_body
+    else:
+        step = FusedSuccessorStep(net, B, True, True)
+        rw, ob = reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous()
+
+        def body():
+            step.launch(counter, block.view(n, px), action.view(n, px), binary, rw, ob, q_t, sf_t, losses)
+            if not args.no_adam:
+                opt.step()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    counter.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    for _ in range(20):
+        counter.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(args.replays):
+        if i % n_b == 0:
+            counter.zero_()
+        graph.replay()
+    b.record()
+    torch.cuda.synchronize()
+    print(f"{'autograd' if args.autograd else 'hand-written'} step{'' if not args.no_adam else ' (no Adam)'}: "
+          f"{a.elapsed_time(b) / args.replays * 1e3:.1f} us per optimiser step (batch {B})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
