@@ -54,7 +54,7 @@ class VecDQN:
                                          mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
                                          ylim=env.ylim, x_discr_ground=env.x_discr_ground,
                                          offset_values=env.offset_values, device=self.device, a_max=env.a_max,
-                                         img_size=(env.img, env.img))
+                                         img_size=(env.img, env.img), f32_rasters=self._replay_f32())
         self.mse = torch.nn.MSELoss()
         for g in optimizer.param_groups:                # step counter on the device: the train step is graph-captured
             if 'capturable' in g:
@@ -82,8 +82,12 @@ class VecDQN:
     # ------------------------------------------------------------------ features of the rows a net is fed
     def _row_features(self, env, idx, row_env, stable_flag):
         n = idx.numel()
-        block = env.crop(env.state_raster[row_env]).unsqueeze(1)         # crop: no-op for the 64x64 default
-        action = env.crop(env.cand_raster[idx]).unsqueeze(1)
+        if env.cand_raster is not None:
+            block = env.crop(env.state_raster[row_env]).unsqueeze(1)     # crop: no-op for the 64x64 default
+            action = env.crop(env.cand_raster[idx]).unsqueeze(1)
+        else:                                                            # env without f32 rasters: expand the rows asked for
+            block = env.crop(ops.bits_to_f32(env.state_bits[row_env])).unsqueeze(1)
+            action = env.crop(ops.bits_to_f32(env.cand_bits[idx])).unsqueeze(1)
         binary = torch.zeros((n, 6), dtype=torch.float32, device=self.device)
         binary[:, 0] = stable_flag[row_env].float()
         reward = env.reward_features.unsqueeze(0).expand(n, -1, -1, -1)
@@ -209,8 +213,13 @@ class VecDQN:
                                              mu=env.mu, density=env.density, bounds=env.bounds, xlim=env.xlim,
                                              ylim=env.ylim, x_discr_ground=env.x_discr_ground,
                                              offset_values=env.offset_values, device=self.device, a_max=env.a_max,
-                                         img_size=(env.img, env.img))
+                                             img_size=(env.img, env.img), f32_rasters=self._replay_f32())
         return self.replay_env
+
+    def _replay_f32(self):
+        """The scratch env writes f32 rasters of every raw candidate only for nets that consume them row by row; the
+        factored MLP reads the bit rasters and expands the few rows it needs (the arg-max row of each transition)."""
+        return not self._factored(self.target_net)
 
     @torch.no_grad()
     def _targets(self, rec):
@@ -368,7 +377,9 @@ class VecDQN:
         if len(self.ring) < self.B or n_steps <= 0:
             return []
         B = self.B
-        rec = torch.cat([self.ring.sample(B, self.sample_gen, self.prioritized) for _ in range(n_steps)])
+        # n_steps independent batches = ONE draw of n_steps * B records: both sampling rules draw with replacement, so
+        # the batches are i.i.d. either way (25 separate draws cost ~100 launches of host time per lock-step)
+        rec = self.ring.sample(n_steps * B, self.sample_gen, self.prioritized)
         block_f, binary, action_f, q_target, sf_target = self._targets(rec)
         use_sf = sf_target is not None
         st = self._train_graph(n_steps, use_sf)
