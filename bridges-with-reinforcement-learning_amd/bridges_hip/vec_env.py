@@ -262,6 +262,7 @@ class VecAssemblyGym:
     def reset(self):
         abi.check(self.L.bridges_env_reset(self._env, _stream()), "bridges_env_reset")
         self._contacts_current = True
+        self._cand_version = getattr(self, "_cand_version", 0) + 1
 
     def select_random(self):
         """Synthetic uniform-random policy over each env's valid candidates -> sel_index."""
@@ -271,6 +272,7 @@ class VecAssemblyGym:
         if sel_index is not None:
             self.buf["sel_index"].copy_(sel_index.to(device=self.device, dtype=torch.int32))
         abi.check(self.L.bridges_env_step(self._env, _stream()), "bridges_env_step")
+        self._cand_version += 1
 
     def timing_begin(self, max_launches):
         abi.check(self.L.bridges_env_timing_begin(self._env, int(max_launches)), "bridges_env_timing_begin")
@@ -284,6 +286,7 @@ class VecAssemblyGym:
     def refresh(self):
         """Recompute the candidate set (enumerate, rasterise, mask) after the host edited the state arrays."""
         abi.check(self.L.bridges_env_refresh(self._env, _stream()), "bridges_env_refresh")
+        self._cand_version += 1
 
     def load_states(self, n_blocks, blk_shape, blk_pose, blk_occ):
         """Overwrite the state of every env with caller-supplied block lists (replay re-rasterisation): world
@@ -310,7 +313,9 @@ class VecAssemblyGym:
         self._keep = (bits, ranges, flat_shape)       # alive until the stream has consumed them
         # candidate counts of the loaded states, then the usual refresh
         nfree = torch.zeros(E, dtype=torch.int32, device=self.device)
-        nv = torch.tensor([g.num_faces_2d for g in self.table_geoms], dtype=torch.int32, device=self.device)
+        if getattr(self, "_nv_dev", None) is None:      # once: a host list -> device copy makes the host wait
+            self._nv_dev = torch.tensor([g.num_faces_2d for g in self.table_geoms], dtype=torch.int32, device=self.device)
+        nv = self._nv_dev
         kidx = torch.arange(K, device=self.device)[None, :]
         live = kidx < self.buf["n_blocks"][:, None]
         faces = nv[self.buf["blk_shape"].long()]
@@ -352,9 +357,14 @@ class VecAssemblyGym:
 
     def valid_rows(self):
         """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed."""
+        cached = getattr(self, "_valid_rows", None)
+        if cached is not None and cached[0] == self._cand_version:       # same candidate set as when it was last asked for
+            return cached[1], cached[2]
         total = self.total_candidates()
         idx = torch.nonzero(self.buf["cand_mask"][:total]).squeeze(1)
-        return idx, self.buf["cand_env"][idx].long()
+        row_env = self.buf["cand_env"][idx].long()
+        self._valid_rows = (self._cand_version, idx, row_env)
+        return idx, row_env
 
     # ------------------------------------------------------------------ views
     def flags(self):
@@ -438,6 +448,7 @@ class VecAssemblyGymGroups:
         fn = self.envs[0].L.bridges_env_lockstep_random
         for env, sp in zip(self.envs, self._stream_ptrs):
             rc = fn(env._env, sp)
+            env._cand_version += 1
             if rc != 0:
                 abi.check(rc, "bridges_env_lockstep_random")
 

@@ -109,9 +109,11 @@ class VecDQN:
         return not cls._factored(net)
 
     @staticmethod
-    def _segments(row_env, E, device):
-        counts = torch.bincount(row_env, minlength=E)
-        seg = torch.zeros(E + 1, dtype=torch.int32, device=device)
+    def _segments(env):
+        """Row ranges of the envs in ``env.valid_rows()`` (rows are env-major) from the env's own per-env counts --
+        torch.bincount would make the host wait for the device (it reads the maximum back)."""
+        counts = env.n_valid[:env.E].long()
+        seg = torch.zeros(env.E + 1, dtype=torch.int32, device=env.device)
         seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return seg, counts
 
@@ -155,7 +157,7 @@ class VecDQN:
         next_q = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
             q = self._policy_q(env, idx, row_env, self._stable_flags(env))
-            seg, counts = self._segments(row_env, E, self.device)
+            seg, counts = self._segments(env)
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
             next_q, _, _ = dqn_ops.td_target(seg, q.contiguous().float(), zeros, done | (counts == 0), 1.0)   # segmented max
         expected = rec[:, R.O_REWARD].float() + 0.95 * next_q                      # hard-coded 0.95 (successor_dqn.py:425)
@@ -167,7 +169,7 @@ class VecDQN:
         env, E = self.env, self.env.E
         idx, row_env = env.valid_rows()
         stable = self._stable_flags(env)
-        seg, counts = self._segments(row_env, E, self.device)
+        seg, counts = self._segments(env)
         sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
         self._q_sel = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
@@ -190,9 +192,11 @@ class VecDQN:
             has = counts > 0
             sel_row = torch.where(has, sel_row, torch.zeros_like(sel_row))
             ex = explore & has
-            if ex.any():
-                rows = sel_row[ex]
-                self.step_images.index_add_(0, step_of_row[rows], env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])))
+            # count images of the explored choices; every env takes part with weight 0 or 1, so no host decision
+            # (an `if ex.any()` here would make the host wait for the Q pass it has just queued)
+            rows = sel_row.clamp(max=idx.numel() - 1)
+            picked = env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])) * ex[:, None, None].to(torch.float32)
+            self.step_images.index_add_(0, step_of_row[rows], picked)
             sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
             self._q_sel = torch.where(has, q.float()[sel_row.clamp(max=idx.numel() - 1)], self._q_sel)
         else:
@@ -242,7 +246,7 @@ class VecDQN:
         block_f = renv.crop(ops.bits_to_f32(bits_s)).unsqueeze(1)
         action_f = renv.crop(ops.bits_to_f32(renv.state_bits & ~bits_s)).unsqueeze(1)         # s' minus s = the new block
         idx, row_env = renv.valid_rows()
-        seg, counts = self._segments(row_env, E, self.device)
+        seg, counts = self._segments(renv)
         done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)
         use_sf = 'mse_block_features' in self.loss_parts
         stable_n = rec_p[:, R.O_STABLE_N] > 0.5
@@ -372,10 +376,13 @@ class VecDQN:
                 return None
         return st
 
-    def train_steps(self, n_steps):
-        """n_steps optimiser steps on n_steps independently sampled batches; returns the losses (one host sync)."""
+    def train_steps(self, n_steps, defer=False):
+        """n_steps optimiser steps on n_steps independently sampled batches; returns the losses (one host sync).
+        defer=True: returns a ``DeferredLosses`` -- the losses travel to pinned host memory behind the optimiser steps and
+        ``.get()`` waits for that copy only, so the host can queue the next lock-step's acting while the GPU still
+        trains (the list form makes the host wait for the last optimiser step before it queues anything)."""
         if len(self.ring) < self.B or n_steps <= 0:
-            return []
+            return DeferredLosses(None, None, self) if defer else []
         B = self.B
         # n_steps independent batches = ONE draw of n_steps * B records: both sampling rules draw with replacement, so
         # the batches are i.i.d. either way (25 separate draws cost ~100 launches of host time per lock-step)
@@ -393,15 +400,13 @@ class VecDQN:
             st["losses"].zero_()
             for _ in range(n_steps):
                 st["graph"].replay()
-            losses = st["losses"][:n_steps].tolist()            # the one host sync of the call
-            # Guard for the anomaly recorded in DESIGN.md: a multi-workgroup reduction inside a replayed graph once
-            # returned garbage (a negative "MSE"; ROCm 7.2 + torch 2.10, cause not established).  The graph holds only
-            # single-workgroup reductions since, and every replay's loss is checked here: a sum of squares that is
-            # negative or not finite means a kernel in the graph misbehaved -- from then on the step runs eagerly.
-            if not all(np.isfinite(l) and l >= 0.0 for l in losses):
-                warnings.warn(f"train-step graph produced an invalid loss {losses}; switching to the eager step")
-                self._graph_state, self._eager_calls = None, -(1 << 30)
-            return losses
+            if defer:
+                host = torch.empty(n_steps, dtype=torch.float32, pin_memory=True)
+                host.copy_(st["losses"][:n_steps], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                return DeferredLosses(host, done, self)
+            return self._check_graph_losses(st["losses"][:n_steps].tolist())            # the one host sync of the call
         reward = self.env.reward_features.unsqueeze(0).expand(B, -1, -1, -1)
         obstacle = self.env.obstacle_raster.unsqueeze(0).expand(B, -1, -1, -1)
         self.policy_net.train()
@@ -414,7 +419,23 @@ class VecDQN:
             loss.backward()
             self.opt.step()
             losses.append(loss.detach())
+        if defer:
+            host = torch.empty(n_steps, dtype=torch.float32, pin_memory=True)
+            host.copy_(torch.stack(losses), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            return DeferredLosses(host, done, None)
         return torch.stack(losses).tolist()
+
+    def _check_graph_losses(self, losses):
+        """Guard for the anomaly recorded in DESIGN.md: a multi-workgroup reduction inside a replayed graph once returned
+        garbage (a negative "MSE"; ROCm 7.2 + torch 2.10, cause not established).  The graph holds only single-workgroup
+        reductions since, and every replay's loss is checked here: a sum of squares that is negative or not finite
+        means a kernel in the graph misbehaved -- from then on the step runs eagerly."""
+        if not all(np.isfinite(l) and l >= 0.0 for l in losses):
+            warnings.warn(f"train-step graph produced an invalid loss {losses}; switching to the eager step")
+            self._graph_state, self._eager_calls = None, -(1 << 30)
+        return losses
 
     def train_step(self):
         out = self.train_steps(1)
@@ -439,18 +460,40 @@ class VecDQN:
         return blob["counters"]
 
     # ------------------------------------------------------------------ driver
-    def lockstep(self, n_train_steps):
+    def lockstep(self, n_train_steps, defer_losses=False):
+        """act -> all-gather -> replay push -> n optimiser steps -> soft update.  defer_losses=True returns the losses as
+        a DeferredLosses (see train_steps): nothing after the replay push waits for the GPU, so the optimiser steps run
+        under the host's queueing of the next lock-step."""
         rec, valid = self.act()
         if self.prioritized:
             rec[:, R.O_TD] = self.td_errors(rec).to(rec.dtype)
+        self.env.valid_rows()                           # the next act's candidate rows, while the host waits here anyway
         self.env_steps += int(valid.sum().item())
         allrec = D.all_gather_records(rec, valid)
         self.ring.push(allrec)
         self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())
-        losses = self.train_steps(n_train_steps)
+        losses = self.train_steps(n_train_steps, defer=defer_losses)
         self.update_target()
         self.epsilon = (self.epsilon - self.eps_end) * self.eps_decay + self.eps_end
         return losses, allrec
+
+
+class DeferredLosses:
+    """Losses of one train_steps call on their way to the host (pinned buffer + event)."""
+
+    def __init__(self, host, done, agent):
+        self._host, self._done, self._agent, self._list = host, done, agent, None
+
+    def get(self):
+        if self._list is None:
+            if self._host is None:
+                self._list = []
+            else:
+                self._done.synchronize()
+                self._list = self._host.tolist()
+                if self._agent is not None:
+                    self._agent._check_graph_losses(self._list)
+        return self._list
 
 
 def run_vectorised(args, device):
@@ -488,8 +531,22 @@ def run_vectorised(args, device):
         it = agent.load_extra(os.path.join(path, 'agent.pt'))['lockstep']
         next_ckpt = (agent.episodes_done // args['checkpoint_every'] + 1) * args['checkpoint_every']
         env.reset()                                      # a checkpoint is taken with all environments freshly reset
+    def finish(entry):
+        """Fill in the numbers of a lock-step that were still on their way to the host when its entry was made."""
+        info, deferred, stats_host, done = entry
+        ls = deferred.get()
+        info['avg_loss'] = float(np.mean(ls)) if ls else None
+        if stats_host is not None:
+            done.synchronize()
+            info['mean_reward'], info['mean_lin_reward'] = float(stats_host[0]), float(stats_host[1])
+        if args['verbose'] and rank == 0:
+            print(info)
+
+    pending = None
     while agent.episodes_done < args['num_episodes']:
-        losses, rec = agent.lockstep(args['num_training_steps'])
+        # losses and record statistics are read one lock-step late: nothing here waits for the optimiser steps, so they
+        # run while the host queues the next lock-step's acting
+        losses, rec = agent.lockstep(args['num_training_steps'], defer_losses=True)
         it += 1
         if args.get('save_checkpoint') and agent.episodes_done >= next_ckpt:                  # utils.py:54-89 layout
             if rank == 0:
@@ -504,12 +561,18 @@ def run_vectorised(args, device):
         if it % 100 == 0:
             D.broadcast_module(policy_net)
             D.broadcast_module(target_net)
-        info = dict(lockstep=it, episodes=agent.episodes_done, env_steps=agent.env_steps,
-                    avg_loss=float(np.mean(losses)) if losses else None,
-                    mean_reward=float(rec[:, R.O_REWARD].mean().item()) if rec.numel() else None,
-                    mean_lin_reward=float(rec[:, R.O_LIN].mean().item()) if rec.numel() else None,
-                    epsilon=agent.epsilon, steps_per_s=agent.env_steps * world / (time.time() - t0))
+        stats_host, done = None, None
+        if rec.numel():
+            stats_host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+            stats_host.copy_(torch.stack([rec[:, R.O_REWARD].mean(), rec[:, R.O_LIN].mean()]).double(), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        info = dict(lockstep=it, episodes=agent.episodes_done, env_steps=agent.env_steps, avg_loss=None, mean_reward=None,
+                    mean_lin_reward=None, epsilon=agent.epsilon, steps_per_s=agent.env_steps * world / (time.time() - t0))
         history.append(info)
-        if args['verbose'] and rank == 0:
-            print(info)
+        if pending is not None:
+            finish(pending)
+        pending = (info, losses, stats_host, done)
+    if pending is not None:
+        finish(pending)
     return history
