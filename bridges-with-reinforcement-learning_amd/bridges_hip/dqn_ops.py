@@ -74,6 +74,26 @@ def bias_relu_pool2(x, bias):
     return out
 
 
+def conv3x3_relu_o16_applies(x, conv):
+    """The hand-written conv3x3 + bias + ReLU [+ pool] kernel covers: 16 output channels, 1-4 / 16 / 32 input channels,
+    64-pixel-wide float32 NCHW images with a height that is a multiple of 8, stride 1, padding 1."""
+    return (conv.out_channels == 16 and conv.in_channels in (1, 2, 3, 4, 16, 32) and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and conv.bias is not None and x.dim() == 4 and x.shape[3] == 64 and x.shape[2] % 8 == 0
+            and x.dtype == torch.float32 and x.is_cuda)
+
+
+def conv3x3_relu_o16(x, weight, bias, pool=False):
+    """relu(conv2d(x, weight, bias, padding=1)) [-> max_pool2d(2)] by bridges_conv3x3_relu_o16 (f32 matrix cores)."""
+    L = abi.require_gpu()
+    x = x.contiguous()
+    n, c_in, H, W = x.shape
+    out = torch.empty((n, 16, H // 2, W // 2) if pool else (n, 16, H, W), dtype=torch.float32, device=x.device)
+    abi.check(L.bridges_conv3x3_relu_o16(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out), n, c_in, H, W,
+                                         int(bool(pool)), _stream()), "bridges_conv3x3_relu_o16")
+    return out
+
+
 class FlatParameters:
     """All parameters and float buffers of a module re-pointed into ONE contiguous float32 device buffer, so the
     Polyak update of a 6.4 M-parameter SuccessorMLP is a single launch instead of one per state_dict key."""

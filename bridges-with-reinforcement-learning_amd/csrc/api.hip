@@ -9,6 +9,7 @@
 #include "ops_kernels.hip"
 #include "dqn_kernels.hip"
 #include "mlp_kernels.hip"
+#include "conv_kernels.hip"
 
 using namespace bridges;
 
@@ -642,6 +643,31 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
         hipLaunchKernelGGL(k_loss_log, dim3(1), dim3(64), 0, st, batch, loss_rows, losses, n_losses, counter_inc);
         LAUNCH_CHECK("k_loss_log");
     }
+    return BRIDGES_OK;
+}
+
+// ---- conv3x3 + bias + ReLU [+ pool] for the 64-wide, 16-output-channel layers (conv_kernels.hip) ------------------
+int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in,
+                             int32_t H, int32_t W, int32_t pool, void* stream) {
+    if (n < 0 || !x || !w || !bias || !out) return fail_arg("bridges_conv3x3_relu_o16");
+    if (W != CONV_W || H <= 0 || (H % CONV_BAND) != 0) return fail_arg("bridges_conv3x3_relu_o16: W must be 64 and H a multiple of 8");
+    if (!(c_in >= 1 && c_in <= 4) && c_in != 16 && c_in != 32) return fail_arg("bridges_conv3x3_relu_o16: C_in must be 1..4, 16 or 32");
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 15)) return fail_arg("bridges_conv3x3_relu_o16: x / out must be 16-byte aligned");
+    if (n == 0) return BRIDGES_OK;
+    const int64_t blocks = n * (H / CONV_BAND);
+    if (blocks > 0x7fffffff) return fail_arg("bridges_conv3x3_relu_o16: too many images");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((unsigned)blocks), b(256);
+#define CONV_LAUNCH(CC, NC)                                                                                   \
+    do {                                                                                                      \
+        if (pool) hipLaunchKernelGGL((k_conv3x3_o16<CC, NC, true>), g, b, 0, st, x, w, bias, out, (int)H, (int)c_in);     \
+        else hipLaunchKernelGGL((k_conv3x3_o16<CC, NC, false>), g, b, 0, st, x, w, bias, out, (int)H, (int)c_in);         \
+    } while (0)
+    if (c_in <= 4) CONV_LAUNCH(4, 1);
+    else if (c_in == 16) CONV_LAUNCH(16, 1);
+    else CONV_LAUNCH(16, 2);
+#undef CONV_LAUNCH
+    LAUNCH_CHECK("k_conv3x3_o16");
     return BRIDGES_OK;
 }
 

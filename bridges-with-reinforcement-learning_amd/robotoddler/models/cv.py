@@ -23,6 +23,8 @@ def _fused_inference(x):
 def _conv_relu(conv, x, pool=False):
     """relu(conv(x)) [then 2x2 max-pool] with the bias / ReLU / pool epilogue as one HIP pass."""
     from bridges_hip import dqn_ops
+    if dqn_ops.conv3x3_relu_o16_applies(x, conv):           # the 64-wide, 16-channel layers: hand-written MFMA kernel
+        return dqn_ops.conv3x3_relu_o16(x, conv.weight, conv.bias, pool)
     y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups).contiguous()
     if pool:
         return dqn_ops.bias_relu_pool2(y, conv.bias)

@@ -320,6 +320,13 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
                            int32_t use_sf, float* dy, float* loss_rows, float* q_out, float* losses, int32_t n_losses,
                            int64_t* counter_inc, void* stream);
 
+/* relu(conv3x3(x, w, padding 1) + bias) [then MaxPool2d(2)] for the 64-pixel-wide layers with 16 output channels of
+ * the conv Q-networks (cv.py:5-17 ConvBlock(4,16) / (16,16); cv.py:138-254 UNet e11, e12, d41, d42), inference passes:
+ * x [n, c_in, H, 64] f32 NCHW contiguous, w [16, c_in, 3, 3], bias [16] -> out [n, 16, H, 64] (pool: [n, 16, H/2, 32]).
+ * c_in in {1..4, 16, 32}, H % 8 == 0.  Same function as torch's conv2d + relu (+ max_pool2d) up to f32 summation order. */
+int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in,
+                             int32_t H, int32_t W, int32_t pool, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

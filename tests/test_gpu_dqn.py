@@ -332,8 +332,10 @@ def test_log_episode_reports_the_reference_numbers():
 @pytest.mark.parametrize("model", ["ConvNet", "Policy"])
 def test_fused_conv_epilogues_equal_the_module_forward(model):
     """Inference passes of the conv nets run every convolution bias-free and apply ``+ bias -> ReLU [-> MaxPool2d(2)]``
-    as one HIP pass (bridges_bias_relu / bridges_bias_relu_pool2): bit-identical to the plain torch forward (which the
-    same modules take whenever autograd records), on the ops alone and through ConvNet / Policy."""
+    as one HIP pass (bridges_bias_relu / bridges_bias_relu_pool2): the ops alone are bit-identical to torch's.  Through
+    ConvNet / Policy the 64-wide 16-channel layers additionally run on the hand-written convolution
+    (bridges_conv3x3_relu_o16), whose float32 summation order differs from the library's: the outputs agree with the
+    plain torch forward (which the same modules take whenever autograd records) to 1e-5 of the largest value."""
     from bridges_hip import dqn_ops
     from robotoddler.models.cv import ConvNet, Policy
     from robotoddler.utils.utils import init_weights
@@ -358,4 +360,28 @@ def test_fused_conv_epilogues_equal_the_module_forward(model):
         plain = net(*args)
     for a, bb in zip(fused, plain):
         if a is not None:
-            assert torch.equal(a, bb.detach())
+            bb = bb.detach()
+            assert float((a - bb).abs().max()) <= 1e-5 * max(1.0, float(bb.abs().max())), float((a - bb).abs().max())
+
+
+@pytest.mark.parametrize("c_in,H,n,pool", [(4, 64, 5, False), (4, 64, 3, True), (16, 64, 4, False), (16, 64, 6, True),
+                                           (32, 64, 3, False), (32, 64, 2, True), (16, 8, 3, True), (16, 128, 1, False),
+                                           (2, 64, 3, True), (1, 16, 2, False), (3, 64, 2, False)])
+def test_hand_written_conv3x3_matches_torch(c_in, H, n, pool):
+    """bridges_conv3x3_relu_o16 (f32 matrix cores, LDS-staged bands) against torch's conv2d + relu [+ max_pool2d] in
+    float64: same function up to float32 summation order (1e-5 of the largest output), borders included."""
+    import torch.nn.functional as F
+    from bridges_hip import dqn_ops
+    g = torch.Generator(device="cuda").manual_seed(c_in * 100 + H + n)
+    x = torch.randn(n, c_in, H, 64, device="cuda", generator=g)
+    x[:, :, :, :3] += 1.0                                   # structure at the borders
+    w = torch.randn(16, c_in, 3, 3, device="cuda", generator=g) / (3.0 * c_in ** 0.5)
+    b = torch.randn(16, device="cuda", generator=g)
+    out = dqn_ops.conv3x3_relu_o16(x, w, b, pool)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2)
+    assert out.shape == ref.shape
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    assert bool(((out == 0) == (ref.float() <= 0)).float().mean() > 0.999)        # the ReLU pattern agrees
