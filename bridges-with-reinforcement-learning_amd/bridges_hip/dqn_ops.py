@@ -74,24 +74,52 @@ def bias_relu_pool2(x, bias):
     return out
 
 
-def conv3x3_relu_o16_applies(x, conv):
+def conv3x3_relu_o16_applies(x, conv, x2=None):
     """The hand-written conv3x3 + bias + ReLU [+ pool] kernel covers: 16 output channels, 1-4 / 16 / 32 input channels,
-    64-pixel-wide float32 NCHW images with a height that is a multiple of 8, stride 1, padding 1."""
+    64-pixel-wide float32 NCHW images with a height that is a multiple of 8, stride 1, padding 1 (x2: the input is the
+    concatenation of two 16-channel tensors)."""
+    if x2 is not None and not (x.shape[1] == 16 and x2.shape[1] == 16 and conv.in_channels == 32 and x2.shape[2:] == x.shape[2:]):
+        return False
     return (conv.out_channels == 16 and conv.in_channels in (1, 2, 3, 4, 16, 32) and tuple(conv.kernel_size) == (3, 3)
             and tuple(conv.padding) == (1, 1) and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1)
             and conv.groups == 1 and conv.bias is not None and x.dim() == 4 and x.shape[3] == 64 and x.shape[2] % 8 == 0
             and x.dtype == torch.float32 and x.is_cuda)
 
 
-def conv3x3_relu_o16(x, weight, bias, pool=False):
-    """relu(conv2d(x, weight, bias, padding=1)) [-> max_pool2d(2)] by bridges_conv3x3_relu_o16 (f32 matrix cores)."""
+def conv3x3_relu_o16(x, weight, bias, pool=False, x2=None, both=False, proj=None):
+    """relu(conv2d(x, weight, bias, padding=1)) by bridges_conv3x3_relu_o16_ex (f32 matrix cores), with the neighbours
+    the U-Net puts around it folded in:
+      pool=True        -> max_pool2d(., 2) of it;
+      both=True        -> (it, max_pool2d(it, 2));
+      x2=tensor        -> the input is torch.cat([x, x2], dim=1) (16 + 16 channels), not materialised;
+      proj=(w1, b1)    -> conv2d(it, w1, b1) for a 1x1 convolution w1 [1,16,1,1] to one channel."""
     L = abi.require_gpu()
     x = x.contiguous()
     n, c_in, H, W = x.shape
-    out = torch.empty((n, 16, H // 2, W // 2) if pool else (n, 16, H, W), dtype=torch.float32, device=x.device)
-    abi.check(L.bridges_conv3x3_relu_o16(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out), n, c_in, H, W,
-                                         int(bool(pool)), _stream()), "bridges_conv3x3_relu_o16")
-    return out
+    c_in2 = 0
+    if x2 is not None:
+        x2 = x2.contiguous()
+        assert x2.shape[0] == n and x2.shape[2:] == x.shape[2:]
+        c_in2 = x2.shape[1]
+    dev = x.device
+    mode, out2, pw, pb = 0, None, None, None
+    if proj is not None:
+        mode, pw, pb = 3, proj[0].reshape(-1).contiguous(), proj[1].reshape(-1).contiguous()
+        assert pw.numel() == 16 and pb.numel() == 1 and not (pool or both)
+        out = torch.empty((n, 1, H, W), dtype=torch.float32, device=dev)
+    elif both:
+        mode = 2
+        out = torch.empty((n, 16, H, W), dtype=torch.float32, device=dev)
+        out2 = torch.empty((n, 16, H // 2, W // 2), dtype=torch.float32, device=dev)
+    elif pool:
+        mode = 1
+        out = torch.empty((n, 16, H // 2, W // 2), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((n, 16, H, W), dtype=torch.float32, device=dev)
+    abi.check(L.bridges_conv3x3_relu_o16_ex(_ptr(x), _ptr(x2), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out),
+                                            _ptr(out2), _ptr(pw), _ptr(pb), n, c_in, c_in2, H, W, mode, _stream()),
+              "bridges_conv3x3_relu_o16")
+    return (out, out2) if both else out
 
 
 class FlatParameters:

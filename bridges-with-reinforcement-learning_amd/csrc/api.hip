@@ -647,28 +647,49 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
 }
 
 // ---- conv3x3 + bias + ReLU [+ pool] for the 64-wide, 16-output-channel layers (conv_kernels.hip) ------------------
-int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in,
-                             int32_t H, int32_t W, int32_t pool, void* stream) {
+int bridges_conv3x3_relu_o16_ex(const float* x, const float* x2, const float* w, const float* bias, float* out, float* out2,
+                                const float* proj_w, const float* proj_b, int64_t n, int32_t c_in, int32_t c_in2, int32_t H,
+                                int32_t W, int32_t mode, void* stream) {
     if (n < 0 || !x || !w || !bias || !out) return fail_arg("bridges_conv3x3_relu_o16");
     if (W != CONV_W || H <= 0 || (H % CONV_BAND) != 0) return fail_arg("bridges_conv3x3_relu_o16: W must be 64 and H a multiple of 8");
-    if (!(c_in >= 1 && c_in <= 4) && c_in != 16 && c_in != 32) return fail_arg("bridges_conv3x3_relu_o16: C_in must be 1..4, 16 or 32");
-    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 15)) return fail_arg("bridges_conv3x3_relu_o16: x / out must be 16-byte aligned");
+    if (mode < CONV_EPI_PLAIN || mode > CONV_EPI_PROJ) return fail_arg("bridges_conv3x3_relu_o16: mode");
+    if (mode == CONV_EPI_BOTH && !out2) return fail_arg("bridges_conv3x3_relu_o16: out2 missing");
+    if (mode == CONV_EPI_PROJ && (!proj_w || !proj_b)) return fail_arg("bridges_conv3x3_relu_o16: projection weights missing");
+    if (x2) {
+        if (c_in != 16 || c_in2 != 16) return fail_arg("bridges_conv3x3_relu_o16: two inputs must hold 16 channels each");
+    } else {
+        c_in2 = 0;
+        if (!(c_in >= 1 && c_in <= 4) && c_in != 16 && c_in != 32) return fail_arg("bridges_conv3x3_relu_o16: C_in must be 1..4, 16 or 32");
+    }
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)out) & 15) || (((uintptr_t)x2) & 15) || (((uintptr_t)out2) & 7))
+        return fail_arg("bridges_conv3x3_relu_o16: tensors must be 16-byte aligned");
     if (n == 0) return BRIDGES_OK;
     const int64_t blocks = n * (H / CONV_BAND);
     if (blocks > 0x7fffffff) return fail_arg("bridges_conv3x3_relu_o16: too many images");
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)blocks), b(256);
-#define CONV_LAUNCH(CC, NC)                                                                                   \
-    do {                                                                                                      \
-        if (pool) hipLaunchKernelGGL((k_conv3x3_o16<CC, NC, true>), g, b, 0, st, x, w, bias, out, (int)H, (int)c_in);     \
-        else hipLaunchKernelGGL((k_conv3x3_o16<CC, NC, false>), g, b, 0, st, x, w, bias, out, (int)H, (int)c_in);         \
+#define CONV_LAUNCH_E(CC, NC, E)                                                                                        \
+    hipLaunchKernelGGL((k_conv3x3_o16<CC, NC, E>), g, b, 0, st, x, x2, w, bias, out, out2, proj_w, proj_b, (int)H, (int)c_in, (int)c_in2)
+#define CONV_LAUNCH(CC, NC)                                                                                             \
+    do {                                                                                                                \
+        if (mode == CONV_EPI_PLAIN) CONV_LAUNCH_E(CC, NC, CONV_EPI_PLAIN);                                              \
+        else if (mode == CONV_EPI_POOL) CONV_LAUNCH_E(CC, NC, CONV_EPI_POOL);                                           \
+        else if (mode == CONV_EPI_BOTH) CONV_LAUNCH_E(CC, NC, CONV_EPI_BOTH);                                           \
+        else CONV_LAUNCH_E(CC, NC, CONV_EPI_PROJ);                                                                      \
     } while (0)
-    if (c_in <= 4) CONV_LAUNCH(4, 1);
-    else if (c_in == 16) CONV_LAUNCH(16, 1);
-    else CONV_LAUNCH(16, 2);
+    if (x2 || c_in == 32) CONV_LAUNCH(16, 2);
+    else if (c_in <= 4) CONV_LAUNCH(4, 1);
+    else CONV_LAUNCH(16, 1);
 #undef CONV_LAUNCH
+#undef CONV_LAUNCH_E
     LAUNCH_CHECK("k_conv3x3_o16");
     return BRIDGES_OK;
+}
+
+int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in,
+                             int32_t H, int32_t W, int32_t pool, void* stream) {
+    return bridges_conv3x3_relu_o16_ex(x, nullptr, w, bias, out, nullptr, nullptr, nullptr, n, c_in, 0, H, W,
+                                       pool ? CONV_EPI_POOL : CONV_EPI_PLAIN, stream);
 }
 
 }  // extern "C"

@@ -25,9 +25,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CONV_PLANE ((CONV_BAND + 2) * CONV_LDS_W)      // 720 floats per input channel
 
 // CIN_CHUNK = input channels staged at once (4 or 16), N_CHUNKS chunks in total (C_in = CIN_CHUNK * N_CHUNKS).
-template <int CIN_CHUNK, int N_CHUNKS, bool POOL>
-__global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ out, int H, int c_in) {
+// Epilogues: what leaves the kernel after relu(conv + bias)
+#define CONV_EPI_PLAIN 0      // out [n,16,H,64]
+#define CONV_EPI_POOL 1       // out [n,16,H/2,32] = MaxPool2d(2)
+#define CONV_EPI_BOTH 2       // out = plain AND out2 = pooled (U-Net encoder: the skip tensor and the next level's input)
+#define CONV_EPI_PROJ 3       // out [n,1,H,64] = sum_c proj_w[c] * relu(...)_c + proj_b (a 1x1 convolution to one channel behind it)
+
+// x2 != nullptr: the input channels come from two tensors, chunk 0 from x (c_in channels), chunk 1 from x2 (c_in2) -- the
+// torch.cat([upconv(u), skip], dim=1) in front of a U-Net decoder convolution without materialising it.
+template <int CIN_CHUNK, int N_CHUNKS, int EPI>
+__global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x, const float* __restrict__ x2,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out, float* __restrict__ out2,
+                                                     const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+                                                     int H, int c_in, int c_in2) {
+    constexpr bool POOL = (EPI == CONV_EPI_POOL);
+    const int c_w = c_in + c_in2;                                // input channels of the weight tensor
     // c_in = channels the tensors really hold (<= CIN_CHUNK * N_CHUNKS; the missing ones count as zero planes)
     constexpr int GROUPS = CIN_CHUNK / 4;                        // channel groups of 4 per chunk
     constexpr int KSTEPS = 9 * GROUPS;                           // MFMAs per tile and chunk
@@ -45,7 +58,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
     for (int chunk = 0; chunk < N_CHUNKS; ++chunk) {
         if (chunk) __syncthreads();                              // the previous chunk's reads are done
         // ---- stage [CIN_CHUNK][10][72]: 16 threads per row (float4 each), zero halo rows / columns
-        const float* xin = x + ((size_t)n * c_in + (size_t)chunk * CIN_CHUNK) * H * CONV_W;
+        const bool second = (x2 != nullptr && chunk == 1);
+        const int c_here = second ? c_in2 : c_in;                // channels of the tensor this chunk reads
+        const int c_base = second ? 0 : chunk * CIN_CHUNK;       // first channel of the chunk inside that tensor
+        const float* xin = (second ? x2 : x) + ((size_t)n * c_here + c_base) * H * CONV_W;
         // (all global loads are issued before the first LDS write: one memory latency per band, not one per pass)
         constexpr int ITEMS = CIN_CHUNK * (CONV_BAND + 2) * 18;
         constexpr int SLOTS = (ITEMS + 255) / 256;
@@ -56,7 +72,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
             const int seg = i % 18, rr = (i / 18) % (CONV_BAND + 2), c = i / (18 * (CONV_BAND + 2));
             const int y = y0 - 1 + rr;
             stage[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < ITEMS && seg >= 1 && seg <= 16 && y >= 0 && y < H && chunk * CIN_CHUNK + c < c_in)
+            if (i < ITEMS && seg >= 1 && seg <= 16 && y >= 0 && y < H && c_base + c < c_here)
                 stage[u] = *reinterpret_cast<const float4*>(xin + ((size_t)c * H + y) * CONV_W + 4 * (seg - 1));
         }
         // ---- B fragments of this chunk: B[k = q][cout = px] for every (tap, group)
@@ -64,8 +80,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int tap = s / GROUPS, g = s % GROUPS;
-            const int cin = chunk * CIN_CHUNK + 4 * g + q;
-            bf[s] = cin < c_in ? w[((size_t)px * c_in + cin) * 9 + tap] : 0.f;
+            const int cl = 4 * g + q;                            // channel inside the chunk
+            const int cin = (second ? c_in : c_base) + cl;       // its index in the weight tensor
+            const bool live = c_base + cl < c_here;
+            const int cin_ld = live ? cin : 0;                   // unconditional load: a guarded one is not hoisted over the
+            const float wv = w[((size_t)px * c_w + cin_ld) * 9 + tap];    // staging and costs a second memory latency (0.65 vs 0.43 ms)
+            bf[s] = live ? wv : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
     // ---- epilogue: lane = (cout = px, pixels 4 q .. 4 q + 3 of the tile)
     const float b = bias[px];
     const int y = y0 + 2 * wave;
-    if (POOL) {
-        float* o = out + (((size_t)n * 16 + px) * (H / 2) + (y >> 1)) * (CONV_W / 2);
+    if (EPI == CONV_EPI_POOL || EPI == CONV_EPI_BOTH) {
+        float* o = (EPI == CONV_EPI_BOTH ? out2 : out) + (((size_t)n * 16 + px) * (H / 2) + (y >> 1)) * (CONV_W / 2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const f32x4 u = acc[0][c], v = acc[1][c];
@@ -105,7 +125,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
             p.y = fmaxf(fmaxf(fmaxf(u[2], u[3]), fmaxf(v[2], v[3])) + b, 0.f);
             *reinterpret_cast<float2*>(o + 8 * c + 2 * q) = p;
         }
-    } else {
+    }
+    if (EPI == CONV_EPI_PLAIN || EPI == CONV_EPI_BOTH) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             float* o = out + (((size_t)n * 16 + px) * H + (y + r)) * CONV_W;
@@ -115,6 +136,29 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
                 float4 p;
                 p.x = fmaxf(u[0] + b, 0.f); p.y = fmaxf(u[1] + b, 0.f); p.z = fmaxf(u[2] + b, 0.f); p.w = fmaxf(u[3] + b, 0.f);
                 *reinterpret_cast<float4*>(o + 16 * c + 4 * q) = p;
+            }
+        }
+    }
+    if (EPI == CONV_EPI_PROJ) {
+        // 1x1 convolution to one channel: the 16 channels of a pixel sit in the 16 lanes px = 0..15 of a lane group
+        const float pw = proj_w[px], pb = proj_b[0];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float* o = out + ((size_t)n * H + (y + r)) * CONV_W;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 u = acc[r][c];
+                float4 p;
+                p.x = pw * fmaxf(u[0] + b, 0.f); p.y = pw * fmaxf(u[1] + b, 0.f);
+                p.z = pw * fmaxf(u[2] + b, 0.f); p.w = pw * fmaxf(u[3] + b, 0.f);
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {               // sum over the 16 lanes of the group (fixed butterfly order)
+                    p.x += __shfl_xor(p.x, m); p.y += __shfl_xor(p.y, m); p.z += __shfl_xor(p.z, m); p.w += __shfl_xor(p.w, m);
+                }
+                if (px == 0) {
+                    p.x += pb; p.y += pb; p.z += pb; p.w += pb;
+                    *reinterpret_cast<float4*>(o + 16 * c + 4 * q) = p;
+                }
             }
         }
     }

@@ -184,14 +184,29 @@ class UNet(nn.Module):
     def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
         x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1)
         cr = _conv_relu if (_fused_inference(x) and x.shape[-1] % 16 == 0) else (lambda conv, t: F.relu(conv(t)))
-        s1 = cr(self.e12, cr(self.e11, x))
-        s2 = cr(self.e22, cr(self.e21, self.pool1(s1)))
-        b = cr(self.e32, cr(self.e31, self.pool2(s2)))
-        u = torch.cat([self.upconv3(b), s2], dim=1)
-        u = cr(self.d32, cr(self.d31, u))
-        u = torch.cat([self.upconv4(u), s1], dim=1)
-        u = cr(self.d42, cr(self.d41, u))
-        out = self.outconv(u)
+        from bridges_hip import dqn_ops
+        if _fused_inference(x) and dqn_ops.conv3x3_relu_o16_applies(x, self.e11):
+            # 64x64 inference: the four 16-channel layers on the hand-written kernel with their neighbours folded in -- the
+            # first pooling comes out of e12 together with the skip tensor, d41 reads (upconv4, skip) without the
+            # concatenation, the 1x1 outconv to one channel is d42's epilogue
+            s1, p1 = dqn_ops.conv3x3_relu_o16(cr(self.e11, x), self.e12.weight, self.e12.bias, both=True)
+            s2 = cr(self.e22, cr(self.e21, p1))
+            b = cr(self.e32, cr(self.e31, self.pool2(s2)))
+            u = torch.cat([self.upconv3(b), s2], dim=1)
+            u = cr(self.d32, cr(self.d31, u))
+            u = dqn_ops.conv3x3_relu_o16(self.upconv4(u), self.d41.weight, self.d41.bias, x2=s1)
+            if self.n_class == 1:
+                return dqn_ops.conv3x3_relu_o16(u, self.d42.weight, self.d42.bias, proj=(self.outconv.weight, self.outconv.bias))
+            out = self.outconv(cr(self.d42, u))
+        else:
+            s1 = cr(self.e12, cr(self.e11, x))
+            s2 = cr(self.e22, cr(self.e21, self.pool1(s1)))
+            b = cr(self.e32, cr(self.e31, self.pool2(s2)))
+            u = torch.cat([self.upconv3(b), s2], dim=1)
+            u = cr(self.d32, cr(self.d31, u))
+            u = torch.cat([self.upconv4(u), s1], dim=1)
+            u = cr(self.d42, cr(self.d41, u))
+            out = self.outconv(u)
         if self.n_class == 2:
             out = out.softmax(dim=1)[:, 1]
         return out

@@ -326,6 +326,15 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
  * c_in in {1..4, 16, 32}, H % 8 == 0.  Same function as torch's conv2d + relu (+ max_pool2d) up to f32 summation order. */
 int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in,
                              int32_t H, int32_t W, int32_t pool, void* stream);
+/* The same kernel with the U-Net's neighbours folded in (cv.py:184-197):
+ *   x2 != NULL: the 32 input channels are torch.cat([x, x2], dim=1) of two 16-channel tensors (decoder: up-convolution
+ *               output + skip tensor), never materialised;
+ *   mode 0 plain, 1 pooled, 2 both (out = relu(conv) [n,16,H,64] AND out2 = its MaxPool2d(2) [n,16,H/2,32]: the encoder's
+ *        skip tensor and next level), 3 projection (out [n,1,H,64] = sum_c proj_w[c] * relu(conv)_c + proj_b[0]: the
+ *        1x1 outconv to one channel behind the last decoder convolution). */
+int bridges_conv3x3_relu_o16_ex(const float* x, const float* x2, const float* w, const float* bias, float* out, float* out2,
+                                const float* proj_w, const float* proj_b, int64_t n, int32_t c_in, int32_t c_in2, int32_t H,
+                                int32_t W, int32_t mode, void* stream);
 
 #ifdef __cplusplus
 }

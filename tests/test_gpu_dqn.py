@@ -385,3 +385,27 @@ def test_hand_written_conv3x3_matches_torch(c_in, H, n, pool):
     err = float((out.double() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
     assert bool(((out == 0) == (ref.float() <= 0)).float().mean() > 0.999)        # the ReLU pattern agrees
+
+
+def test_hand_written_conv3x3_unet_variants_match_torch():
+    """The U-Net's neighbours folded into the kernel (cv.py:184-197): plain + pooled output from one launch, the
+    decoder's torch.cat([up, skip]) read from the two tensors, the 1x1 outconv to one channel as epilogue."""
+    import torch.nn.functional as F
+    from bridges_hip import dqn_ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, H = 3, 64
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    x, x2 = r(n, 16, H, 64), r(n, 16, H, 64)
+    w16, w32, b = r(16, 16, 3, 3) / 12.0, r(16, 32, 3, 3) / 17.0, r(16)
+    err = lambda a, ref: float((a.double() - ref).abs().max() / ref.abs().max())
+    ref = F.relu(F.conv2d(x.double(), w16.double(), b.double(), padding=1))
+    plain, pooled = dqn_ops.conv3x3_relu_o16(x, w16, b, both=True)
+    assert err(plain, ref) < 1e-5 and err(pooled, F.max_pool2d(ref, 2)) < 1e-5
+    assert torch.equal(pooled, F.max_pool2d(plain, 2))                  # the two outputs of one launch are consistent
+    ref2 = F.relu(F.conv2d(torch.cat([x, x2], dim=1).double(), w32.double(), b.double(), padding=1))
+    assert err(dqn_ops.conv3x3_relu_o16(x, w32, b, x2=x2), ref2) < 1e-5
+    assert err(dqn_ops.conv3x3_relu_o16(torch.cat([x, x2], dim=1), w32, b), ref2) < 1e-5
+    w1, b1 = r(1, 16, 1, 1), r(1)
+    ref3 = F.conv2d(ref, w1.double(), b1.double())
+    out = dqn_ops.conv3x3_relu_o16(x, w16, b, proj=(w1, b1))
+    assert out.shape == (n, 1, H, 64) and err(out, ref3) < 1e-5
