@@ -122,6 +122,26 @@ def conv3x3_relu_o16(x, weight, bias, pool=False, x2=None, both=False, proj=None
     return (out, out2) if both else out
 
 
+def upconv2x2_applies(x, up):
+    """ConvTranspose2d(kernel 2, stride 2) layers the hand-written kernel covers (the U-Net's upconv3 / upconv4)."""
+    return ((up.in_channels, up.out_channels) in ((32, 16), (64, 32)) and tuple(up.kernel_size) == (2, 2)
+            and tuple(up.stride) == (2, 2) and tuple(up.padding) == (0, 0) and tuple(up.output_padding) == (0, 0)
+            and up.groups == 1 and up.bias is not None and x.dim() == 4 and x.shape[3] % 16 == 0
+            and x.dtype == torch.float32 and x.is_cuda)
+
+
+def upconv2x2(x, weight, bias):
+    """conv_transpose2d(x, weight, bias, stride=2) for a 2x2 kernel by bridges_upconv2x2 (f32 matrix cores)."""
+    L = abi.require_gpu()
+    x = x.contiguous()
+    n, c_in, H, W = x.shape
+    c_out = weight.shape[1]
+    out = torch.empty((n, c_out, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    abi.check(L.bridges_upconv2x2(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out), n, c_in, c_out, H, W,
+                                  _stream()), "bridges_upconv2x2")
+    return out
+
+
 class FlatParameters:
     """All parameters and float buffers of a module re-pointed into ONE contiguous float32 device buffer, so the
     Polyak update of a 6.4 M-parameter SuccessorMLP is a single launch instead of one per state_dict key."""

@@ -692,4 +692,20 @@ int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, 
                                        pool ? CONV_EPI_POOL : CONV_EPI_PLAIN, stream);
 }
 
+int bridges_upconv2x2(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in, int32_t c_out,
+                      int32_t H, int32_t W, void* stream) {
+    if (n < 0 || !x || !w || !bias || !out || H <= 0 || W <= 0 || (W % 16) != 0) return fail_arg("bridges_upconv2x2: W must be a multiple of 16");
+    if (!((c_in == 32 && c_out == 16) || (c_in == 64 && c_out == 32))) return fail_arg("bridges_upconv2x2: (C_in, C_out) must be (32, 16) or (64, 32)");
+    if ((((uintptr_t)out) & 15) || (((uintptr_t)w) & 7)) return fail_arg("bridges_upconv2x2: out must be 16-byte, w 8-byte aligned");
+    if (n == 0) return BRIDGES_OK;
+    const int64_t tiles = n * H * (W / 16);
+    const int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 0x7fffffff) return fail_arg("bridges_upconv2x2: too many images");
+    hipStream_t st = (hipStream_t)stream;
+    if (c_in == 32) hipLaunchKernelGGL((k_upconv2x2<32, 1>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, (int)H, (int)W, (long)tiles);
+    else hipLaunchKernelGGL((k_upconv2x2<64, 2>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, out, (int)H, (int)W, (long)tiles);
+    LAUNCH_CHECK("k_upconv2x2");
+    return BRIDGES_OK;
+}
+
 }  // extern "C"

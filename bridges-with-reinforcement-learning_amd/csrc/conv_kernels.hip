@@ -165,3 +165,56 @@ __global__ __launch_bounds__(256) void k_conv3x3_o16(const float* __restrict__ x
 }
 
 }  // namespace bridges
+
+namespace bridges {
+
+// ConvTranspose2d(kernel 2, stride 2) + bias (cv.py:176, 179 UNet upconv3 / upconv4), inference passes:
+//   out[n][co][2y + dy][2x + dx] = bias[co] + sum_ci in[n][ci][y][x] * w[ci][co][dy][dx].
+// Per image a [H W x C_in] . [C_in x 4 C_out] product whose 384 KiB (upconv4) of traffic bound it; the library runs it as
+// a GEMM plus a col2im pass.  Here: v_mfma_f32_16x16x4_f32 with M = 16 input pixels along x, K = 4 input channels,
+// N = 16 output channels of one (dy, dx); the A operand is read straight from global memory (lane l: channel 4 g + (l >> 4),
+// pixel x0 + (l & 15): 64-B runs) and serves all 4 C_out / 16 column tiles; a lane ends up with 4 consecutive input pixels
+// for dx = 0 and dx = 1, i.e. 8 consecutive output pixels: two 16-B stores.
+// One wave = one tile of 16 input pixels; CO_TILES = C_out / 16.
+template <int C_IN, int CO_TILES>
+__global__ __launch_bounds__(256) void k_upconv2x2(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int H, int W,
+                                                   long n_tiles) {
+    constexpr int C_OUT = 16 * CO_TILES;
+    constexpr int KS = C_IN / 4;
+    const int lane = threadIdx.x & 63, px = lane & 15, q = lane >> 4;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int xt = W / 16;                                       // tiles per input row
+    const long n = tile / ((long)H * xt);
+    const int rem = (int)(tile % ((long)H * xt)), y = rem / xt, x0 = (rem % xt) * 16;
+    float a[KS];
+#pragma unroll
+    for (int g = 0; g < KS; ++g) a[g] = x[(((size_t)n * C_IN + 4 * g + q) * H + y) * W + x0 + px];
+    const int Wo = 2 * W;
+#pragma unroll
+    for (int ct = 0; ct < CO_TILES; ++ct) {
+        const int co = 16 * ct + px;
+        const float bv = bias[co];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                const float* wp = w + (((size_t)(4 * g + q) * C_OUT + co) * 2 + dy) * 2;        // B[k = q][j = px], dx = 0 / 1
+                const float2 wv = *reinterpret_cast<const float2*>(wp);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], wv.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g], wv.y, acc1, 0, 0, 0);
+            }
+            // lane: channel co, input pixels x0 + 4 q + u (u = 0..3) -> output pixels 2 (x0 + 4 q) .. + 7 of row 2 y + dy
+            float* o = out + (((size_t)n * C_OUT + co) * (2 * H) + 2 * y + dy) * Wo + 2 * (x0 + 4 * q);
+            float4 lo, hi;
+            lo.x = acc0[0] + bv; lo.y = acc1[0] + bv; lo.z = acc0[1] + bv; lo.w = acc1[1] + bv;
+            hi.x = acc0[2] + bv; hi.y = acc1[2] + bv; hi.z = acc0[3] + bv; hi.w = acc1[3] + bv;
+            *reinterpret_cast<float4*>(o) = lo;
+            *reinterpret_cast<float4*>(o + 4) = hi;
+        }
+    }
+}
+
+}  // namespace bridges

@@ -192,9 +192,10 @@ class UNet(nn.Module):
             s1, p1 = dqn_ops.conv3x3_relu_o16(cr(self.e11, x), self.e12.weight, self.e12.bias, both=True)
             s2 = cr(self.e22, cr(self.e21, p1))
             b = cr(self.e32, cr(self.e31, self.pool2(s2)))
-            u = torch.cat([self.upconv3(b), s2], dim=1)
+            up = lambda m, t: dqn_ops.upconv2x2(t, m.weight, m.bias) if dqn_ops.upconv2x2_applies(t, m) else m(t)
+            u = torch.cat([up(self.upconv3, b), s2], dim=1)
             u = cr(self.d32, cr(self.d31, u))
-            u = dqn_ops.conv3x3_relu_o16(self.upconv4(u), self.d41.weight, self.d41.bias, x2=s1)
+            u = dqn_ops.conv3x3_relu_o16(up(self.upconv4, u), self.d41.weight, self.d41.bias, x2=s1)
             if self.n_class == 1:
                 return dqn_ops.conv3x3_relu_o16(u, self.d42.weight, self.d42.bias, proj=(self.outconv.weight, self.outconv.bias))
             out = self.outconv(cr(self.d42, u))

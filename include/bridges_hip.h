@@ -335,6 +335,11 @@ int bridges_conv3x3_relu_o16(const float* x, const float* w, const float* bias, 
 int bridges_conv3x3_relu_o16_ex(const float* x, const float* x2, const float* w, const float* bias, float* out, float* out2,
                                 const float* proj_w, const float* proj_b, int64_t n, int32_t c_in, int32_t c_in2, int32_t H,
                                 int32_t W, int32_t mode, void* stream);
+/* ConvTranspose2d(kernel_size=2, stride=2) + bias of the U-Net decoder (cv.py:176, 179 upconv3 / upconv4), inference:
+ * x [n, c_in, H, W] f32 NCHW (W % 16 == 0), w [c_in, c_out, 2, 2], bias [c_out] -> out [n, c_out, 2H, 2W];
+ * (c_in, c_out) = (32, 16) or (64, 32). */
+int bridges_upconv2x2(const float* x, const float* w, const float* bias, float* out, int64_t n, int32_t c_in, int32_t c_out,
+                      int32_t H, int32_t W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -409,3 +409,18 @@ def test_hand_written_conv3x3_unet_variants_match_torch():
     ref3 = F.conv2d(ref, w1.double(), b1.double())
     out = dqn_ops.conv3x3_relu_o16(x, w16, b, proj=(w1, b1))
     assert out.shape == (n, 1, H, 64) and err(out, ref3) < 1e-5
+
+
+@pytest.mark.parametrize("c_in,c_out,H,W,n", [(32, 16, 32, 32, 3), (64, 32, 16, 16, 5), (32, 16, 8, 48, 2)])
+def test_hand_written_upconv_matches_torch(c_in, c_out, H, W, n):
+    """bridges_upconv2x2 (ConvTranspose2d(kernel 2, stride 2) + bias, cv.py:176, 179) against torch in float64."""
+    import torch.nn.functional as F
+    from bridges_hip import dqn_ops
+    g = torch.Generator(device="cuda").manual_seed(c_in + H)
+    x = torch.randn(n, c_in, H, W, device="cuda", generator=g)
+    w = torch.randn(c_in, c_out, 2, 2, device="cuda", generator=g) / c_in ** 0.5
+    b = torch.randn(c_out, device="cuda", generator=g)
+    out = dqn_ops.upconv2x2(x, w, b)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    assert out.shape == ref.shape
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5
