@@ -288,9 +288,11 @@ def main():
     names, obstacles, targets, task_label = task_of(args)
     geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
     V = sum(g.num_faces_2d for g in geoms) / len(geoms)
-    kw = dict(max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev, f32_rasters=not args.no_f32_rasters,
-              debug=args.debug, sparse_raster_update=args.sparse_raster_update)
     cand_mode = args.mode == "candidate-stability"
+    # the per-env "last block frozen" tableau snapshots only serve candidate_stability_mask(): kept in that mode only
+    kw = dict(max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev, f32_rasters=not args.no_f32_rasters,
+              debug=args.debug, sparse_raster_update=args.sparse_raster_update,
+              candidate_snapshots=cand_mode or bool(os.environ.get("BENCH_SNAPSHOTS")))
     if cand_mode:
         env = VecAssemblyGym(args.envs, geoms, obstacles, targets, env_id_base=0, **kw)
         cand_ev, cand_count = [], []
