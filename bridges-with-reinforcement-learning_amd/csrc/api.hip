@@ -46,6 +46,8 @@ struct bridges_env {
     int32_t* h_total;          // pinned: candidate count of the previous lock-step (sizes the raster / expand grids)
     int max_blocks;            // upper bound of a useful grid
     int split_permille;        // > 0: rasteriser launched as head (this share of the expected items) + tail
+    hipStream_t raster_stream; // != nullptr: the rasteriser runs on this stream (event-ordered with the caller's stream)
+    hipEvent_t pre_done;       // the kernels in front of the rasteriser are done (recorded on the caller's stream)
     // optional per-launch timing of the dominant kernel (k_raster) with HIP events on the launch stream
     hipEvent_t* ev_start;
     hipEvent_t* ev_stop;
@@ -127,6 +129,8 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     env->ev_cap = env->ev_used = 0;
     env->gate = nullptr;
     env->raster_done = nullptr;
+    env->raster_stream = nullptr;
+    env->pre_done = nullptr;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     (void)cus;
@@ -154,6 +158,7 @@ int bridges_env_destroy(bridges_env* env) {
     if (!env) return BRIDGES_OK;
     free_events(env);
     if (env->raster_done) (void)hipEventDestroy(env->raster_done);
+    if (env->pre_done) (void)hipEventDestroy(env->pre_done);
     (void)hipFree(env->tt_dev);
     (void)hipHostFree(env->h_total);
     delete env;
@@ -178,6 +183,28 @@ int bridges_env_set_gate(bridges_env* env, bridges_gate* gate) {
     if (!env) return fail_arg("set_gate");
     if (gate && !env->raster_done) HIP_TRY(hipEventCreateWithFlags(&env->raster_done, hipEventDisableTiming));
     env->gate = gate;
+    return BRIDGES_OK;
+}
+
+int bridges_env_set_raster_stream(bridges_env* env, void* raster_stream) {
+    if (!env) return fail_arg("set_raster_stream");
+    if (raster_stream && !env->raster_done) HIP_TRY(hipEventCreateWithFlags(&env->raster_done, hipEventDisableTiming));
+    if (raster_stream && !env->pre_done) HIP_TRY(hipEventCreateWithFlags(&env->pre_done, hipEventDisableTiming));
+    env->raster_stream = (hipStream_t)raster_stream;
+    return BRIDGES_OK;
+}
+
+int bridges_stream_create_masked(const uint32_t* cu_mask, int32_t n_words, void** out_stream) {
+    if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) return fail_arg("bridges_stream_create_masked");
+    hipStream_t st = nullptr;
+    if (n_words == 0) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    else HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+    *out_stream = (void*)st;
+    return BRIDGES_OK;
+}
+
+int bridges_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return BRIDGES_OK;
 }
 
@@ -238,6 +265,22 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     long long rblocks = (items_est + 3) / 4;
     if (rblocks > env->max_blocks) rblocks = env->max_blocks;
     const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
+    if (env->raster_stream) {
+        // the rasterisers of all groups share ONE stream (they run back to back without a cross-queue hand-over between
+        // them); this group's stream only hands its candidate list over and takes the masks back
+        hipStream_t rs = env->raster_stream;
+        HIP_TRY(hipEventRecord(env->pre_done, s));
+        HIP_TRY(hipStreamWaitEvent(rs, env->pre_done, 0));
+        if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], rs));
+        hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, rs, c, 0, 0x7fffffff);
+        LAUNCH_CHECK("k_raster");
+        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], rs)); env->ev_used++; }
+        HIP_TRY(hipEventRecord(env->raster_done, rs));
+        HIP_TRY(hipStreamWaitEvent(s, env->raster_done, 0));
+        hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
+        LAUNCH_CHECK("k_select");
+        return BRIDGES_OK;
+    }
     if (env->gate && env->gate->last) HIP_TRY(hipStreamWaitEvent(s, env->gate->last, 0));
     if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
     if (env->gate && env->split_permille > 0 && env->split_permille < 1000) {

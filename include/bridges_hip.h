@@ -184,6 +184,14 @@ typedef struct bridges_gate bridges_gate;
 int bridges_gate_create(bridges_gate** out);
 int bridges_gate_destroy(bridges_gate* gate);
 int bridges_env_set_gate(bridges_env* env, bridges_gate* gate);
+/* Run this env's rasteriser on `raster_stream` instead of the stream passed to bridges_env_step (NULL: back to one
+ * stream).  With several env groups sharing ONE raster stream their rasterisers run back to back in stream order
+ * while each group's latency-bound kernels stay on the group's own stream (which may carry a CU mask). */
+int bridges_env_set_raster_stream(bridges_env* env, void* raster_stream);
+/* A HIP stream restricted to the compute units whose bits are set in cu_mask (n_words 32-bit words; 0 words: an
+ * ordinary non-blocking stream), for the caller to pass as `stream` / `raster_stream`. */
+int bridges_stream_create_masked(const uint32_t* cu_mask, int32_t n_words, void** out_stream);
+int bridges_stream_destroy(void* stream);
 /* With a gate: launch the rasteriser of a lock-step as a head (head_permille / 1000 of the expected images) and a tail,
  * and release the gate behind the head, so the next group's rasteriser starts while this one's tail drains.
  * 0 = one launch (default).  Results do not depend on it. */
