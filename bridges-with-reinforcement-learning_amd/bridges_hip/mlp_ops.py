@@ -65,12 +65,16 @@ class FusedSuccessorStep:
         self.dz = [z(self.rows, d) for d in dims[1:]]                # gradient at the pre-activation of every layer
         self.ws = torch.empty(self.WS_FLOATS, dtype=torch.float32, device=dev)
         self.loss_rows, self.q = z(self.rows), z(self.rows)
+        # the gradient tensors the launches write: referenced here as well, so a later zero_grad(set_to_none=True) cannot
+        # hand their memory to someone else while a captured graph still writes to it
+        self._grads = []
         for lin in self.linears:
             for p in (lin.weight, lin.bias):
                 assert p.dtype == torch.float32 and p.is_contiguous()
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 assert p.grad.is_contiguous()
+                self._grads.append(p.grad)
 
     def launch(self, counter, block_all, action_all, binary_all, reward, obstacle, q_target_all, sf_target_all, losses):
         L, rows, px, nf, B = self.L, self.rows, self.px, self.nf, self.batch
