@@ -294,3 +294,19 @@ def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "9", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+
+
+def test_image_size_rule_and_deferred_losses_without_a_gpu():
+    """Host-side pieces that need no device: the image sizes the rasteriser accepts (--image_size, successor_dqn.py:585)
+    and the empty DeferredLosses a training call returns before the replay holds a batch."""
+    import torch
+    from bridges_hip import ops
+    from robotoddler.training.vec_dqn import DeferredLosses
+    assert ops.image_size((64, 64)) == 64 and ops.image_size((17, 17)) == 17 and ops.image_size([2, 2]) == 2
+    for bad in ((128, 128), (64, 32), (1, 1), (0, 0)):
+        with pytest.raises(NotImplementedError):
+            ops.image_size(bad)
+    canvas = torch.arange(2 * 64 * 64, dtype=torch.float32).reshape(2, 64, 64)
+    assert ops.crop(canvas, (64, 64)) is canvas
+    assert torch.equal(ops.crop(canvas, (8, 8)), canvas[:, :8, :8])
+    assert DeferredLosses(None, None, None).get() == []
