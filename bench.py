@@ -239,6 +239,8 @@ def parse_args():
                          "released behind it); 0 = one launch")
     ap.add_argument("--mode", choices=["sim", "candidate-stability"], default="sim",
                     help="candidate-stability: every lock-step also decides is_action_stable_rbe for every valid candidate")
+    ap.add_argument("--snapshots", action="store_true",
+                    help="keep the per-env tableau snapshots of the candidate-stability kernel in the simulator modes too (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
     ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
@@ -292,7 +294,7 @@ def main():
     # the per-env "last block frozen" tableau snapshots only serve candidate_stability_mask(): kept in that mode only
     kw = dict(max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev, f32_rasters=not args.no_f32_rasters,
               debug=args.debug, sparse_raster_update=args.sparse_raster_update,
-              candidate_snapshots=cand_mode or bool(os.environ.get("BENCH_SNAPSHOTS")))
+              candidate_snapshots=cand_mode or args.snapshots)
     if cand_mode:
         env = VecAssemblyGym(args.envs, geoms, obstacles, targets, env_id_base=0, **kw)
         cand_ev, cand_count = [], []
@@ -400,7 +402,8 @@ def main():
                 "env_step_fraction": env_steps / max(units, 1),
                 "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
-                "debug": args.debug, "dist_backend": backend if world > 1 else None,
+                "debug": args.debug, "tableau_snapshots": bool(cand_mode or args.snapshots),
+                "dist_backend": backend if world > 1 else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_raster",
