@@ -403,6 +403,7 @@ def main():
                 "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
                 "debug": args.debug, "tableau_snapshots": bool(cand_mode or args.snapshots),
+                "raster_stream": os.environ.get("BRIDGES_RASTER_STREAM") or None,       # experiment knob of VecAssemblyGymGroups
                 "dist_backend": backend if world > 1 else None,
             },
             "roofline": {
