@@ -49,8 +49,9 @@ __global__ void k_check(const float* out, float expect, int* bad, const int* sem
 }
 
 int main() {
-    float *x, *partial, *out; int *sem, *bad, *early;
+    float *x, *partial, *out; int *sem, *bad, *early, *sem2;
     CHECK(hipMalloc(&x, N * 4)); CHECK(hipMalloc(&partial, G * 4)); CHECK(hipMalloc(&out, 4)); CHECK(hipMalloc(&sem, 4));
+    CHECK(hipMalloc(&sem2, 4));
     CHECK(hipMalloc(&bad, 8)); CHECK(hipMalloc(&early, 4));
     float* hx = new float[N];
     double ss = 0;
@@ -64,16 +65,30 @@ int main() {
         hipLaunchKernelGGL(k_reduce, dim3(G), dim3(T), 0, st, x, partial, sem, out, early);
         hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, out, expect, bad, sem);
     };
+    // second arrangement: TWO reductions per round with DIFFERENT semaphores (two memset nodes with different
+    // destinations in one graph) -- a memset node that replays with another node's parameters shows up here only
+    auto round2 = [&](hipStream_t st) {
+        hipLaunchKernelGGL(k_poison, dim3(1), dim3(T), 0, st, partial, out);
+        hipMemsetAsync(sem, 0, 4, st);
+        hipLaunchKernelGGL(k_reduce, dim3(G), dim3(T), 0, st, x, partial, sem, out, early);
+        hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, out, expect, bad, sem);
+        hipLaunchKernelGGL(k_poison, dim3(1), dim3(T), 0, st, partial, out);
+        hipMemsetAsync(sem2, 0, 4, st);
+        hipLaunchKernelGGL(k_reduce, dim3(G), dim3(T), 0, st, x, partial, sem2, out, early);
+        hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, st, out, expect, bad, sem2);
+    };
     const int total = 20000;
-    for (int mode = 0; mode < 3; ++mode) {
-        CHECK(hipMemset(bad, 0, 8)); CHECK(hipMemset(early, 0, 4)); CHECK(hipMemset(sem, 0, 4)); CHECK(hipDeviceSynchronize());
-        const int per = mode == 0 ? 0 : (mode == 1 ? 1 : 25);
+    for (int mode = 0; mode < 5; ++mode) {
+        CHECK(hipMemset(bad, 0, 8)); CHECK(hipMemset(early, 0, 4)); CHECK(hipMemset(sem, 0, 4)); CHECK(hipMemset(sem2, 0, 4));
+        CHECK(hipDeviceSynchronize());
+        const bool two = mode >= 3;
+        const int per = mode == 0 ? 0 : (mode == 1 ? 1 : (mode == 2 ? 25 : (mode == 3 ? 1 : 25)));
         if (per == 0) {
             for (int i = 0; i < total; ++i) round(s);
         } else {
             hipGraph_t g; hipGraphExec_t ge;
             CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
-            for (int i = 0; i < per; ++i) round(s);
+            for (int i = 0; i < per; ++i) { if (two) round2(s); else round(s); }
             CHECK(hipStreamEndCapture(s, &g));
             CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             for (int i = 0; i < total / per; ++i) CHECK(hipGraphLaunch(ge, s));
@@ -84,7 +99,8 @@ int main() {
         int hb[2], he;
         CHECK(hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&he, early, 4, hipMemcpyDeviceToHost));
         printf("%-28s %d rounds: wrong results %d, semaphore != G after the kernel %d, blocks that found the semaphore dirty %d\n",
-               mode == 0 ? "stream launches" : (mode == 1 ? "graph of 1 round, replayed" : "graph of 25 rounds, replayed"), total, hb[0], hb[1], he);
+               mode == 0 ? "stream launches" : (mode == 1 ? "graph of 1 round, replayed" : (mode == 2 ? "graph of 25 rounds, replayed" :
+               (mode == 3 ? "2 semaphores, graph of 1 round" : "2 semaphores, graph of 25 rounds"))), total, hb[0], hb[1], he);
     }
     return 0;
 }
