@@ -468,7 +468,12 @@ class VecAssemblyGymGroups:
             self.sync()
             for env in self.envs:
                 env.L.bridges_env_set_gate(env._env, None)
+            for env in self.envs:
+                env.L.bridges_env_set_raster_stream(env._env, None)
             self.envs[0].L.bridges_gate_destroy(self._gate)
+            for ptr in getattr(self, "_own_streams", []):
+                self.envs[0].L.bridges_stream_destroy(ptr)
+            self._own_streams = []
         except Exception:
             pass
 
