@@ -467,7 +467,8 @@ int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bit
 int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* stream) {
     if (n < 0) return fail_arg("bridges_bits_to_f32");
     if (n == 0) return BRIDGES_OK;
-    hipLaunchKernelGGL(k_bits_to_f32, dim3(grid_for_waves(n)), dim3(256), 0, (hipStream_t)stream, n, bits, img);
+    // one short-lived wave per image, dispatched in image order (the store structure of k_raster)
+    hipLaunchKernelGGL(k_bits_to_f32, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, bits, img);
     LAUNCH_CHECK("k_bits_to_f32");
     return BRIDGES_OK;
 }

@@ -279,6 +279,26 @@ def rollout_episode_scripted(env, predefined_actions, setup_fct, x_discr_ground,
     return transitions, images
 
 
+def track_run_sinks(values, step, context, aim_run=None, wandb_run=None):
+    """The two logging sinks of log_episode (successor_dqn.py:544-565 of the reference), shared by the single-env loop
+    (step = episode) and the vectorised loop (step = finished episodes so far): aim gets one ``track(value, name=key,
+    step=step, context={'context': context})`` per value that is not None; wandb one ``log`` of a dict with the
+    reference's keys -- ``episode`` first, then the values as they are (``avg_loss`` may be None),
+    ``episode_<step>_combined_image`` (None: this build draws no matplotlib figure) and ``eval_reward`` (the linear
+    reward in an evaluation context, else None).  The reference calls the module-level ``wandb.log``; a run object's
+    ``log`` is the same call."""
+    if aim_run is not None:
+        for k, v in values.items():
+            if v is not None:
+                aim_run.track(v, name=k, step=step, context=dict(context=context))
+    if wandb_run is not None:
+        payload = {"episode": step}
+        payload.update({k: v for k, v in values.items() if k != 'epsilon'})
+        payload[f"episode_{str(step).zfill(5)}_combined_image"] = None
+        payload["eval_reward"] = values.get('lin_reward') if context == 'evaluation' else None
+        wandb_run.log(payload)
+
+
 def log_episode(episode, transitions, losses, gamma, context='training', policy=None, images=None, log_images=False,
                 wandb_run=None, aim_run=None, verbose=False):
     """Episode summary (successor_dqn.py:479-567) without the matplotlib figure; aim / wandb sinks are used when the
@@ -293,12 +313,7 @@ def log_episode(episode, transitions, losses, gamma, context='training', policy=
     }
     if policy is not None and hasattr(policy, 'epsilon'):
         info['epsilon'] = policy.epsilon
-    if aim_run is not None:
-        for k, v in info.items():
-            if v is not None:
-                aim_run.track(v, name=k, step=episode, context=dict(context=context))
-    if wandb_run is not None:
-        wandb_run.log(dict(episode=episode, **{k: v for k, v in info.items()}))
+    track_run_sinks(info, episode, context, aim_run=aim_run, wandb_run=wandb_run)
     return info, None
 
 
@@ -389,7 +404,7 @@ def main(argv=None):
         wandb_run = wandb.init(project="dual_arm", config=args)
     if args['num_envs'] > 1:
         from robotoddler.training.vec_dqn import run_vectorised
-        return run_vectorised(args, device)
+        return run_vectorised(args, device, aim_run=aim_run, wandb_run=wandb_run)
 
     x_discr_ground = np.linspace(-2, 0, 10)
     offset_values = [0]

@@ -47,6 +47,7 @@ class VecDQN:
         # replay sampling must be identical on every rank (replicated rings) -> shared seed; exploration differs
         self.sample_gen = torch.Generator(device=self.device).manual_seed(1234567 + seed)
         self.explore_gen = torch.Generator(device=self.device).manual_seed(7654321 + seed * 1000 + rank)
+        self.seed, self.rank = int(seed), int(rank)
         self.epsilon, self.eps_end, self.eps_decay = eps_start, eps_end, eps_decay
         self.step_images = torch.zeros((env.K + 1, env.img, env.img), dtype=torch.float32, device=self.device)
         # scratch env used to rebuild the candidate sets of sampled next states (see _replay_env)
@@ -452,11 +453,19 @@ class VecDQN:
                         explore_gen=self.explore_gen.get_state().cpu(), counters={k: int(v) for k, v in counters.items()}), path)
 
     def load_extra(self, path):
+        """Restores what save_extra wrote.  The file is rank 0's: exact continuation (same exploration draws, same
+        env-step count) holds for a single-rank run.  With several ranks the shared items (epsilon, count images, replay
+        sampling stream, episode counter) are restored everywhere, while a rank > 0 -- whose exploration stream and
+        env-step count were never saved -- re-seeds its exploration stream from (seed, rank, lock-step) so that the
+        ranks keep drawing different uniforms, and starts its local env-step count from rank 0's."""
         blob = torch.load(path, weights_only=True)
         self.epsilon, self.episodes_done, self.env_steps = blob["epsilon"], blob["episodes_done"], blob["env_steps"]
         self.step_images.copy_(blob["step_images"])
         self.sample_gen.set_state(blob["sample_gen"])
-        self.explore_gen.set_state(blob["explore_gen"])
+        if self.rank == 0:
+            self.explore_gen.set_state(blob["explore_gen"])
+        else:
+            self.explore_gen.manual_seed(7654321 + self.seed * 1000 + self.rank + 7919 * (int(blob["counters"].get("lockstep", 0)) + 1))
         return blob["counters"]
 
     # ------------------------------------------------------------------ driver
@@ -496,8 +505,17 @@ class DeferredLosses:
         return self._list
 
 
-def run_vectorised(args, device):
-    from robotoddler.training.successor_dqn import make_nets
+def lockstep_log_values(info):
+    """What one lock-step hands to the aim / wandb sinks, under the reference's names (successor_dqn.py:489-499) where the
+    quantity exists per lock-step: reward / lin_reward = mean over the lock-step's transitions (the reference: discounted
+    sum over one episode), avg_loss, num_steps = env-steps of the lock-step on this rank, epsilon; plus the run counters."""
+    return dict(reward=info['mean_reward'], lin_reward=info['mean_lin_reward'], avg_loss=info['avg_loss'],
+                num_steps=info['lockstep_env_steps'], epsilon=info['epsilon'], env_steps=info['env_steps'],
+                steps_per_s=info['steps_per_s'])
+
+
+def run_vectorised(args, device, aim_run=None, wandb_run=None):
+    from robotoddler.training.successor_dqn import make_nets, track_run_sinks
     backend = os.environ.get("BRIDGES_DIST_BACKEND")          # 'gloo' = rehearsal with several ranks on one card
     rank, world = D.init(backend=backend, device=device)
     names = dict(trapezoid=["trapezoid"], hexagon=["hexagon"], both=["trapezoid", "hexagon"])[args['shapes']]
@@ -531,6 +549,8 @@ def run_vectorised(args, device):
         it = agent.load_extra(os.path.join(path, 'agent.pt'))['lockstep']
         next_ckpt = (agent.episodes_done // args['checkpoint_every'] + 1) * args['checkpoint_every']
         env.reset()                                      # a checkpoint is taken with all environments freshly reset
+    steps_at_start, t0 = agent.env_steps, time.time()    # throughput counts what THIS run (resumed or not) has stepped
+
     def finish(entry):
         """Fill in the numbers of a lock-step that were still on their way to the host when its entry was made."""
         info, deferred, stats_host, done = entry
@@ -539,6 +559,9 @@ def run_vectorised(args, device):
         if stats_host is not None:
             done.synchronize()
             info['mean_reward'], info['mean_lin_reward'] = float(stats_host[0]), float(stats_host[1])
+        if rank == 0 and (aim_run is not None or wandb_run is not None):
+            # one call per lock-step, step = episodes finished so far (the reference's x axis is the episode number)
+            track_run_sinks(lockstep_log_values(info), info['episodes'], 'training', aim_run=aim_run, wandb_run=wandb_run)
         if args['verbose'] and rank == 0:
             print(info)
 
@@ -546,6 +569,7 @@ def run_vectorised(args, device):
     while agent.episodes_done < args['num_episodes']:
         # losses and record statistics are read one lock-step late: nothing here waits for the optimiser steps, so they
         # run while the host queues the next lock-step's acting
+        steps_before = agent.env_steps
         losses, rec = agent.lockstep(args['num_training_steps'], defer_losses=True)
         it += 1
         if args.get('save_checkpoint') and agent.episodes_done >= next_ckpt:                  # utils.py:54-89 layout
@@ -568,7 +592,8 @@ def run_vectorised(args, device):
             done = torch.cuda.Event()
             done.record()
         info = dict(lockstep=it, episodes=agent.episodes_done, env_steps=agent.env_steps, avg_loss=None, mean_reward=None,
-                    mean_lin_reward=None, epsilon=agent.epsilon, steps_per_s=agent.env_steps * world / (time.time() - t0))
+                    mean_lin_reward=None, epsilon=agent.epsilon, lockstep_env_steps=agent.env_steps - steps_before,
+                    steps_per_s=(agent.env_steps - steps_at_start) * world / max(time.time() - t0, 1e-9))
         history.append(info)
         if pending is not None:
             finish(pending)

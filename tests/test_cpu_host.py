@@ -310,3 +310,75 @@ def test_image_size_rule_and_deferred_losses_without_a_gpu():
     assert ops.crop(canvas, (64, 64)) is canvas
     assert torch.equal(ops.crop(canvas, (8, 8)), canvas[:, :8, :8])
     assert DeferredLosses(None, None, None).get() == []
+
+
+class _FakeAim:
+    def __init__(self):
+        self.calls = []
+
+    def track(self, value, name=None, step=None, context=None):
+        self.calls.append((name, value, step, context))
+
+
+class _FakeWandb:
+    def __init__(self):
+        self.calls = []
+
+    def log(self, payload):
+        self.calls.append(dict(payload))
+
+
+def test_log_episode_feeds_the_aim_and_wandb_sinks_like_the_reference():
+    """/root/reference/robotoddler/training/successor_dqn.py:544-565: aim gets track(v, name=k, step=episode,
+    context={'context': context}) for every value of log_info that is not None (epsilon included when a policy is
+    given); wandb.log gets episode, reward, lin_reward, avg_loss, num_steps, stable, collision,
+    episode_<00007>_combined_image (None without --log_images) and eval_reward (lin_reward in an evaluation context)."""
+    from collections import namedtuple
+    from robotoddler.training.successor_dqn import log_episode
+    T = namedtuple("T", "reward lin_reward next_binary_features")
+    trs = [T(torch.tensor([-1.0]), torch.tensor([0.25]), torch.tensor([[1.0, 0.0, 0, 0, 0, 0]])),
+           T(torch.tensor([1.0]), torch.tensor([0.5]), torch.tensor([[0.0, 0.0, 0, 0, 0, 0]]))]
+    pol = namedtuple("P", "epsilon")(0.3)
+    aim_run, wb = _FakeAim(), _FakeWandb()
+    info, fig = log_episode(7, trs, [0.5, 1.5], 0.8, policy=pol, aim_run=aim_run, wandb_run=wb)
+    assert fig is None
+    want = dict(reward=-1.0 + 0.8 * 1.0, lin_reward=0.25 + 0.8 * 0.5, avg_loss=1.0, num_steps=2, stable=0.0, collision=0.0,
+                epsilon=0.3)
+    assert info.keys() == want.keys()
+    for k, v in want.items():
+        assert info[k] == pytest.approx(v, abs=1e-6)
+    assert [c[0] for c in aim_run.calls] == list(want.keys())          # the reference's dict order
+    for name, value, step, ctx in aim_run.calls:
+        assert step == 7 and ctx == {"context": "training"} and value == pytest.approx(want[name], abs=1e-6)
+    assert len(wb.calls) == 1
+    p = wb.calls[0]
+    assert list(p.keys()) == ["episode", "reward", "lin_reward", "avg_loss", "num_steps", "stable", "collision",
+                              "episode_00007_combined_image", "eval_reward"]
+    assert p["episode"] == 7 and p["episode_00007_combined_image"] is None and p["eval_reward"] is None
+    # evaluation context, no losses: avg_loss is None -> not tracked by aim, logged as None by wandb; eval_reward set
+    aim2, wb2 = _FakeAim(), _FakeWandb()
+    info2, _ = log_episode(100, trs, None, 0.8, context="evaluation", aim_run=aim2, wandb_run=wb2)
+    assert "avg_loss" not in [c[0] for c in aim2.calls] and "epsilon" not in [c[0] for c in aim2.calls]
+    assert all(c[3] == {"context": "evaluation"} and c[2] == 100 for c in aim2.calls)
+    assert wb2.calls[0]["avg_loss"] is None and wb2.calls[0]["eval_reward"] == pytest.approx(info2["lin_reward"])
+
+
+def test_vectorised_loop_hands_every_lockstep_to_the_same_sinks():
+    """run_vectorised logs through track_run_sinks once per lock-step (step = finished episodes)."""
+    from robotoddler.training.successor_dqn import track_run_sinks
+    from robotoddler.training.vec_dqn import lockstep_log_values
+    info = dict(lockstep=3, episodes=41, env_steps=900, lockstep_env_steps=300, avg_loss=None, mean_reward=-0.5,
+                mean_lin_reward=0.125, epsilon=0.4, steps_per_s=1e5)
+    vals = lockstep_log_values(info)
+    assert list(vals)[:5] == ["reward", "lin_reward", "avg_loss", "num_steps", "epsilon"]
+    aim_run, wb = _FakeAim(), _FakeWandb()
+    track_run_sinks(vals, info["episodes"], "training", aim_run=aim_run, wandb_run=wb)
+    names = [c[0] for c in aim_run.calls]
+    assert "avg_loss" not in names and names[:2] == ["reward", "lin_reward"] and "steps_per_s" in names
+    assert all(c[2] == 41 and c[3] == {"context": "training"} for c in aim_run.calls)
+    assert wb.calls[0]["episode"] == 41 and wb.calls[0]["num_steps"] == 300 and "epsilon" not in wb.calls[0]
+    import inspect
+    from robotoddler.training import successor_dqn, vec_dqn
+    assert "aim_run=aim_run, wandb_run=wandb_run" in inspect.getsource(successor_dqn.main)
+    src = inspect.getsource(vec_dqn.run_vectorised)
+    assert "track_run_sinks(lockstep_log_values(info)" in src
