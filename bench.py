@@ -171,7 +171,7 @@ def side_modes(args):
     hardware queues inside one process moved the latency-bound modes by +-30 %."""
     me = os.path.abspath(__file__)
     base = [sys.executable, me, "--no-cpu-baseline", "--no-other-modes", "--envs", str(args.envs), "--steps", str(args.steps),
-            "--warmup", str(args.warmup), "--seed", str(args.seed)]
+            "--warmup", str(args.warmup), "--seeds", str(args.seeds).split(",")[0]]
     task = ["--tower_height", str(args.tower_height), "--max_steps", str(args.max_steps), "--shapes", args.shapes]
     if args.bridge_length:
         task += ["--bridge_length", str(args.bridge_length)]
@@ -221,6 +221,89 @@ def side_modes(args):
     return out
 
 
+# ------------------------------------------------------------------------- N > 1: BASELINE.json configs[3]
+def train_config4_leg(args, dev, rank, world, backend):
+    """configs[3] ("8 x MI355X over xGMI, 4096 envs/GPU, tower_height=4, mse_q_values+mse_block_features, shared replay via
+    RCCL all-gather") on the ranks of this run: every rank steps its own env shard, ONE all_gather_into_tensor of the
+    880-B transition records per lock-step fills every rank's replica of the replay ring, every rank takes the same 25
+    optimiser steps (robotoddler/training/vec_dqn.py, distributed.py).  Reported beside the headline, never part of
+    `value`.  Collective: the process group bench.py was started with (nccl = RCCL on a node; gloo in the rehearsal)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    from robotoddler.training import distributed as D
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    loss = "mse_q_values+mse_block_features"
+    E = int(os.environ.get("BENCH_CONFIG4_ENVS", args.envs))
+    n_ls, n_warm, n_train = int(os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")), 6, 25
+    targs = vars(build_parser().parse_args(["--model", "SuccessorMLP", "--loss_function", loss, "--learning_rate", "1e-4"]))
+    torch.manual_seed(0)                                          # identical initial weights on every rank
+    pol, tgt = make_nets(targs, dev)
+    H, n = 0.8, 4
+    env = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0.0, i * H + H / 2) for i in range(n)],
+                         [(0.5, 0.0, n * H + H / 2)], max_steps=15, seed=rank, device=dev, env_id_base=rank * E,
+                         f32_rasters=VecDQN.acting_needs_f32_rasters(pol), candidate_snapshots=False)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True)
+    agent = VecDQN(pol, tgt, opt, env, max(2000, 4 * E * world), 32, 0.95, 0.01, loss, seed=0, rank=rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(n_warm):
+        agent.lockstep(n_train)
+    sync()
+    steps0, t0 = agent.env_steps, time.perf_counter()
+    pending, rec = None, None
+    for _ in range(n_ls):
+        losses, rec_all = agent.lockstep(n_train, defer_losses=True)
+        if pending is not None:
+            pending.get()
+        pending = losses
+    last = pending.get() if pending is not None else []
+    sync()
+    dt = time.perf_counter() - t0
+    # the collective alone, on a full-size payload (every env valid), bracketed by device syncs
+    rec = torch.zeros((E, agent.ring.data.shape[1]), dtype=torch.float64, device=dev)
+    valid = torch.ones(E, dtype=torch.bool, device=dev)
+    for _ in range(3):
+        D.all_gather_records(rec, valid)
+    sync()
+    t1 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        got = D.all_gather_records(rec, valid)
+    torch.cuda.synchronize()
+    ag_ms = (time.perf_counter() - t1) / reps * 1e3
+    ring = agent.ring
+    order = (ring.head - ring.size + torch.arange(ring.size, device=ring.data.device)) % ring.capacity
+    h_ring = hashlib.sha256(ring.data[order].cpu().numpy().tobytes()).digest()[:8]
+    h_pol = hashlib.sha256(pol._flat_params.flat.detach().cpu().numpy().tobytes()).digest()[:8]
+    mine = torch.tensor([int.from_bytes(h_ring, "little", signed=True), int.from_bytes(h_pol, "little", signed=True),
+                         agent.env_steps - steps0, int(got.shape[0])], dtype=torch.int64, device=red_dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    allv = torch.stack(allv).cpu()
+    steps_all = int(allv[:, 2].sum())
+    return {"value": steps_all / float(tt[0]), "unit": "env-steps/s (all ranks: acting + record all-gather + replay + 25 optimiser steps per lock-step)",
+            "config": "BASELINE.json configs[3] on %d rank(s): %d envs/rank, tower_height=4, SuccessorMLP, %s, replicated "
+                      "replay ring filled by one all_gather_into_tensor of 888-B records per lock-step" % (world, E, loss),
+            "ms_per_lockstep": float(tt[0]) / n_ls * 1e3, "locksteps": n_ls, "ranks_seen": dist.get_world_size(),
+            "dist_backend": backend, "allgather_ms_per_lockstep": ag_ms,
+            "allgather_bytes_per_rank": int(E * (agent.ring.data.shape[1] + 1) * 8),
+            "allgather_rows_received": int(allv[0, 3]),
+            "ring_records": int(ring.size), "ring_hash_equal": bool((allv[:, 0] == allv[0, 0]).all()),
+            "policy_hash_equal": bool((allv[:, 1] == allv[0, 1]).all()),
+            "last_losses_finite": bool(all(l == l and l >= 0.0 for l in last))}
+
+
 # ------------------------------------------------------------------------- main
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -232,18 +315,17 @@ def parse_args():
     ap.add_argument("--bridge_length", type=int, default=0, help="> 0: horizontal_bridge_setup(num_obstacles=N) instead of the tower")
     ap.add_argument("--shapes", choices=["trapezoid", "hexagon", "both"], default="trapezoid")
     ap.add_argument("--max_steps", type=int, default=15)
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--seeds", type=str, default="0,1,2",
+                    help="policy seeds, one full measurement (W warm-up + K timed lock-steps) each; `value` = the median run")
     ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, one HIP stream each")
-    ap.add_argument("--raster-split", type=int, default=0,
-                    help="per mille of a lock-step's images in the rasteriser's head launch (the next group's rasteriser is "
-                         "released behind it); 0 = one launch")
     ap.add_argument("--mode", choices=["sim", "candidate-stability"], default="sim",
                     help="candidate-stability: every lock-step also decides is_action_stable_rbe for every valid candidate")
     ap.add_argument("--snapshots", action="store_true",
                     help="keep the per-env tableau snapshots of the candidate-stability kernel in the simulator modes too (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (experiment: their cost)")
-    ap.add_argument("--debug", type=int, default=0, help="kernel timing experiments (bit0: skip the LPs) -- invalidates the run")
+    ap.add_argument("--debug", type=int, default=0,
+                    help="kernel timing experiments of a diagnostic build (BRIDGES_LIB=tools/libbridges_hip_diag.so) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the child runs of the side modes")
     ap.add_argument("--sparse-raster-update", action="store_true",
@@ -291,67 +373,95 @@ def main():
     geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
     V = sum(g.num_faces_2d for g in geoms) / len(geoms)
     cand_mode = args.mode == "candidate-stability"
-    # the per-env "last block frozen" tableau snapshots only serve candidate_stability_mask(): kept in that mode only
-    kw = dict(max_steps=args.max_steps, seed=args.seed * 1000003 + rank, device=dev, f32_rasters=not args.no_f32_rasters,
-              debug=args.debug, sparse_raster_update=args.sparse_raster_update,
-              candidate_snapshots=cand_mode or args.snapshots)
-    if cand_mode:
-        env = VecAssemblyGym(args.envs, geoms, obstacles, targets, env_id_base=0, **kw)
+    seeds = [int(v) for v in str(args.seeds).split(",") if v != ""]
+
+    def measure(seed):
+        """W untimed + exactly K timed lock-steps of a freshly created environment set with policy seed `seed`.  The policy
+        RNG stream of an env is keyed by (seed, GLOBAL env id = rank * envs + e): an N-rank run steps the same
+        trajectories as one run over N * envs environments."""
+        # the per-env "last block frozen" tableau snapshots only serve candidate_stability_mask(): kept in that mode only
+        kw = dict(max_steps=args.max_steps, seed=seed, device=dev, f32_rasters=not args.no_f32_rasters,
+                  debug=args.debug, sparse_raster_update=args.sparse_raster_update,
+                  candidate_snapshots=cand_mode or args.snapshots, env_id_base=rank * args.envs)
         cand_ev, cand_count = [], []
+        if cand_mode:
+            env = VecAssemblyGym(args.envs, geoms, obstacles, targets, **kw)
 
-        def lockstep():
-            env.select_random()
-            env.step()
-            if len(cand_ev) < 4096:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                n_dec = env.candidate_stability_mask()
-                b.record()
-                cand_ev.append((a, b))
-                cand_count.append(n_dec)
-            else:
-                env.candidate_stability_mask()
-        env.sync = lambda: None
-    else:
-        env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, raster_split=args.raster_split, **kw)
-        lockstep = env.lockstep_random
+            def lockstep():
+                env.select_random()
+                env.step()
+                if len(cand_ev) < 4096:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    n_dec = env.candidate_stability_mask()
+                    b.record()
+                    cand_ev.append((a, b))
+                    cand_count.append(n_dec)
+                else:
+                    env.candidate_stability_mask()
+            env.sync = lambda: None
+        else:
+            env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, **kw)
+            lockstep = env.lockstep_random
 
-    for _ in range(args.warmup):
-        lockstep()
+        for _ in range(args.warmup):
+            lockstep()
 
-    def sync():
-        env.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def sync():
+            env.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    sync()
-    if cand_mode:
+        sync()
         cand_ev.clear()
         cand_count.clear()
-    s0 = env.read_stats()
-    if not args.no_kernel_timing:
-        env.timing_begin(args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lockstep()
-    sync()
-    dt = time.perf_counter() - t0
-    raster_ms, n_launch = (0.0, 0) if args.no_kernel_timing else env.timing_end()
-    s1 = env.read_stats()
-    d = {k: s1[k] - s0[k] for k in s1}
+        s0 = env.read_stats()
+        if not args.no_kernel_timing:
+            env.timing_begin(args.steps)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lockstep()
+        sync()
+        dt = time.perf_counter() - t0
+        raster_ms, n_launch = (0.0, 0) if args.no_kernel_timing else env.timing_end()
+        s1 = env.read_stats()
+        d = {k: s1[k] - s0[k] for k in s1}
+        env_steps = float(d["env_steps"])
+        if world > 1:
+            t = torch.tensor([dt, env_steps], dtype=torch.float64, device=red_dev)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone()
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            dt_all, steps_all = float(tmax[0]), float(tsum[1])
+        else:
+            dt_all, steps_all = dt, env_steps
+        return dict(seed=seed, env=env, dt=dt, d=d, env_steps=env_steps, dt_all=dt_all, steps_all=steps_all,
+                    raster_ms=raster_ms, n_launch=n_launch, cand_ev=cand_ev, cand_count=cand_count)
 
-    env_steps = float(d["env_steps"])
-    if world > 1:
-        t = torch.tensor([dt, env_steps], dtype=torch.float64, device=red_dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_all, steps_all = float(tmax[0]), float(tsum[1])
-    else:
-        dt_all, steps_all = dt, env_steps
+    # SURVEY.md section 8(d): seeds {0, 1, 2}; `value` is the MEDIAN run, every run's value is listed in config.per_seed
+    runs = []
+    for sd in seeds:
+        r = measure(sd)
+        runs.append(r)
+        if sd != seeds[-1]:
+            r["env"] = None                            # free the 20 GB of buffers before the next set is created
+            torch.cuda.empty_cache()
+    order = sorted(range(len(runs)), key=lambda i: runs[i]["steps_all"] / runs[i]["dt_all"])
+    med = runs[order[len(order) // 2]]
+    env = runs[-1]["env"]                              # (side figures of the candidate-stability mode read the last set)
+    dt, d, env_steps, dt_all, steps_all = med["dt"], med["d"], med["env_steps"], med["dt_all"], med["steps_all"]
+    raster_ms, n_launch, cand_ev, cand_count = med["raster_ms"], med["n_launch"], runs[-1]["cand_ev"], runs[-1]["cand_count"]
+
+    def release():
+        """Drop every environment set (18.8 GB of raster buffers each) before a side mode allocates its own."""
+        nonlocal env
+        for r in runs:
+            r["env"] = None
+        env = None
+        torch.cuda.empty_cache()
 
     if rank == 0:
         units = args.envs * args.steps                      # env slots processed by the timed rasteriser launches
@@ -393,7 +503,11 @@ def main():
             "config": {
                 "workload": "%d envs/GPU lock-step, %s, %s, max_steps=%d, uniform-random policy, %s"
                             % (args.envs, task_label, args.shapes, args.max_steps, raster_mode),
-                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups, "raster_split": args.raster_split,
+                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups,
+                "seeds": seeds, "seed_of_value": med["seed"],
+                "per_seed": [{"seed": r["seed"], "value": r["steps_all"] / r["dt_all"], "ms_per_step": r["dt_all"] / args.steps * 1e3}
+                             for r in runs],
+                "env_ids": "policy RNG keyed by (seed, global env id = rank * envs_per_gpu + e)",
                 "tower_height": args.tower_height,
                 "bridge_length": args.bridge_length, "shapes": args.shapes, "max_steps": args.max_steps,
                 "mean_raw_candidates": d["sum_cand"] / max(units, 1),
@@ -403,7 +517,6 @@ def main():
                 "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
                 "debug": args.debug, "tableau_snapshots": bool(cand_mode or args.snapshots),
-                "raster_stream": os.environ.get("BRIDGES_RASTER_STREAM") or None,       # experiment knob of VecAssemblyGymGroups
                 "dist_backend": backend if world > 1 else None,
             },
             "roofline": {
@@ -441,15 +554,26 @@ def main():
                                   "queued_large_tableaux": int(env.cand_counters[0])}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if world > 1:
+            release()
         plain = not (args.no_f32_rasters or args.sparse_raster_update or args.debug or cand_mode or args.bridge_length
                      or args.shapes != "trapezoid")
         if world == 1 and plain and not args.no_other_modes:
             try:
-                del env, lockstep
-                torch.cuda.empty_cache()
+                release()
                 out["other_modes"] = side_modes(args)
             except Exception as exc:                     # the headline line must survive whatever happens here
                 out["other_modes"] = {"error": repr(exc)[:200]}
+    if world > 1 and args.mode == "sim" and os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
+        # every rank takes part (collectives inside); only rank 0 holds `out`
+        try:
+            release()
+            leg = train_config4_leg(args, dev, rank, world, backend)
+        except Exception as exc:                         # the headline line must survive whatever happens here
+            leg = {"error": repr(exc)[:300]}
+        if rank == 0:
+            out.setdefault("other_modes", {})["train_config4"] = leg
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

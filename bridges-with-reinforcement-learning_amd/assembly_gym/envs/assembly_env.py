@@ -185,6 +185,7 @@ class AssemblyEnv:
 
     def reset(self):
         self.obstacles, self.blocks = [], []
+        self._stability_memo = {}
         self.is_block_frozen = False
         self.frozen_block_index = None
         self._update_state_info()
@@ -204,7 +205,17 @@ class AssemblyEnv:
             "collision_info": {"obstacles": [], "blocks": [], "floor": False, "bounding_box": False},
             "frozen_block": self.frozen_block_index,
         }
-        is_stable, info = self.stability_fct(self)
+        # the reference re-solves the same assembly several times per env-step (add_block, step's _update_state_info and
+        # the three calls of stabilities_freezing see only two or three distinct (blocks, frozen set) pairs); the
+        # solver is a pure function of those, so a verdict is computed once per distinct pair and looked up afterwards
+        key = (tuple(id(b) for b in self.blocks), tuple(bool(b.is_static) for b in self.blocks), float(self.mu),
+               float(self.density), id(self.stability_fct))
+        memo = self._stability_memo
+        if key not in memo:
+            if len(memo) > 64:
+                memo.clear()
+            memo[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique
+        (is_stable, info), _ = memo[key]
         self._state_info["stable"] = is_stable
         self._state_info["stability_info"] = info
 

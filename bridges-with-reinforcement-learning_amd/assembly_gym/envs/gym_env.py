@@ -85,6 +85,7 @@ class AssemblyGym:
         self.reward_fct, self.render_mode, self.restrict_2d, self.max_steps = reward_fct, render_mode, restrict_2d, max_steps
         self.observation_space = self.action_space = None       # gymnasium attributes, unused like in the reference
         self.action_history = self.block_graph = None
+        self._block_cache, self._block_cache_state = {}, None
         self.assembly_env = assembly_env if assembly_env is not None else AssemblyEnv(render=render_mode == 'human')
         self.reset(shapes, obstacles, targets)
 
@@ -147,12 +148,29 @@ class AssemblyGym:
         return {'blocks_initial_state': None, 'blocks_final_state': None}
 
     def create_block(self, action: Action):
-        target = None if action.target_block == -1 else self.assembly_env.blocks[action.target_block]
-        shape = self.shapes[action.shape]
-        pose, verts, frames = ops.create_block(target, action.target_face, shape.geometry, action.face,
-                                               action.offset_x, action.offset_y)
-        return Block(shape, position=[pose[0], 0.0, pose[1]], orientation=Quaternion.from_cos_sin(pose[2], pose[3]),
-                     _posed=(pose, verts, frames))
+        return self.create_blocks([action])[0]
+
+    def create_blocks(self, actions):
+        """create_block (gym_env.py:204-216 of the reference) for a list of actions in one batched operator call.  The
+        blocks of the current state's candidates are kept until the assembly changes: the reference creates every
+        candidate twice per env-step (get_action_features, successor_dqn.py:69, then collision_on_action through
+        filter_actions, actions.py:71-82) -- the second round is served from here."""
+        state = (len(self.assembly_env.blocks), id(self.assembly_env.blocks[-1]) if self.assembly_env.blocks else None)
+        if self._block_cache_state != state:
+            self._block_cache, self._block_cache_state = {}, state
+        keys = [(a.target_block, a.target_face, a.shape, a.face, float(a.offset_x), float(a.offset_y)) for a in actions]
+        todo = [i for i, k in enumerate(keys) if k not in self._block_cache]
+        if todo:
+            acts = [actions[i] for i in todo]
+            targets = [None if a.target_block == -1 else self.assembly_env.blocks[a.target_block] for a in acts]
+            shapes = [self.shapes[a.shape] for a in acts]
+            posed = ops.create_blocks(targets, [a.target_face for a in acts], [sh.geometry for sh in shapes],
+                                      [a.face for a in acts], [a.offset_x for a in acts], [a.offset_y for a in acts])
+            for i, sh, (pose, verts, frames) in zip(todo, shapes, posed):
+                self._block_cache[keys[i]] = Block(sh, position=[pose[0], 0.0, pose[1]],
+                                                   orientation=Quaternion.from_cos_sin(pose[2], pose[3]),
+                                                   _posed=(pose, verts, frames))
+        return [self._block_cache[k] for k in keys]
 
     def step(self, action: Action):
         new_block = self.create_block(action)

@@ -108,6 +108,7 @@ ENV_BUFFER_FIELDS = [
     ("state_raster_nz", "int32", "E"),
     ("obstacle_bits", "int64", "64"),
     ("reward_map", "float32", "64,64"),
+    ("reward_prefix", "float64", "64,65"),
     ("lp_ws", "float64", "E,WS"),
 ]
 
@@ -159,7 +160,6 @@ def lib():
         "bridges_gate_create": [C.POINTER(vp)],
         "bridges_gate_destroy": [vp],
         "bridges_env_set_gate": [vp, vp],
-        "bridges_env_set_raster_split": [vp, i32],
         "bridges_env_timing_begin": [vp, i32],
         "bridges_env_timing_end": [vp, C.POINTER(C.c_double), C.POINTER(i32)],
         "bridges_shapes_upload": [C.POINTER(Shape), i32, C.POINTER(vp)],
@@ -182,9 +182,6 @@ def lib():
         "bridges_bias_relu_pool2": [vp, vp, vp, i64, i32, i32, i32, vp],
         "bridges_conv3x3_relu_o16": [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
         "bridges_conv3x3_relu_o16_ex": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
-        "bridges_env_set_raster_stream": [vp, vp],
-        "bridges_stream_create_masked": [vp, i32, vp],
-        "bridges_stream_destroy": [vp],
         "bridges_upconv2x2": [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
         "bridges_linear_forward": [i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp],
         "bridges_linear_backward": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
@@ -204,11 +201,11 @@ EXPORTED_SYMBOLS = (
     "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_env_candidate_stability",
-    "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate", "bridges_env_set_raster_split",
+    "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
     "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
-    "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_env_set_raster_stream", "bridges_stream_create_masked", "bridges_stream_destroy", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_successor_loss",
+    "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_successor_loss",
 )
 
 

@@ -227,30 +227,43 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension
     return bool(stable.item()), out
 
 
+def create_blocks(target_blocks, target_faces, geoms, faces, oxs, oys):
+    """AssemblyGym.create_block for n candidate placements in ONE bridges_create_block + ONE bridges_face_frames launch
+    and three device-to-host copies (the per-candidate form costs a launch pair and three blocking copies each).
+    target_blocks[i] = None for the floor, else an object with ``verts_2d`` / ``geometry``.  Returns per placement
+    (pose[4], verts[nv,2], frames[nv,6]) float64 numpy -- the same values as n single calls (the kernels work per item)."""
+    L = abi.require_gpu()
+    dev = device()
+    n = len(geoms)
+    if n == 0:
+        return []
+    sid = np.array([REGISTRY.id_of(g) for g in geoms], dtype=np.int32)
+    tsid = np.array([REGISTRY.id_of(t.geometry) if t is not None else sid[i] for i, t in enumerate(target_blocks)], dtype=np.int32)
+    tab = REGISTRY.device_table()
+    tv = np.zeros((n, 6, 2))
+    tf = np.full(n, -1, dtype=np.int32)
+    for i, t in enumerate(target_blocks):
+        if t is not None:
+            tv[i, :len(t.verts_2d)] = t.verts_2d
+            tf[i] = int(target_faces[i])
+    t_ = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+    pose = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    verts = torch.empty((n, 6, 2), dtype=torch.float64, device=dev)
+    frames = torch.empty((n, 6, 6), dtype=torch.float64, device=dev)
+    sh, a_tv, a_ts, a_tf = t_(sid, torch.int32), t_(tv, torch.float64), t_(tsid, torch.int32), t_(tf, torch.int32)
+    a_face = t_(np.asarray(faces, dtype=np.int32), torch.int32)
+    a_ox, a_oy = t_(np.asarray(oxs, dtype=np.float64), torch.float64), t_(np.asarray(oys, dtype=np.float64), torch.float64)
+    abi.check(L.bridges_create_block(tab, n, _ptr(a_tv), _ptr(a_ts), _ptr(a_tf), _ptr(sh), _ptr(a_face), _ptr(a_ox),
+                                     _ptr(a_oy), _ptr(pose), _ptr(verts), None, _stream()), "bridges_create_block")
+    abi.check(L.bridges_face_frames(tab, n, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
+    pose_h, verts_h, frames_h = pose.cpu().numpy(), verts.cpu().numpy(), frames.cpu().numpy()
+    return [(pose_h[i], verts_h[i, :len(g.verts)], frames_h[i, :len(g.verts)]) for i, g in enumerate(geoms)]
+
+
 def create_block(target_block, target_face, geom, face, ox, oy):
     """AssemblyGym.create_block on the device.  target_block = None for the floor, else an object with
     ``verts_2d`` / ``geometry``.  Returns (pose[4], verts[nv,2], frames[nv,6]) float64 numpy."""
-    L = abi.require_gpu()
-    dev = device()
-    sid = REGISTRY.id_of(geom)
-    tsid = REGISTRY.id_of(target_block.geometry) if target_block is not None else sid
-    tab = REGISTRY.device_table()
-    tv = np.zeros((1, 6, 2))
-    if target_block is not None:
-        tv[0, :len(target_block.verts_2d)] = target_block.verts_2d
-    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
-    pose = torch.empty((1, 4), dtype=torch.float64, device=dev)
-    verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
-    frames = torch.empty((1, 6, 6), dtype=torch.float64, device=dev)
-    sh = t([sid], torch.int32)
-    a_tv, a_ts = t(tv, torch.float64), t([tsid], torch.int32)
-    a_tf = t([int(target_face) if target_block is not None else -1], torch.int32)
-    a_face, a_ox, a_oy = t([int(face)], torch.int32), t([float(ox)], torch.float64), t([float(oy)], torch.float64)
-    abi.check(L.bridges_create_block(tab, 1, _ptr(a_tv), _ptr(a_ts), _ptr(a_tf), _ptr(sh), _ptr(a_face), _ptr(a_ox),
-                                     _ptr(a_oy), _ptr(pose), _ptr(verts), None, _stream()), "bridges_create_block")
-    abi.check(L.bridges_face_frames(tab, 1, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
-    nv = len(geom.verts)
-    return pose[0].cpu().numpy(), verts[0, :nv].cpu().numpy(), frames[0, :nv].cpu().numpy()
+    return create_blocks([target_block], [target_face], [geom], [face], [ox], [oy])[0]
 
 
 def pose_block(geom, pose4):

@@ -198,6 +198,11 @@ class VecAssemblyGym:
         rm = torch.nn.functional.conv2d(timg[None, :, :S, :S].contiguous(), kernel.unsqueeze(0).unsqueeze(0), padding=50)
         self.buf["reward_map"].zero_()
         self.buf["reward_map"][:S, :S].copy_(rm[0, 0])
+        # float64 row prefix sums of the map, accumulated left to right on the host (one fixed order on every box): the
+        # rasteriser takes sum(raster * reward_map) of a candidate from the runs of its rows (bridges_env_buffers.reward_prefix)
+        pre = np.zeros((64, 65), dtype=np.float64)
+        pre[:, 1:] = np.cumsum(self.buf["reward_map"].cpu().numpy().astype(np.float64), axis=1)
+        self.buf["reward_prefix"].copy_(torch.from_numpy(pre))
         oimg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
         abi.check(self.L.bridges_bits_to_f32(1, _ptr(self.buf["obstacle_bits"]), _ptr(oimg), _stream()),
                   "bridges_bits_to_f32")
@@ -395,33 +400,16 @@ class VecAssemblyGymGroups:
     rasteriser of another.  Environments are independent, so results are identical to a single group with the same
     global env ids (policy RNG streams are keyed by seed and global env id)."""
 
-    def __init__(self, num_envs, *args, groups=2, device="cuda:0", raster_gate=None, raster_split=0, **kw):
+    def __init__(self, num_envs, *args, groups=2, device="cuda:0", raster_gate=None, env_id_base=0, **kw):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.G = int(groups)
         base = num_envs // self.G
         sizes = [base + (1 if g < num_envs % self.G else 0) for g in range(self.G)]
         self.E = int(num_envs)
-        self.envs, self.streams, start = [], [], 0
-        # BRIDGES_RASTER_STREAM (experiment, see DESIGN.md): "plain" = all rasterisers on one extra stream;
-        # "mask:<n latency CUs>:<all|rest>" = additionally the group streams only get the first n CUs (bit order of the CU
-        # mask) and the raster stream all CUs or the remaining ones
-        self._raster_mode = os.environ.get("BRIDGES_RASTER_STREAM", "")
-        self._own_streams = []
-        lat_mask = None
-        if self._raster_mode.startswith("mask:"):
-            n_lat = int(self._raster_mode.split(":")[1])
-            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            words = (n_cu + 31) // 32
-            bits = [(1 if i < n_lat else 0) for i in range(n_cu)]
-            lat_mask = [sum(bits[32 * w + b] << b for b in range(32) if 32 * w + b < n_cu) for w in range(words)]
-            self._rest_mask = [(~m) & 0xFFFFFFFF if 32 * (w + 1) <= n_cu else (~m) & ((1 << (n_cu - 32 * w)) - 1)
-                               for w, m in enumerate(lat_mask)]
+        self.envs, self.streams, start = [], [], int(env_id_base)
         for n in sizes:
-            if lat_mask is not None:
-                st = self._masked_stream(lat_mask)
-            else:
-                st = torch.cuda.Stream(device=self.device)
+            st = torch.cuda.Stream(device=self.device)
             with torch.cuda.stream(st):
                 self.envs.append(VecAssemblyGym(n, *args, device=device, env_id_base=start, **kw))
             self.streams.append(st)
@@ -435,29 +423,10 @@ class VecAssemblyGymGroups:
         if raster_gate is None:                     # the gate pays when the rasterisers are HBM-bound (full rewrite);
             # measured 3 groups, sparse row-group update: 6.89 M env-steps/s without it, 6.18 M with it
             raster_gate = os.environ.get("BRIDGES_RASTER_GATE", "0" if kw.get("sparse_raster_update") else "1") != "0"
-        if self.G > 1 and self._raster_mode:
-            raster_gate = False
-            use_rest = self._raster_mode.endswith(":rest")
-            self._raster_stream = self._masked_stream(self._rest_mask if use_rest else [])
-            for env in self.envs:
-                abi.check(L.bridges_env_set_raster_stream(env._env, C.c_void_p(self._raster_stream.cuda_stream)),
-                          "bridges_env_set_raster_stream")
-            self.streams.append(self._raster_stream)            # sync() waits for it too
         if self.G > 1 and raster_gate:
             for env in self.envs:
                 abi.check(L.bridges_env_set_gate(env._env, self._gate), "bridges_env_set_gate")
-                # release the next group's rasteriser behind the first raster_split / 1000 of this one's images
-                abi.check(L.bridges_env_set_raster_split(env._env, int(raster_split)), "bridges_env_set_raster_split")
         self.sync()
-
-    def _masked_stream(self, mask_words):
-        """A HIP stream limited to the CUs in mask_words ([] = all), wrapped for torch."""
-        L = abi.require_gpu()
-        ptr = C.c_void_p()
-        arr = (C.c_uint32 * max(len(mask_words), 1))(*mask_words)
-        abi.check(L.bridges_stream_create_masked(arr, len(mask_words), C.byref(ptr)), "bridges_stream_create_masked")
-        self._own_streams.append(ptr)
-        return torch.cuda.ExternalStream(ptr.value, device=self.device)
 
     def sync(self):
         for st in self.streams:
@@ -468,12 +437,7 @@ class VecAssemblyGymGroups:
             self.sync()
             for env in self.envs:
                 env.L.bridges_env_set_gate(env._env, None)
-            for env in self.envs:
-                env.L.bridges_env_set_raster_stream(env._env, None)
             self.envs[0].L.bridges_gate_destroy(self._gate)
-            for ptr in getattr(self, "_own_streams", []):
-                self.envs[0].L.bridges_stream_destroy(ptr)
-            self._own_streams = []
         except Exception:
             pass
 

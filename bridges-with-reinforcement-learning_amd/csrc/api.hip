@@ -45,9 +45,7 @@ struct bridges_env {
     TaskTable* tt_dev;
     int32_t* h_total;          // pinned: candidate count of the previous lock-step (sizes the raster / expand grids)
     int max_blocks;            // upper bound of a useful grid
-    int split_permille;        // > 0: rasteriser launched as head (this share of the expected items) + tail
-    hipStream_t raster_stream; // != nullptr: the rasteriser runs on this stream (event-ordered with the caller's stream)
-    hipEvent_t pre_done;       // the kernels in front of the rasteriser are done (recorded on the caller's stream)
+    int max_faces;             // most 2-D faces among the task's candidate shapes (picks the rasteriser instantiation)
     // optional per-launch timing of the dominant kernel (k_raster) with HIP events on the launch stream
     hipEvent_t* ev_start;
     hipEvent_t* ev_stop;
@@ -74,6 +72,10 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (t->n_targets < 0 || t->n_targets > BRIDGES_MAX_TARGETS) return fail_arg("n_targets");
     if (t->a_max <= 0) return fail_arg("a_max");
     if (t->img_size != 0 && (t->img_size < 2 || t->img_size > BRIDGES_IMG)) return fail_arg("img_size must be 0 (= 64) or 2..64");
+#ifndef BRIDGES_DIAG
+    if (t->debug != 0) return fail_arg("debug switches exist only in a diagnostic build (-DBRIDGES_DIAG, tools/build_diag.sh)");
+#endif
+    if (!buf->reward_prefix) return fail_arg("reward_prefix (float64 row prefix sums of reward_map) not given");
     if (buf->lp_ws_stride < (int64_t)BRIDGES_LP_WS_DOUBLES) return fail_arg("lp_ws_stride < BRIDGES_LP_WS_DOUBLES");
     static_assert(BRIDGES_LP_WS_DOUBLES == WARM_WS_DOUBLES, "header and device code disagree on the persistent tableau size");
     static_assert(BRIDGES_LP_SNAP_DOUBLES == WARM_HDR_DOUBLES + WARM_HALF, "header and device code disagree on the snapshot size");
@@ -129,8 +131,6 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     env->ev_cap = env->ev_used = 0;
     env->gate = nullptr;
     env->raster_done = nullptr;
-    env->raster_stream = nullptr;
-    env->pre_done = nullptr;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     (void)cus;
@@ -138,7 +138,11 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     if (e != hipSuccess) { (void)hipFree(env->tt_dev); delete env; return fail_hip(e, "hipHostMalloc"); }
     *env->h_total = t->n_envs * 64;        // first guess; replaced after every scan
     env->max_blocks = 1 << 22;
-    env->split_permille = 0;
+    env->max_faces = 0;
+    for (int g = 0; g < t->n_groups; ++g) {
+        const int nv = t->shapes[t->group_shape[g]].nv;
+        if (nv > env->max_faces) env->max_faces = nv;
+    }
     *out = env;
     return BRIDGES_OK;
 }
@@ -158,7 +162,6 @@ int bridges_env_destroy(bridges_env* env) {
     if (!env) return BRIDGES_OK;
     free_events(env);
     if (env->raster_done) (void)hipEventDestroy(env->raster_done);
-    if (env->pre_done) (void)hipEventDestroy(env->pre_done);
     (void)hipFree(env->tt_dev);
     (void)hipHostFree(env->h_total);
     delete env;
@@ -183,34 +186,6 @@ int bridges_env_set_gate(bridges_env* env, bridges_gate* gate) {
     if (!env) return fail_arg("set_gate");
     if (gate && !env->raster_done) HIP_TRY(hipEventCreateWithFlags(&env->raster_done, hipEventDisableTiming));
     env->gate = gate;
-    return BRIDGES_OK;
-}
-
-int bridges_env_set_raster_stream(bridges_env* env, void* raster_stream) {
-    if (!env) return fail_arg("set_raster_stream");
-    if (raster_stream && !env->raster_done) HIP_TRY(hipEventCreateWithFlags(&env->raster_done, hipEventDisableTiming));
-    if (raster_stream && !env->pre_done) HIP_TRY(hipEventCreateWithFlags(&env->pre_done, hipEventDisableTiming));
-    env->raster_stream = (hipStream_t)raster_stream;
-    return BRIDGES_OK;
-}
-
-int bridges_stream_create_masked(const uint32_t* cu_mask, int32_t n_words, void** out_stream) {
-    if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) return fail_arg("bridges_stream_create_masked");
-    hipStream_t st = nullptr;
-    if (n_words == 0) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    else HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
-    *out_stream = (void*)st;
-    return BRIDGES_OK;
-}
-
-int bridges_stream_destroy(void* stream) {
-    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
-    return BRIDGES_OK;
-}
-
-int bridges_env_set_raster_split(bridges_env* env, int32_t head_permille) {
-    if (!env || head_permille < 0 || head_permille >= 1000) return fail_arg("set_raster_split");
-    env->split_permille = head_permille;
     return BRIDGES_OK;
 }
 
@@ -265,46 +240,15 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     long long rblocks = (items_est + 3) / 4;
     if (rblocks > env->max_blocks) rblocks = env->max_blocks;
     const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
-    if (env->raster_stream) {
-        // the rasterisers of all groups share ONE stream (they run back to back without a cross-queue hand-over between
-        // them); this group's stream only hands its candidate list over and takes the masks back
-        hipStream_t rs = env->raster_stream;
-        HIP_TRY(hipEventRecord(env->pre_done, s));
-        HIP_TRY(hipStreamWaitEvent(rs, env->pre_done, 0));
-        if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], rs));
-        hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, rs, c, 0, 0x7fffffff);
-        LAUNCH_CHECK("k_raster");
-        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], rs)); env->ev_used++; }
-        HIP_TRY(hipEventRecord(env->raster_done, rs));
-        HIP_TRY(hipStreamWaitEvent(s, env->raster_done, 0));
-        hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
-        LAUNCH_CHECK("k_select");
-        return BRIDGES_OK;
-    }
     if (env->gate && env->gate->last) HIP_TRY(hipStreamWaitEvent(s, env->gate->last, 0));
     if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
-    if (env->gate && env->split_permille > 0 && env->split_permille < 1000) {
-        // head: the first share of the expected items; the gate is released behind it, so the next group's rasteriser
-        // ramps up (and the ~25 us cross-queue hand-over passes) while the tail of this one drains
-        const long long head_items = items_est * env->split_permille / 1000 / 4 * 4;
-        const long long hblocks = head_items / 4 > 0 ? head_items / 4 : 1;
-        hipLaunchKernelGGL(k_raster, dim3((unsigned)hblocks), dim3(256), 0, s, c, 0, (int)head_items);
-        LAUNCH_CHECK("k_raster (head)");
+    if (env->max_faces <= 4) hipLaunchKernelGGL(k_raster<4>, dim3((unsigned)rblocks), dim3(256), 0, s, c);
+    else hipLaunchKernelGGL(k_raster<MAXV>, dim3((unsigned)rblocks), dim3(256), 0, s, c);
+    LAUNCH_CHECK("k_raster");
+    if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
+    if (env->gate) {
         HIP_TRY(hipEventRecord(env->raster_done, s));
         env->gate->last = env->raster_done;
-        long long tblocks = rblocks - hblocks;
-        if (tblocks < 64) tblocks = 64;                // the tail grid-strides over whatever the estimate missed
-        hipLaunchKernelGGL(k_raster, dim3((unsigned)tblocks), dim3(256), 0, s, c, (int)head_items, 0x7fffffff);
-        LAUNCH_CHECK("k_raster (tail)");
-        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
-    } else {
-        hipLaunchKernelGGL(k_raster, dim3((unsigned)rblocks), dim3(256), 0, s, c, 0, 0x7fffffff);
-        LAUNCH_CHECK("k_raster");
-        if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
-        if (env->gate) {
-            HIP_TRY(hipEventRecord(env->raster_done, s));
-            env->gate->last = env->raster_done;
-        }
     }
     hipLaunchKernelGGL(k_select, dim3(c.E), dim3(WAVE), 0, s, c, 0);
     LAUNCH_CHECK("k_select");

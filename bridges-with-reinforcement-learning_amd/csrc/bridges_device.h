@@ -17,6 +17,14 @@
 #define MAXIF BRIDGES_MAX_INTERFACES
 #define IMG BRIDGES_IMG
 
+// Diagnostic switches (bridges_task.debug) exist only in builds made with -DBRIDGES_DIAG (tools/build_diag.sh); the
+// product library compiles every such branch away and bridges_env_create refuses a non-zero debug word.
+#ifdef BRIDGES_DIAG
+#define DIAG(c, bit) (((c).debug & (bit)) != 0)
+#else
+#define DIAG(c, bit) false
+#endif
+
 namespace bridges {
 
 struct Frame2 {            // face frame: centre, tangent (x-axis), outward normal
@@ -56,19 +64,6 @@ __device__ __forceinline__ void align_place(const Frame2& f1, double c2x, double
     rot2(c2x, c2z, c, s, r2x, r2z);
     px = ((f1.cx + ox * f1.tx) + oy * f1.nx) - r2x;
     pz = ((f1.cz + ox * f1.tz) + oy * f1.nz) - r2z;
-}
-
-// Conservative image-row window of a block spanning z in [zmin, zmax]: one extra pixel row either side; outside it
-// every pixel fails some half-plane test by a margin of ~0.08 world units >> 1 ulp, so skipping the rows cannot
-// change a bit of the raster.  grid_y = np.linspace(ylim1, ylim0, 64) (row 0 = top).
-// n_rows = image height S <= 64 (gy_last = grid_y[S - 1]); images smaller than 64x64 live in the top-left S x S
-// corner of the 64x64 canvas.
-__device__ __forceinline__ void row_window2(double gy_first, double gy_last, int n_rows, double zmin, double zmax, int& r_lo, int& r_hi) {
-    const double ytop = gy_first, dy = (gy_first - gy_last) / (double)(n_rows - 1);
-    r_lo = (int)floor((ytop - zmax) / dy) - 1;
-    r_hi = (int)ceil((ytop - zmin) / dy) + 1;
-    r_lo = r_lo < 0 ? 0 : r_lo;
-    r_hi = r_hi > n_rows - 1 ? n_rows - 1 : r_hi;
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -149,7 +144,8 @@ struct DevCtx {
     bridges_env_buffers b;
     const TaskTable* tt;
     int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
-    int32_t debug, env_id_base;     // debug bit0: skip the LPs (timing experiments only)
+    int32_t debug, env_id_base;     // debug: BRIDGES_DIAG builds only (bit0 skip the LPs, bit1 / bit2 skip the half-plane runs / the f32
+                                    // stores of the rasteriser, bit3 per-env phase stamps, bit4 empty candidate-stability grid)
     int32_t n_shapes, img;            // img: image width = height S <= 64 (64 = the reference's default)
     int32_t group_shape[BRIDGES_MAX_GROUPS];
     int32_t group_face[BRIDGES_MAX_GROUPS];

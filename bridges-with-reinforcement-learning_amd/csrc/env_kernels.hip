@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
     uint8_t* flags = c.b.step_flags + (size_t)e * 8;
-    const long long ts0 = (c.debug & 8) ? wall_clock64() : 0;      // debug bit3: per-env phase stamps (tools/kstep_phases.py)
+    const long long ts0 = DIAG(c, 8) ? wall_clock64() : 0;      // debug bit3: per-env phase stamps (tools/kstep_phases.py)
     int32_t* shape_id_g = c.b.blk_shape + (size_t)e * K;
     double* pose_g = c.b.blk_pose + (size_t)e * K * 4;
     double* verts_g = c.b.blk_verts + (size_t)e * K * MAXV * 2;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
         }
     }
     const int n_reached = c.n_targets - __popc(left);
-    const long long ts1 = (c.debug & 8) ? wall_clock64() : 0;
+    const long long ts1 = DIAG(c, 8) ? wall_clock64() : 0;
 
     // ---- contact interfaces of the new block (assembly_env.py:281-304): its faces against the floor and every
     //      older block's faces, frames computed on the fly from the LDS vertices (same pair order and arithmetic as
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     // ---- stability with the last block frozen / nothing frozen (gym_env.py:238-245, 325-333) ----
     bool err = false;
     bool st_frozen = true, st_free = true;
-    const long long ts2 = (c.debug & 8) ? wall_clock64() : 0;
+    const long long ts2 = DIAG(c, 8) ? wall_clock64() : 0;
     bool warm_used = false;
     int lp_diag = 0;
-    if (!(c.debug & 1)) {
+    if (!DIAG(c, 1)) {
         AsmView A;                                  // centroids / volumes / contacts from LDS; the block arrays are gone
         A.pose = nullptr; A.shape_id = nullptr; A.shapes = nullptr; A.n_blocks = nb + 1;
         A.cand_b = -1; A.cand_pose = nullptr; A.cand_shape = 0; A.cen = Lk.cen; A.vol = Lk.vol; A.n_tens = 0; A.tens_coef = 1.0;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
                  &warm_used, &lp_diag, c.b.lp_snap ? c.b.lp_snap + (size_t)e * c.b.lp_snap_stride : nullptr);
     }
 
-    const long long ts3 = (c.debug & 8) ? wall_clock64() : 0;
+    const long long ts3 = DIAG(c, 8) ? wall_clock64() : 0;
     // ---- reward / termination (gym_env.py:11-22, 141-145) ----
     const bool all_reached = left == 0;
     const bool terminated = !st_frozen || all_reached;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     int nc = c.n_groups * (c.n_ground + nfree * c.n_offsets);
     nc = nc > c.a_max ? c.a_max : nc;
     if (lane == 0) c.b.n_cand[e] = nc;
-    if ((c.debug & 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
+    if (DIAG(c, 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
         const long long ts4 = wall_clock64();
         double* st = ws + c.b.lp_ws_stride - 8;     // the last 8 doubles of the env's workspace are never used otherwise
         st[0] = (double)ts0; st[1] = (double)(ts1 - ts0); st[2] = (double)(ts2 - ts1); st[3] = (double)(ts3 - ts2);
@@ -415,14 +415,13 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
     __shared__ bridges_shape sh_l[8];
     __shared__ double verts_l[MAXK * MAXV * 2];
     __shared__ int32_t shape_l[MAXK], occ_l[MAXK];
-    __shared__ double xg_l[32], offs_l[8], gy_l[2];
+    __shared__ double xg_l[32], offs_l[8];
     __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int K = c.K;
     // everything the env id addresses is requested at once and staged in LDS (see k_step)
     if (lane < 32) xg_l[lane] = c.tt->x_ground[lane];
     if (lane < 8) offs_l[lane] = c.tt->offsets[lane];
-    if (lane < 2) gy_l[lane] = c.tt->grid_y[lane * (c.img - 1)];
     const int nb = c.b.n_blocks[e];
     const int ncand = c.b.n_cand[e];
     const size_t off = (size_t)c.b.cand_offset[e];
@@ -483,7 +482,6 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
         bool inb = true;
         const double eps = 1e-6;
         double wx[MAXV], wz[MAXV];
-        double zmin = 1e300, zmax = -1e300;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             wx[i] = 0.0; wz[i] = 0.0;
@@ -493,12 +491,11 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
                 wx[i] = px + rx; wz[i] = pz + rz;
                 if (wx[i] < c.xlim0 - eps || wx[i] > c.xlim1 + eps || wz[i] < c.ylim0 - eps || wz[i] > c.ylim1 + eps) inb = false;
                 if (wz[i] < -eps) inb = false;
-                zmin = fmin(zmin, wz[i]); zmax = fmax(zmax, wz[i]);
             }
             c.b.cand_verts[ci * MAXV * 2 + 2 * i] = wx[i];
             c.b.cand_verts[ci * MAXV * 2 + 2 * i + 1] = wz[i];
         }
-        // world face frames (oracle: Block.frames) and the conservative row window of the rasteriser
+        // world face frames (oracle: Block.frames) for the rasteriser
         {
 #define PICK6(v, k) ((k) == 5 ? v[5] : (k) == 4 ? v[4] : (k) == 3 ? v[3] : (k) == 2 ? v[2] : (k) == 1 ? v[1] : v[0])
 #pragma unroll
@@ -515,9 +512,7 @@ __global__ __launch_bounds__(WAVE) void k_enumerate(DevCtx c) {
                 dst[1] = make_double2(o2, o3);
             }
 #undef PICK6
-            int r_lo, r_hi;
-            row_window2(gy_l[0], gy_l[1], c.img, zmin, zmax, r_lo, r_hi);
-            c.b.cand_rows[ci * 2 + 0] = r_lo | (r_hi << 8) | (sn.nv << 16) | ((inb ? 1 : 0) << 24);   // packed for the rasteriser
+            c.b.cand_rows[ci * 2 + 0] = (sn.nv << 16) | ((inb ? 1 : 0) << 24);   // packed for the rasteriser (bits 0-15: unused)
             c.b.cand_rows[ci * 2 + 1] = e;
         }
         c.b.cand_pose[ci * 4 + 0] = px; c.b.cand_pose[ci * 4 + 1] = pz;
@@ -578,138 +573,132 @@ __device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, in
     }
 }
 
-// Rasterise one convex outline from its world face frames.  Lane = pixel column; returns the row masks with row r
-// in lane r.  `frames` = [nv][4] (centre.xz, normal.xz), gyv = this lane's grid_y value (lane r holds Y[r]).
-// If s_w != nullptr (LDS copy of the reward map) also accumulates sum(inside * reward_map) into *lin (per lane).
-__device__ __forceinline__ uint64_t raster_frames(const double* frames, int nv, int r_lo, int r_hi, int n_cols, double X, double gyv,
-                                                  const float* s_w, double* lin, int lane) {
-    double fr0 = 0.0, fr1 = 0.0, fr2 = 0.0, fr3 = 0.0;
-    if (lane < nv) {
-        const double2* p = reinterpret_cast<const double2*>(frames + (size_t)lane * 4);
-        double2 a = p[0], b = p[1];
-        fr0 = a.x; fr1 = a.y; fr2 = b.x; fr3 = b.y;
-    }
-    double txf[MAXV], czf[MAXV], nzf[MAXV];
+// Rasterise one convex outline from its world face frames (centre.xz, outward normal.xz per face) WITHOUT visiting
+// pixels.  The reference's pixel test (assembly_env.py:126-137 through oracle/raster.py) is, per face,
+//     d = ((X[x] - c.x) * n.x) + ((Y[r] - c.z) * n.z) <= 0
+// with separately rounded binary64 operations.  With a[x] = fl(fl(X[x] - c.x) * n.x) and b[r] = fl(fl(Y[r] - c.z) * n.z)
+// the rounded sum fl(a + b) is <= 0 exactly when the exact sum is (rounding is monotone and never turns a non-zero
+// sum of two doubles into zero), i.e. when  a[x] <= -b[r]  -- one comparison, no addition.  X = np.linspace is strictly
+// increasing, rounding is monotone, so a[x] is monotone in x (non-decreasing for n.x > 0, non-increasing for n.x < 0,
+// constant +-0 for n.x = 0): the pixels of row r that pass face f form a prefix or a suffix of the row, whose length is
+// found by a 7-probe binary search over a[.] with exactly the reference's comparison.  The row of the raster is the
+// intersection of those runs.  Lane x holds a[x] (column role) and lane r holds -b[r] (row role); every lane searches
+// for its own row, so all 64 rows of the image come out at once (row r in lane r) with ~50 wave instructions per face,
+// independent of the block's size, instead of ~30 per face-row pair in a loop over the rows.  Bit for bit the same
+// raster as the per-pixel test (tests/test_gpu_env_parity.py against oracle/raster.py).
+// fr0..fr3: lane f < NF holds centre.x, centre.z, normal.x, normal.z of face f (all-zero frames pass every pixel).
+// X / Y: this lane's column / row coordinate (lanes >= n_img repeat the last grid value); n_img = S <= 64.
+__device__ __forceinline__ uint64_t low_mask64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+template <int NF>
+__device__ __forceinline__ uint64_t raster_rows(double fr0, double fr1, double fr2, double fr3, int n_img, double X, double Y,
+                                                int lane) {
+    int alo[NF], ahi[NF], pos[NF];
+    double t[NF];
+    bool rev[NF];
 #pragma unroll
-    for (int f = 0; f < MAXV; ++f) {
-        const double cxf = readlane_d(fr0, f), nxf = readlane_d(fr2, f);
-        czf[f] = readlane_d(fr1, f);
-        nzf[f] = readlane_d(fr3, f);
-        txf[f] = (X - cxf) * nxf;
+    for (int f = 0; f < NF; ++f) {
+        const double cxf = readlane_d(fr0, f), czf = readlane_d(fr1, f), nxf = readlane_d(fr2, f), nzf = readlane_d(fr3, f);
+        const double a = (X - cxf) * nxf;               // column role
+        t[f] = -((Y - czf) * nzf);                      // row role: pixel (r, x) passes face f iff a[x] <= t[r]
+        alo[f] = __double2loint(a);
+        ahi[f] = __double2hiint(a);
+        rev[f] = nxf < 0.0;                             // wave-uniform: a[.] non-increasing, the run is a suffix
+        pos[f] = 0;
     }
-    uint64_t mybits = 0ull;
-    const bool col_ok = lane < n_cols;         // images narrower than the 64-lane canvas: columns >= S stay empty
-    for (int r = r_lo; r <= r_hi; ++r) {
-        const double Y = readlane_d(gyv, r);
-        bool in = col_ok;
-#pragma unroll
-        for (int f = 0; f < MAXV; ++f) {
-            if (f < nv) {
-                double d = txf[f] + (Y - czf[f]) * nzf[f];
-                in = in && (d <= 0.0);
-            }
-        }
-        const uint64_t m = __ballot(in);
-        if (lane == r) mybits = m;
+    // probes at pos + s - 1 for s = 32 .. 1 (pos = the largest count <= 63 the run supports), then at pos itself (64)
+#define RASTER_PROBE(S_, INC_)                                                                                          \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                    \
+        const int j = pos[f] + (S_);                                                                                    \
+        const int src = rev[f] ? 63 - j : j;                                                                            \
+        const double av = __hiloint2double(__shfl(ahi[f], src, WAVE), __shfl(alo[f], src, WAVE));                       \
+        if (av <= t[f]) pos[f] += (INC_);                                                                               \
     }
-    if (lin) {
-        // linear reward: sum of reward_map over the inside pixels; the row loads are independent of the masks, so
-        // they are issued four at a time ahead of the bit tests (L2-resident 16 KiB map)
-        double acc = 0.0;
-        for (int r0 = r_lo; r0 <= r_hi; r0 += 4) {
-            float wv[4];
+    RASTER_PROBE(31, 32) RASTER_PROBE(15, 16) RASTER_PROBE(7, 8) RASTER_PROBE(3, 4) RASTER_PROBE(1, 2) RASTER_PROBE(0, 1)
+    RASTER_PROBE(0, 1)
+#undef RASTER_PROBE
+    uint64_t bits = low_mask64(n_img);                  // images narrower than the canvas: columns >= S stay empty
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wv[u] = (r0 + u <= r_hi) ? s_w[(r0 + u) * IMG + lane] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (r0 + u <= r_hi) {
-                    const uint64_t m = shfl_u64(mybits, r0 + u);
-                    if ((m >> lane) & 1ull) acc += (double)wv[u];
-                }
-            }
-        }
-        *lin = acc;
+    for (int f = 0; f < NF; ++f) {
+        const uint64_t run = low_mask64(pos[f]);
+        bits &= rev[f] ? (pos[f] ? ~low_mask64(64 - pos[f]) : 0ull) : run;
     }
-    return mybits;
+    return lane < n_img ? bits : 0ull;                  // rows >= S stay empty
+}
+
+__device__ __forceinline__ uint64_t raster_rows_nv(double fr0, double fr1, double fr2, double fr3, int nv, int n_img, double X,
+                                                   double Y, int lane) {
+    return nv <= 4 ? raster_rows<4>(fr0, fr1, fr2, fr3, n_img, X, Y, lane) : raster_rows<MAXV>(fr0, fr1, fr2, fr3, n_img, X, Y, lane);
+}
+
+// sum(raster * reward_map) from the row runs: the pixels of a row of a convex outline are one run [lo, hi), so the
+// row's sum is prefix[r][hi] - prefix[r][lo] on the float64 row prefix sums of the reward map (reward_prefix, [64][65]).
+__device__ __forceinline__ double raster_reward(uint64_t rowbits, const double* prefix, int lane) {
+    double v = 0.0;
+    if (rowbits) {
+        const int lo = __builtin_ctzll(rowbits), hi = 64 - __builtin_clzll(rowbits);
+        const double* p = prefix + lane * (IMG + 1);
+        v = p[hi] - p[lo];
+    }
+    return wave_sum_d(v);
 }
 
 // Same from world vertices (stand-alone operator): frames are derived first (oracle/raster.py contains_2d).
 __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, int nv, const int32_t* fa,
                                                    const int32_t* fb, const double* gx, const double* gy, int size, int lane) {
-    double cx = 0.0, cz = 0.0, nx = 0.0, nz = 0.0, myz = 0.0;
+    double cx = 0.0, cz = 0.0, nx = 0.0, nz = 0.0;
     if (lane < nv) {
         Frame2 fr = edge_frame(v[2 * fa[lane]], v[2 * fa[lane] + 1], v[2 * fb[lane]], v[2 * fb[lane] + 1]);
         cx = fr.cx; cz = fr.cz; nx = fr.nx; nz = fr.nz;
-        myz = v[2 * lane + 1];
     }
-    const double zmin = wave_min_d(lane < nv ? myz : 1e300);
-    const double zmax = wave_max_d(lane < nv ? myz : -1e300);
-    int r_lo, r_hi;
-    row_window2(gy[0], gy[size - 1], size, zmin, zmax, r_lo, r_hi);
-    const bool col_ok = lane < size;
-    const double X = gx[col_ok ? lane : 0];
-    double txf[MAXV], czf[MAXV], nzf[MAXV];
-#pragma unroll
-    for (int f = 0; f < MAXV; ++f) {
-        double cxf = readlane_d(cx, f), nxf = readlane_d(nx, f);
-        czf[f] = readlane_d(cz, f);
-        nzf[f] = readlane_d(nz, f);
-        txf[f] = (X - cxf) * nxf;
-    }
-    uint64_t mybits = 0ull;
-    for (int r = r_lo; r <= r_hi; ++r) {
-        const double Y = gy[r];
-        bool in = col_ok;
-#pragma unroll
-        for (int f = 0; f < MAXV; ++f) {
-            if (f < nv) {
-                double d = txf[f] + (Y - czf[f]) * nzf[f];
-                in = in && (d <= 0.0);
-            }
-        }
-        uint64_t m = __ballot(in);
-        if (lane == r) mybits = m;
-    }
-    return mybits;
+    const int g = lane < size ? lane : size - 1;        // lanes beyond the image repeat the last grid value (a[.] stays monotone)
+    return raster_rows_nv(cx, cz, nx, nz, nv, size, gx[g], gy[g], lane);
 }
 
 // Rasteriser: work item i < total -> candidate i (compact index), else the state raster of env i - total.  One
 // wave per image.  The grid is sized by the host from the previous lock-step's candidate count (kept in pinned
 // memory) so that a wave sees about one item -- short-lived waves dispatched in item order keep the HBM write
 // stream close to linear, which sustains ~14 % more bandwidth than a persistent grid (tools/store_bench.hip) -- and
-// the grid-stride loop makes any count correct.  The half-plane tests hide behind the 16 KiB of stores per image.
-// item_begin / item_end: the launch covers the work items [item_begin, min(item_end, items)) -- the host splits one
-// lock-step's rasterisation into a head and a tail launch so that the next env group's rasteriser can be released
-// when the head is done (api.hip: refresh).
-__global__ __launch_bounds__(256) void k_raster(DevCtx c, int item_begin, int item_end) {
+// the grid-stride loop makes any count correct.  The row runs (raster_rows) cost ~250 wave instructions per image and
+// hide behind its 16 KiB of stores.
+// NF = 4 when every candidate shape of the task has at most 4 faces (64 VGPRs: 8 waves per SIMD), else MAXV.
+template <int NF>
+__global__ __launch_bounds__(256) void k_raster(DevCtx c) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const int nwaves = (gridDim.x * blockDim.x) / WAVE;
     const int total = c.b.cand_offset[c.E];
-    const int items_all = total + (c.b.state_raster ? c.E : 0);
-    const int items = items_all < item_end ? items_all : item_end;
-    for (int itv = item_begin + wave; itv < items; itv += nwaves) {
+    const int items = total + (c.b.state_raster ? c.E : 0);
+    const double X = c.tt->grid_x[lane], Y = c.tt->grid_y[lane];
+    const uint64_t obst = c.b.obstacle_bits[lane];
+    for (int itv = wave; itv < items; itv += nwaves) {
         const int it = __builtin_amdgcn_readfirstlane(itv);       // wave-uniform: metadata comes through scalar loads
         if (it < total) {
             const size_t ci = (size_t)it;
             const int meta = c.b.cand_rows[ci * 2];
             const int e = c.b.cand_rows[ci * 2 + 1];
-            const int r_lo = meta & 0xff, r_hi = (meta >> 8) & 0xff, nv = (meta >> 16) & 0xff;
+            const int nv = (meta >> 16) & 0xff;
             const bool inb = (meta >> 24) & 1;
-            double linp = 0.0;
+            (void)nv;
+            // everything the descriptor addresses is requested before any of it is used
+            double fr0 = 0.0, fr1 = 0.0, fr2 = 0.0, fr3 = 0.0;
+            if (lane < MAXV) {
+                const double2* p = reinterpret_cast<const double2*>(c.b.cand_frames + (ci * MAXV + lane) * 4);
+                const double2 a = p[0], b = p[1];
+                fr0 = a.x; fr1 = a.y; fr2 = b.x; fr3 = b.y;
+            }
+            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | obst;
             uint64_t bits = 0ull;
-            if (!(c.debug & 2))
-                bits = raster_frames(c.b.cand_frames + ci * MAXV * 4, nv, r_lo, r_hi, c.img, c.tt->grid_x[lane], c.tt->grid_y[lane],
-                                     c.b.reward_map, &linp, lane);
-            const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | c.b.obstacle_bits[lane];
+            if (!DIAG(c, 2)) bits = (NF == 4 || nv <= 4) ? raster_rows<4>(fr0, fr1, fr2, fr3, c.img, X, Y, lane)
+                                                         : raster_rows<MAXV>(fr0, fr1, fr2, fr3, c.img, X, Y, lane);
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
-            const double lin = wave_sum_d(linp);
+            const double lin = raster_reward(bits, c.b.reward_prefix, lane);
             c.b.cand_bits[ci * IMG + lane] = bits;
             if (lane == 0) {
                 c.b.cand_lin[ci] = (float)lin;
                 c.b.cand_mask[ci] = (uint8_t)(inb && !overlap);
             }
-            if (c.b.cand_raster && !(c.debug & 4))
+            if (c.b.cand_raster && !DIAG(c, 4))
                 write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane, c.b.cand_raster_nz ? c.b.cand_raster_nz + ci : nullptr);
         } else {
             const int e = it - total;
@@ -802,7 +791,7 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
         } else {
             if (item >= total) return;
             ci = item;
-            if (!c.b.cand_mask[ci] || (c.debug & 16)) {        // debug bit4: every wave leaves here (cost of the empty grid)
+            if (!c.b.cand_mask[ci] || DIAG(c, 16)) {        // debug bit4: every wave leaves here (cost of the empty grid)
                 if (lane == 0) c.b.cand_stable[ci] = 0;
                 continue;
             }

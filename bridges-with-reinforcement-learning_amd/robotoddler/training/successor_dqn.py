@@ -66,7 +66,8 @@ def get_task_features(obs, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=N
 
 
 def get_action_features(env, actions, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
-    blocks = [env.create_block(action) for action in actions]
+    # one batched bridges_create_block call for all candidates when the gym offers it (the reference: one call each)
+    blocks = env.create_blocks(actions) if hasattr(env, "create_blocks") else [env.create_block(action) for action in actions]
     return _image(ops.raster_bits(blocks, xlim, ylim, img_size), img_size).unsqueeze(1).to(device)   # [A,1,S,S]
 
 

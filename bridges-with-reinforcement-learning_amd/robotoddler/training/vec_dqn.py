@@ -514,7 +514,7 @@ def lockstep_log_values(info):
                 steps_per_s=info['steps_per_s'])
 
 
-def run_vectorised(args, device, aim_run=None, wandb_run=None):
+def run_vectorised(args, device, aim_run=None, wandb_run=None, return_agent=False):
     from robotoddler.training.successor_dqn import make_nets, track_run_sinks
     backend = os.environ.get("BRIDGES_DIST_BACKEND")          # 'gloo' = rehearsal with several ranks on one card
     rank, world = D.init(backend=backend, device=device)
@@ -600,4 +600,4 @@ def run_vectorised(args, device, aim_run=None, wandb_run=None):
         pending = (info, losses, stats_host, done)
     if pending is not None:
         finish(pending)
-    return history
+    return (history, agent) if return_agent else history

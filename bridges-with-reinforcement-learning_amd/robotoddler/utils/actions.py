@@ -28,13 +28,16 @@ def generate_actions(gym: AssemblyGym, x_discr_ground, offset_values=None, max_a
 
 
 def filter_actions(gym_env, available_actions, action_features, block_features, obstacle_features, xlim, ylim):
-    """Keep actions that stay in bounds and overlap neither the state nor the obstacle raster."""
-    mask = torch.zeros(len(available_actions), dtype=bool)
-    kept = []
-    for i, action in enumerate(available_actions):
-        if (not gym_env.collision_on_action(action, xlim, ylim)
-                and torch.sum(action_features[i] * block_features) == 0
-                and torch.sum(action_features[i] * obstacle_features) == 0):
-            mask[i] = True
-            kept.append(action)
+    """Keep actions that stay in bounds and overlap neither the state nor the obstacle raster (actions.py:71-82 of the
+    reference).  Same three tests per action; the two raster overlaps of ALL actions are two reductions and one copy
+    to the host (the reference's loop reads two device scalars back per action), and collision_on_action finds the
+    blocks get_action_features created a moment ago in the gym's candidate cache."""
+    n = len(available_actions)
+    if n == 0:
+        return [], action_features[:0]
+    in_bounds = torch.tensor([not gym_env.collision_on_action(a, xlim, ylim) for a in available_actions], dtype=torch.bool)
+    feats = action_features.reshape(n, -1)
+    free = ((feats * block_features.reshape(1, -1)).sum(dim=1) == 0) & ((feats * obstacle_features.reshape(1, -1)).sum(dim=1) == 0)
+    mask = in_bounds & free.cpu()
+    kept = [a for a, m in zip(available_actions, mask.tolist()) if m]
     return kept, action_features[mask.to(action_features.device)]

@@ -71,7 +71,8 @@ typedef struct {
     int32_t n_ground;          /* len(x_discr_ground) */
     int32_t n_offsets;         /* len(offset_values) */
     int32_t n_targets;
-    int32_t debug;             /* 0; bit0 = skip the LPs (kernel timing experiments only) */
+    int32_t debug;             /* 0.  Diagnostic builds (-DBRIDGES_DIAG) read timing-experiment switches from it; the
+                                  product library refuses any other value */
     int32_t env_id_base;       /* global id of env 0 (policy RNG stream = seed, env_id_base + e) */
     int32_t img_size;          /* S of the S x S images (--image_size, successor_dqn.py:585); 0 = 64.  S < 64: every
                                   image buffer keeps its 64x64 / 64-word layout and the image is its top-left S x S
@@ -136,6 +137,8 @@ typedef struct {
     /* --- task features --- */
     const uint64_t* obstacle_bits; /* [64] */
     const float* reward_map;       /* [64,64] */
+    const double* reward_prefix;   /* [64,65] float64 row prefix sums of reward_map: [r][x] = sum of reward_map[r][0..x-1]
+                                      (the rasteriser takes a candidate's sum(raster * reward_map) from its row runs) */
     /* --- scratch --- */
     double* lp_ws;             /* [E, lp_ws_stride] per-env persistent simplex tableau (incremental solve of bridges_env_step):
                                   header + basis + two tableau halves; owned by the library between reset and step calls */
@@ -184,18 +187,6 @@ typedef struct bridges_gate bridges_gate;
 int bridges_gate_create(bridges_gate** out);
 int bridges_gate_destroy(bridges_gate* gate);
 int bridges_env_set_gate(bridges_env* env, bridges_gate* gate);
-/* Run this env's rasteriser on `raster_stream` instead of the stream passed to bridges_env_step (NULL: back to one
- * stream).  With several env groups sharing ONE raster stream their rasterisers run back to back in stream order
- * while each group's latency-bound kernels stay on the group's own stream (which may carry a CU mask). */
-int bridges_env_set_raster_stream(bridges_env* env, void* raster_stream);
-/* A HIP stream restricted to the compute units whose bits are set in cu_mask (n_words 32-bit words; 0 words: an
- * ordinary non-blocking stream), for the caller to pass as `stream` / `raster_stream`. */
-int bridges_stream_create_masked(const uint32_t* cu_mask, int32_t n_words, void** out_stream);
-int bridges_stream_destroy(void* stream);
-/* With a gate: launch the rasteriser of a lock-step as a head (head_permille / 1000 of the expected images) and a tail,
- * and release the gate behind the head, so the next group's rasteriser starts while this one's tail drains.
- * 0 = one launch (default).  Results do not depend on it. */
-int bridges_env_set_raster_split(bridges_env* env, int32_t head_permille);
 /* Candidate refresh only (used after the host edited the state). */
 int bridges_env_refresh(bridges_env* env, void* stream);
 /* is_action_stable_rbe (assembly_gym/assembly_gym/utils/stability.py:122-130) for EVERY valid candidate of every

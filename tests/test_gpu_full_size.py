@@ -45,19 +45,6 @@ def test_full_size_determinism_and_grouping_independence():
             assert torch.equal(xa, xc)          # env groups / streams do not change any env's trajectory
 
 
-@pytest.mark.parametrize("mode", ["plain", "mask:96:all"])
-def test_raster_stream_arrangements_do_not_change_the_trajectories(mode, monkeypatch):
-    """BRIDGES_RASTER_STREAM (all rasterisers on one extra stream, optionally CU-masked group streams: an experiment
-    recorded in DESIGN.md) only reorders launches: every env's trajectory stays bit-identical."""
-    E, n = 2048, 12
-    a = trajectory(make(E, groups=2, seed=3), n, True)
-    monkeypatch.setenv("BRIDGES_RASTER_STREAM", mode)
-    b = trajectory(make(E, groups=2, seed=3), n, True)
-    for sa, sb in zip(a, b):
-        for xa, xb in zip(sa, sb):
-            assert torch.equal(xa, xb)
-
-
 def test_full_size_invariants():
     E = 4096
     env = make(E, seed=9, f32=True)
