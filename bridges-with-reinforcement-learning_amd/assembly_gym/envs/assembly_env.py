@@ -6,6 +6,8 @@ successor_dqn.py:695 builds AssemblyEnv(render=False)); asking for it raises Not
 import math
 from collections import namedtuple
 
+import os
+
 import numpy as np
 
 from bridges_hip import ops
@@ -211,7 +213,7 @@ class AssemblyEnv:
         key = (tuple(id(b) for b in self.blocks), tuple(bool(b.is_static) for b in self.blocks), float(self.mu),
                float(self.density), id(self.stability_fct))
         memo = self._stability_memo
-        if key not in memo:
+        if key not in memo or os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":
             if len(memo) > 64:
                 memo.clear()
             memo[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique

@@ -2,6 +2,7 @@
 (assembly_gym/assembly_gym/envs/gym_env.py:11-333 of the reference).  gymnasium itself is not required: the class
 keeps the gymnasium calling convention (reset -> (obs, info); step -> (obs, reward, terminated, truncated, info)).
 Placement runs in bridges_create_block, stability in bridges_stability."""
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -156,6 +157,16 @@ class AssemblyGym:
         candidate twice per env-step (get_action_features, successor_dqn.py:69, then collision_on_action through
         filter_actions, actions.py:71-82) -- the second round is served from here."""
         state = (len(self.assembly_env.blocks), id(self.assembly_env.blocks[-1]) if self.assembly_env.blocks else None)
+        if os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":      # A/B switch of tools/single_env_throughput.py:
+            self._block_cache, self._block_cache_state = {}, None       # one operator call per candidate, nothing kept
+            out = []
+            for a in actions:
+                target = None if a.target_block == -1 else self.assembly_env.blocks[a.target_block]
+                sh = self.shapes[a.shape]
+                pose, verts, frames = ops.create_block(target, a.target_face, sh.geometry, a.face, a.offset_x, a.offset_y)
+                out.append(Block(sh, position=[pose[0], 0.0, pose[1]], orientation=Quaternion.from_cos_sin(pose[2], pose[3]),
+                                 _posed=(pose, verts, frames)))
+            return out
         if self._block_cache_state != state:
             self._block_cache, self._block_cache_state = {}, state
         keys = [(a.target_block, a.target_face, a.shape, a.face, float(a.offset_x), float(a.offset_y)) for a in actions]

@@ -186,7 +186,9 @@ def lib():
         "bridges_linear_forward": [i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp],
         "bridges_linear_backward": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
         "bridges_mlp_input": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
-        "bridges_successor_loss": [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp],
+        "bridges_successor_loss": [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp],
+        "bridges_adam_step": [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp],
+        "bridges_linear_backward_adam": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp],
         "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
     }
     for name, argtypes in sigs.items():
@@ -205,7 +207,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_timing_begin", "bridges_env_timing_end",
     "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
-    "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_successor_loss",
+    "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_successor_loss", "bridges_adam_step", "bridges_linear_backward_adam",
 )
 
 

@@ -3,6 +3,8 @@ f32 matrix cores (csrc/mlp_kernels.hip; robotoddler/models/cv.py:76-105, train_p
 robotoddler/training/successor_dqn.py:157-235).  The parameters stay the module's own tensors, the gradients land in
 their ``.grad`` -- the optimiser (torch's fused Adam) is untouched.  No CPU fallback: abi.require_gpu() raises without
 the HIP library."""
+import ctypes as C
+
 import torch
 
 from . import abi
@@ -42,12 +44,17 @@ class FusedSuccessorStep:
 
     ``launch`` reads replay batch ``counter`` of the per-call arrays (row counter * batch + b), leaves the loss in
     ``losses[counter]``, the gradients in the parameters' ``.grad`` and increments ``counter`` -- every argument is a
-    device tensor and nothing synchronises, so the sequence can be captured in a HIP graph together with the
-    optimiser step."""
+    device tensor and nothing synchronises, so the sequence can be captured in a HIP graph.
+
+    With ``optimizer`` = the torch.optim.Adam that owns exactly the net's (flattened) parameters, the Adam update is part
+    of the sequence too (``fused_adam``): one bridges_adam_step launch over the flat parameter / gradient / moment buffers
+    instead of torch's multi-tensor launch; the moments stay the optimiser's own state tensors (re-pointed into flat
+    buffers), the step count lives in ``adam_step`` and is written back by ``export_state()`` (before a checkpoint or a
+    return to ``optimizer.step()``).  The caller must then NOT call ``optimizer.step()`` after ``launch``."""
 
     WS_FLOATS = 4 << 20
 
-    def __init__(self, net, batch, use_q, use_sf):
+    def __init__(self, net, batch, use_q, use_sf, optimizer=None):
         self.L = abi.require_gpu()
         self.linears = [m for m in net.mlp.layers if isinstance(m, torch.nn.Linear)]
         self.px = int(net.img_size[0]) * int(net.img_size[1])
@@ -65,16 +72,90 @@ class FusedSuccessorStep:
         self.dz = [z(self.rows, d) for d in dims[1:]]                # gradient at the pre-activation of every layer
         self.ws = torch.empty(self.WS_FLOATS, dtype=torch.float32, device=dev)
         self.loss_rows, self.q = z(self.rows), z(self.rows)
-        # the gradient tensors the launches write: referenced here as well, so a later zero_grad(set_to_none=True) cannot
-        # hand their memory to someone else while a captured graph still writes to it
+        self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)  # word 0: arrival ticket of the loss kernel (re-armed by it)
+        # the gradient tensors the launches write.  With flattened parameters (dqn_ops.FlatParameters) they are views of
+        # ONE flat buffer laid out like the parameter buffer; either way they are referenced here as well, so a later
+        # zero_grad(set_to_none=True) cannot hand their memory to someone else while a captured graph still writes to it
+        flat = getattr(net, "_flat_params", None)
+        params = [p for lin in self.linears for p in (lin.weight, lin.bias)]
+        self.flat, self.grad_flat = None, None
+        if flat is not None and all(self._offset(flat.flat, p) is not None for p in params):
+            self.flat, self.grad_flat = flat.flat, torch.zeros_like(flat.flat)
         self._grads = []
+        for p in params:
+            assert p.dtype == torch.float32 and p.is_contiguous()
+            if self.grad_flat is not None:
+                off = self._offset(self.flat, p)
+                p.grad = self.grad_flat[off:off + p.numel()].view_as(p)
+            elif p.grad is None:
+                p.grad = torch.zeros_like(p)
+            assert p.grad.is_contiguous()
+            self._grads.append(p.grad)
+        self.fused_adam, self.optimizer = False, None
+        if (optimizer is not None and self.grad_flat is not None and self._adam_applies(optimizer, net)
+                and {id(p) for p in params} == {id(p) for p in net.parameters()}):
+            self._adopt_adam(optimizer, params)
+
+    @staticmethod
+    def _offset(flat, p):
+        """Element offset of parameter ``p`` inside the flat buffer, or None if it does not live there."""
+        d = p.data_ptr() - flat.data_ptr()
+        if d < 0 or d % 4 or d // 4 + p.numel() > flat.numel():
+            return None
+        return d // 4
+
+    @staticmethod
+    def _adam_applies(opt, net):
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("differentiable"):
+            return False
+        if isinstance(g["lr"], torch.Tensor):
+            return False
+        return {id(p) for p in g["params"]} == {id(p) for p in net.parameters()}
+
+    def _adopt_adam(self, opt, params):
+        g = opt.param_groups[0]
+        self.lr, (self.beta1, self.beta2), self.eps = float(g["lr"]), (float(b) for b in g["betas"]), float(g["eps"])
+        self.m_flat, self.v_flat = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        step = 0.0
+        for p in params:
+            off = self._offset(self.flat, p)
+            st = opt.state[p]
+            mv, vv = self.m_flat[off:off + p.numel()].view_as(p), self.v_flat[off:off + p.numel()].view_as(p)
+            if "exp_avg" in st:                                      # continue from what optimizer.step() has done so far
+                mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])
+                step = float(st["step"])
+            else:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+            st["exp_avg"], st["exp_avg_sq"] = mv, vv                 # the optimiser's state IS the flat buffers from here on
+        self.adam_step = torch.full((), step, dtype=torch.float32, device=self.flat.device)
+        # per layer: the flat range [lo, hi) of its weight + bias (hi rounded up to the 16-byte padding of the layout) and
+        # the moment views of the first layer (whose update is folded into its weight-gradient tiles)
+        self._slices, self._moments = [], []
         for lin in self.linears:
-            for p in (lin.weight, lin.bias):
-                assert p.dtype == torch.float32 and p.is_contiguous()
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                assert p.grad.is_contiguous()
-                self._grads.append(p.grad)
+            ow, ob = self._offset(self.flat, lin.weight), self._offset(self.flat, lin.bias)
+            lo, hi = min(ow, ob), max(ow + lin.weight.numel(), ob + lin.bias.numel())
+            hi = min((hi + 3) // 4 * 4, self.flat.numel())
+            assert lo % 4 == 0
+            self._slices.append((lo, hi))
+            self._moments.append((opt.state[lin.weight]["exp_avg"], opt.state[lin.weight]["exp_avg_sq"],
+                                  opt.state[lin.bias]["exp_avg"], opt.state[lin.bias]["exp_avg_sq"]))
+        covered = sorted(self._slices)
+        assert all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), "layer ranges of the flat buffer overlap"
+        self.side = torch.cuda.Stream(device=self.flat.device)
+        self.optimizer, self.fused_adam = opt, True
+
+    def export_state(self):
+        """Write the step count back into the optimiser's per-parameter state (its moments already are the flat buffers):
+        call before ``optimizer.state_dict()`` / ``optimizer.step()``."""
+        if self.fused_adam:
+            for st in self.optimizer.state.values():
+                if isinstance(st.get("step"), torch.Tensor):
+                    st["step"].copy_(self.adam_step)
+                else:
+                    st["step"] = float(self.adam_step)
 
     def launch(self, counter, block_all, action_all, binary_all, reward, obstacle, q_target_all, sf_target_all, losses):
         L, rows, px, nf, B = self.L, self.rows, self.px, self.nf, self.batch
@@ -89,15 +170,39 @@ class FusedSuccessorStep:
             abi.check(L.bridges_linear_forward(rows, lin.in_features, lin.out_features, _ptr(self.acts[l]), _ptr(lin.weight),
                                                _ptr(lin.bias), int(l < last), _ptr(self.acts[l + 1]), _ptr(self.ws),
                                                self.ws.numel(), st), "bridges_linear_forward")
+        # the loss kernel's last-arriving row workgroup logs the loss, advances the batch counter and the Adam step count
         abi.check(L.bridges_successor_loss(B, rows, px, nf, _ptr(self.acts[-1]), _ptr(reward), _ptr(counter),
                                            _ptr(q_target_all) if self.use_q else None,
                                            _ptr(sf_target_all) if self.use_sf else None, int(self.use_q), int(self.use_sf),
                                            _ptr(self.dz[-1]), _ptr(self.loss_rows), _ptr(self.q), _ptr(losses),
-                                           losses.numel(), _ptr(counter), st), "bridges_successor_loss")
+                                           losses.numel(), _ptr(counter), _ptr(self.ticket),
+                                           _ptr(self.adam_step) if self.fused_adam else None, st), "bridges_successor_loss")
+        cur = torch.cuda.current_stream()
+        fold_first = self.fused_adam and rows == 32
         for l in range(last, -1, -1):
             lin = self.linears[l]
+            if l == 0 and fold_first:
+                # the first layer has no input gradient: Adam goes into its weight-gradient tiles, no gradient is written
+                mw, vw, mb, vb = self._moments[0]
+                abi.check(L.bridges_linear_backward_adam(rows, lin.in_features, lin.out_features, _ptr(self.dz[0]), _ptr(self.acts[0]),
+                                                         _ptr(lin.weight), _ptr(lin.bias), _ptr(mw), _ptr(vw), _ptr(mb), _ptr(vb),
+                                                         _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),
+                          "bridges_linear_backward_adam")
+                continue
             abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]), _ptr(self.acts[l]),
                                                 _ptr(lin.weight), _ptr(lin.weight.grad), _ptr(lin.bias.grad),
                                                 _ptr(self.acts[l]) if l > 0 else None,
                                                 _ptr(self.dz[l - 1]) if l > 0 else None, _ptr(self.ws), self.ws.numel(), st),
                       "bridges_linear_backward")
+            if self.fused_adam:
+                # this layer's weights are not read again in the step: its Adam update runs on a side stream beside the
+                # backward launches of the layers below (a parallel branch of the captured graph)
+                lo, hi = self._slices[l]
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    abi.check(L.bridges_adam_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad_flat.data_ptr() + 4 * lo),
+                                                  C.c_void_p(self.m_flat.data_ptr() + 4 * lo), C.c_void_p(self.v_flat.data_ptr() + 4 * lo),
+                                                  hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, _stream()),
+                              "bridges_adam_step")
+        if self.fused_adam:
+            cur.wait_stream(self.side)

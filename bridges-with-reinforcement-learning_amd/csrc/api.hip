@@ -590,9 +590,9 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
     }
     hipStream_t st = (hipStream_t)stream;
     // one split: the input gradient goes straight to dz_below (masked), no partial sums
-    hipLaunchKernelGGL(k_lin_bwd, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
+    hipLaunchKernelGGL(k_lin_bwd<false>, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
                        !dz_below ? (float*)nullptr : (nsplit == 1 ? dz_below : ws), nsplit == 1 ? act_below : (const float*)nullptr,
-                       n_dw_jobs, per_job, nsplit, nchunk);
+                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{});
     LAUNCH_CHECK("k_lin_bwd");
     if (dz_below && nsplit > 1) {
         int blocks = ceil_div(rows * K, 256);
@@ -600,6 +600,23 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
         hipLaunchKernelGGL(k_lin_dx_finish, dim3(blocks), dim3(256), 0, st, rows, K, nsplit, ws, act_below, dz_below);
         LAUNCH_CHECK("k_lin_dx_finish");
     }
+    return BRIDGES_OK;
+}
+
+int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
+                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, const float* step,
+                                 float lr, float beta1, float beta2, float eps, void* stream) {
+    if (rows != 32 || K <= 0 || N <= 0 || !dz || !a_in || !W || !bias || !exp_avg_w || !exp_avg_sq_w || !exp_avg_b || !exp_avg_sq_b || !step)
+        return fail_arg("bridges_linear_backward_adam: one 32-row batch tile, all buffers given");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return fail_arg("bridges_linear_backward_adam: hyper-parameters");
+    const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32);
+    int per_job = ceil_div(n_ntiles * n_ktiles, 1024);
+    if (per_job < 4) per_job = 4;
+    const int n_dw_jobs = n_ntiles * ceil_div(n_ktiles, per_job);
+    AdamFold ad{W, bias, exp_avg_w, exp_avg_sq_w, exp_avg_b, exp_avg_sq_b, step, lr, beta1, beta2, eps};
+    hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in, (const float*)W,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job, 0, 0, ad);
+    LAUNCH_CHECK("k_lin_bwd<adam>");
     return BRIDGES_OK;
 }
 
@@ -619,18 +636,38 @@ int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const
 int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* y, const float* reward,
                            const int64_t* counter, const float* q_target_all, const float* sf_target_all, int32_t use_q,
                            int32_t use_sf, float* dy, float* loss_rows, float* q_out, float* losses, int32_t n_losses,
-                           int64_t* counter_inc, void* stream) {
+                           int64_t* counter_inc, int32_t* ticket, float* adam_step, void* stream) {
     if (batch <= 0 || rows < batch || px <= 0 || nf < 0 || !y || !reward || !counter || !dy || !loss_rows || !q_out)
         return fail_arg("bridges_successor_loss");
     if ((use_q && !q_target_all) || (use_sf && !sf_target_all)) return fail_arg("bridges_successor_loss: target missing");
+    if (ticket && !counter_inc) return fail_arg("bridges_successor_loss: a ticket needs counter_inc");
+    if (adam_step && !ticket) return fail_arg("bridges_successor_loss: adam_step is advanced by the ticket holder");
     hipStream_t st = (hipStream_t)stream;
+    // with a ticket word (zero before the first call; the kernel re-arms it) the logging happens inside the loss kernel
     hipLaunchKernelGGL(k_successor_loss, dim3(rows), dim3(LOSS_THREADS), 0, st, batch, px, nf, y, reward, counter, q_target_all,
-                       sf_target_all, use_q, use_sf, dy, loss_rows, q_out);
+                       sf_target_all, use_q, use_sf, dy, loss_rows, q_out, losses, n_losses, ticket ? counter_inc : (int64_t*)nullptr,
+                       ticket, adam_step);
     LAUNCH_CHECK("k_successor_loss");
-    if (losses && counter_inc) {
+    if (!ticket && losses && counter_inc) {
         hipLaunchKernelGGL(k_loss_log, dim3(1), dim3(64), 0, st, batch, loss_rows, losses, n_losses, counter_inc);
         LAUNCH_CHECK("k_loss_log");
     }
+    return BRIDGES_OK;
+}
+
+int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
+                      float lr, float beta1, float beta2, float eps, void* stream) {
+    if (n < 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step) return fail_arg("bridges_adam_step");
+    if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15)
+        return fail_arg("bridges_adam_step: buffers must be 16-byte aligned");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return fail_arg("bridges_adam_step: hyper-parameters");
+    if (n == 0) return BRIDGES_OK;
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_adam_flat, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, step,
+                       lr, beta1, beta2, eps);
+    LAUNCH_CHECK("k_adam_flat");
     return BRIDGES_OK;
 }
 

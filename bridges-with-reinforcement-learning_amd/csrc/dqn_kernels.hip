@@ -23,6 +23,49 @@ __global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ target,
         target[i] = policy[i] * tau + target[i] * omt;
 }
 
+// One Adam step (torch.optim.Adam, amsgrad = False, weight_decay = 0, maximize = False; the optimiser of
+// successor_dqn.py:640) over ONE flat float32 buffer of parameters / gradients / moments, 16 B per lane:
+//   m = m + (g - m) * (1 - beta1);  v = beta2 * v + (1 - beta2) * g * g;
+//   p = p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+// (the operation order of torch's fused kernel).  t = *step, a device float the caller has ALREADY incremented for this
+// step (the fused SuccessorMLP step does it in its loss kernel); the bias corrections are formed in float64.
+// 7 x 4 B of traffic per parameter (torch's multi-tensor launch moves the same bytes at ~3.9 TB/s: 46 us for the 6.4 M
+// parameters of SuccessorMLP; this launch streams them in one grid).
+__global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ step, float lr,
+                                                   float beta1, float beta2, float eps) {
+    const double t = (double)*step;
+    const float step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+#define ADAM_ONE(P, G, M, V)                                         \
+    do {                                                             \
+        M = M + (G - M) * w1;                                        \
+        V = beta2 * V + w2 * G * G;                                  \
+        P = P - step_size * M / (sqrtf(V) / bc2_sqrt + eps);         \
+    } while (0)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        ADAM_ONE(pp.x, gg.x, mm.x, vv.x);
+        ADAM_ONE(pp.y, gg.y, mm.y, vv.y);
+        ADAM_ONE(pp.z, gg.z, mm.z, vv.z);
+        ADAM_ONE(pp.w, gg.w, mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        ADAM_ONE(pp, gg, mm, vv);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+#undef ADAM_ONE
+}
+
 // train_policy_net target construction (successor_dqn.py:197-213, 222, 230).  One workgroup per transition:
 // segmented first-argmax over its next-action rows, then the q target and (optionally) the successor-feature
 // target row, 16 B per lane.

@@ -140,17 +140,35 @@ __global__ __launch_bounds__(256) void k_lin_fwd_finish(int rows, int N, int spl
     }
 }
 
+// Adam folded into the weight-gradient jobs of a layer WITHOUT an input gradient (the first layer: nothing in the step
+// reads its weights after the forward pass, so they may change in place): the 32x32 gradient tile in the accumulators
+// goes straight into m, v and W -- the gradient never exists in memory (for SuccessorMLP's first layer that is 16.8 MB
+// not written and not read again, and 4.2 M of the 6.4 M parameters out of the separate Adam launch).  Same arithmetic as
+// k_adam_flat (dqn_kernels.hip).
+struct AdamFold {
+    float* W; float* bias; float* mW; float* vW; float* mb; float* vb;
+    const float* step;                  // device float: number of THIS update (already incremented)
+    float lr, beta1, beta2, eps;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, float beta2,
+                                         float w1, float w2, float eps) {
+    m = m + (g - m) * w1;
+    v = beta2 * v + w2 * g * g;
+    p = p - step_size * m / (sqrtf(v) / bc2_sqrt + eps);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of one Linear layer, both products in one launch.  dz [rows][N] = gradient at the layer's pre-activation.
 //   jobs [0, n_dw_jobs): dW[n][k] = sum_b dz[b][n] * a[b][k] (32x32 tiles, the batch is the reduction); the jobs of
 //     the first k group also write db[n] = sum_b dz[b][n].
 //   jobs [n_dw_jobs, ...): dxpart[split][b][k] = sum_{n in split} dz[b][n] * W[n][k]  (k_lin_dx_finish adds the splits
 //     and applies the ReLU mask of the layer below; with one split act_mask is given and the masked sum is final).
+template <bool ADAM>
 __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const float* __restrict__ dz,
                                                  const float* __restrict__ a, const float* __restrict__ W,
                                                  float* __restrict__ dW, float* __restrict__ db,
                                                  float* __restrict__ dxpart, const float* __restrict__ act_mask,
-                                                 int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk) {
+                                                 int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk, AdamFold ad) {
     __shared__ float red[3][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, half = lane >> 5;
@@ -169,12 +187,28 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
             float av[16], bv[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) av[t] = dz[(size_t)(2 * t + half) * N + ncol];
+            float step_size = 0.f, bc2_sqrt = 1.f, w1 = 0.f, w2 = 0.f;
+            if constexpr (ADAM) {
+                const double t = (double)*ad.step;
+                step_size = (float)((double)ad.lr / (1.0 - pow((double)ad.beta1, t)));
+                bc2_sqrt = (float)sqrt(1.0 - pow((double)ad.beta2, t));
+                w1 = 1.f - ad.beta1; w2 = 1.f - ad.beta2;
+            }
             if (want_db) {
                 float sdb = 0.f;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) sdb += av[t];            // rows 2t + half; the other half sits 32 lanes away
                 sdb += __shfl_xor(sdb, 32);
-                if (half == 0 && n0 + row < N) db[n0 + row] = sdb;
+                if (half == 0 && n0 + row < N) {
+                    if constexpr (ADAM) {
+                        const int o = n0 + row;
+                        float pb = ad.bias[o], mb = ad.mb[o], vb = ad.vb[o];
+                        adam_one(pb, sdb, mb, vb, step_size, bc2_sqrt, ad.beta2, w1, w2, ad.eps);
+                        ad.bias[o] = pb; ad.mb[o] = mb; ad.vb[o] = vb;
+                    } else {
+                        db[n0 + row] = sdb;
+                    }
+                }
             }
             if (kt < kt_end) {
                 const int kcol = (kt * 32 + row < K) ? kt * 32 + row : K - 1;
@@ -194,10 +228,29 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
                     for (int t = 0; t < 16; ++t) bv[t] = a[(size_t)(2 * t + half) * K + kcol];
                 }
                 if (k < K) {
+                    if constexpr (ADAM) {
+                        float pw[16], pm[16], pv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int n = n0 + mfma_row(r, lane);
-                        if (n < N) dW[(size_t)n * K + k] = acc[r];
+                        for (int r = 0; r < 16; ++r) {                // all loads of the tile first
+                            const int n = n0 + mfma_row(r, lane);
+                            const size_t o = (size_t)(n < N ? n : N - 1) * K + k;
+                            pw[r] = ad.W[o]; pm[r] = ad.mW[o]; pv[r] = ad.vW[o];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int n = n0 + mfma_row(r, lane);
+                            if (n < N) {
+                                const size_t o = (size_t)n * K + k;
+                                adam_one(pw[r], acc[r], pm[r], pv[r], step_size, bc2_sqrt, ad.beta2, w1, w2, ad.eps);
+                                ad.W[o] = pw[r]; ad.mW[o] = pm[r]; ad.vW[o] = pv[r];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int n = n0 + mfma_row(r, lane);
+                            if (n < N) dW[(size_t)n * K + k] = acc[r];
+                        }
                     }
                 }
             }
@@ -327,6 +380,32 @@ __global__ __launch_bounds__(256) void k_mlp_input(int batch, int rows, int px, 
     }
 }
 
+// What k_loss_log does, inside the loss kernel: the row workgroup that arrives LAST sums the per-row losses in row order
+// (the same order, hence the same float), logs them, advances the batch counter and the optimiser's step count, and
+// re-arms the ticket.  Inter-workgroup hand-off by the counter form of the release / acquire recipe
+// (cdna_hip_programming.md, Guideline 16): thread 0 is the only thread of its workgroup that stored a handed-off value
+// (loss_rows[b]); it drains its stores, releases at agent scope, drains again, then draws its ticket with an agent-scope
+// atomic; the last arriver acquires at agent scope and reads every row with agent-scope (sc1) loads.  The batch counter
+// is read by every workgroup BEFORE it draws its ticket, so the last arriver may advance it.
+__device__ __forceinline__ void loss_log_ticket(int batch, float* loss_rows, float* losses, int n_losses, int64_t* counter,
+                                                int32_t* ticket, float* adam_step, int t) {
+    if (t != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (drawn != (int)gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float l = 0.f;
+    for (int b = 0; b < batch; ++b) l += __hip_atomic_load(&loss_rows[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t c = *counter;
+    if (losses && c >= 0 && c < n_losses) losses[c] = l;
+    *counter = c + 1;
+    if (adam_step) *adam_step = *adam_step + 1.f;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Head and loss (cv.py:104-108, successor_dqn.py:215-232): y [rows][2 px + 2 nf] = (psi0 | psi1 | binary part).
 //   q[b]   = sum_j softmax(psi0, psi1)[1][j] * reward[j]            (softmax over the two channels = sigmoid(psi1 - psi0))
 //   loss   = [use_q] mean_b (q - q_t)^2 + [use_sf] mean_b mean_j (psi0 - sf_t)^2
@@ -339,7 +418,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int 
                                                                  const float* __restrict__ q_target_all,
                                                                  const float* __restrict__ sf_target_all, int use_q,
                                                                  int use_sf, float* __restrict__ dy,
-                                                                 float* __restrict__ loss_rows, float* __restrict__ q_out) {
+                                                                 float* __restrict__ loss_rows, float* __restrict__ q_out,
+                                                                 float* __restrict__ losses, int n_losses,
+                                                                 int64_t* __restrict__ counter_inc, int32_t* __restrict__ ticket,
+                                                                 float* __restrict__ adam_step) {
     __shared__ double s_q[LOSS_THREADS / 64], s_l[LOSS_THREADS / 64];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int N = 2 * px + 2 * nf;
@@ -347,6 +429,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int 
     if (b >= batch) {
         for (int j = t; j < N; j += LOSS_THREADS) dyr[j] = 0.f;
         if (t == 0) { loss_rows[b] = 0.f; q_out[b] = 0.f; }
+        if (ticket) loss_log_ticket(batch, loss_rows, losses, n_losses, counter_inc, ticket, adam_step, t);
         return;
     }
     const float* yr = y + (size_t)b * N;
@@ -409,6 +492,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int 
         loss_rows[b] = l;
         q_out[b] = q;
     }
+    if (ticket) loss_log_ticket(batch, loss_rows, losses, n_losses, counter_inc, ticket, adam_step, t);
 }
 
 // losses[*counter] = sum_b loss_rows[b]; ++*counter.

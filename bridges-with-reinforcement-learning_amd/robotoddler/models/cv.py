@@ -144,6 +144,19 @@ class SuccessorMLP(nn.Module):
         return binary_features @ W1[:, 4 * px:].T + const
 
     @torch.no_grad()
+    def sf0_from_first_layer(self, h_pre):
+        """Channel 0 of the successor block features (``forward(...)[1][:, 0]`` flattened to [n, px]) from the
+        pre-activation of the first layer: the remaining hidden layers and the first px rows of the output layer -- what the
+        successor-feature target of train_policy_net reads of the target net (successor_dqn.py:206-213), without the
+        [n, 4*px+f] input, the other 2*px+2f-px outputs or the softmax of the module forward."""
+        lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
+        px = self.img_size[0] * self.img_size[1]
+        h = F.relu(h_pre)
+        for layer in lin[1:-1]:
+            h = F.relu(layer(h))
+        return torch.addmm(lin[-1].bias[:px], h, lin[-1].weight[:px].T)
+
+    @torch.no_grad()
     def q_from_first_layer(self, h_pre, reward_features, head=None):
         """q from the pre-activation of the first layer ([n, hidden]): the remaining layers and the factored head.
         ``head(d, w) -> sum_j w[j] * sigmoid(d[:, j])`` may be supplied as a fused operator."""

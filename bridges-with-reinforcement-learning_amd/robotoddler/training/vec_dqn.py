@@ -130,7 +130,9 @@ class VecDQN:
         return self._net_q(self.policy_net, env, idx, row_env, stable)
 
     @torch.no_grad()
-    def _net_q(self, net, env, idx, row_env, stable):
+    def _net_q(self, net, env, idx, row_env, stable, return_h=False):
+        """q of ``net`` for the candidate rows; with return_h (factored nets only) also the first layer's pre-activation
+        of every row, from which the successor features of selected rows follow without a second first-layer pass."""
         net.eval()
         if not self._factored(net):
             if env.cand_raster is None:
@@ -146,7 +148,8 @@ class VecDQN:
                                base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
                                base_row=torch.arange(E, device=self.device))
         h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
-        return net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot)
+        q = net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot)
+        return (q, h_pre) if return_h else q
 
     @torch.no_grad()
     def td_errors(self, rec):
@@ -255,15 +258,17 @@ class VecDQN:
         if idx.numel() and self._factored(self.target_net):
             # q of every next candidate through the factored forward on the bit-packed rasters; the 8204-wide output
             # (successor features) is only needed for the arg-max row of each transition
-            nq = self._net_q(self.target_net, renv, idx, row_env, stable_n).contiguous().float()
+            nq, h_pre = self._net_q(self.target_net, renv, idx, row_env, stable_n, return_h=True)
+            nq = nq.contiguous().float()
             q_target, _, arg = dqn_ops.td_target(seg, nq, lin, done, self.gamma)
             sf_target = None
             if use_sf:
                 best = arg.long().clamp_(0, idx.numel() - 1)                       # empty segments are 'done': row unused
-                nsf = self._forward_rows(self.target_net, renv, idx[best], row_env[best], stable_n)[1]
+                # channel 0 of the arg-max rows' successor features from the first-layer pre-activations already at hand
+                nsf0 = self.target_net.sf0_from_first_layer(h_pre.index_select(0, best)).contiguous()
                 one_each = torch.arange(E + 1, dtype=torch.int32, device=self.device)
                 _, sf_target, _ = dqn_ops.td_target(one_each, nq[best].contiguous(), lin, done, self.gamma,
-                                                    next_sf=nsf[:, 0], action_raster=action_f.squeeze(1))
+                                                    next_sf=nsf0, action_raster=action_f.squeeze(1))
         elif idx.numel():
             nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
             if use_sf and nsf is None:
@@ -311,7 +316,8 @@ class VecDQN:
             n = n_max * B
             st["step"].launch(st["counter"], st["block"].view(n, -1), st["action"].view(n, -1), st["binary"], st["reward"],
                               st["obstacle"], st["q"], st["sf"], st["losses"])
-            self.opt.step()
+            if not st["step"].fused_adam:                 # else the Adam update is the last launch of the sequence
+                self.opt.step()
 
         def body():
             idx = st["lane"] + st["counter"] * B
@@ -335,7 +341,8 @@ class VecDQN:
         self.opt.zero_grad(set_to_none=True)
         if st["fused"]:
             from bridges_hip.mlp_ops import FusedSuccessorStep
-            st["step"] = FusedSuccessorStep(self.policy_net, B, 'mse_q_values' in self.loss_parts, use_sf)
+            st["step"] = FusedSuccessorStep(self.policy_net, B, 'mse_q_values' in self.loss_parts, use_sf,
+                                            optimizer=self.opt if os.environ.get("BRIDGES_FUSED_ADAM", "1") != "0" else None)
             st["reward"] = self.env.reward_features.reshape(-1).contiguous()
             st["obstacle"] = self.env.obstacle_raster.reshape(-1).contiguous()
         graph = torch.cuda.CUDAGraph()
@@ -364,6 +371,7 @@ class VecDQN:
             return None
         st = self._graph_state
         if st is not None and (st["n_max"] < n_steps or st["use_sf"] != use_sf):
+            self.sync_optimizer_state()
             st = self._graph_state = None                     # more batches per call than captured for: capture again
         if st is None:
             if self._eager_calls < 2:
@@ -435,8 +443,16 @@ class VecDQN:
         means a kernel in the graph misbehaved -- from then on the step runs eagerly."""
         if not all(np.isfinite(l) and l >= 0.0 for l in losses):
             warnings.warn(f"train-step graph produced an invalid loss {losses}; switching to the eager step")
+            self.sync_optimizer_state()
             self._graph_state, self._eager_calls = None, -(1 << 30)
         return losses
+
+    def sync_optimizer_state(self):
+        """The captured step keeps Adam's step count itself (FusedSuccessorStep.adam_step); hand it back to the torch
+        optimiser before its state is saved or ``optimizer.step()`` takes over again."""
+        st = self._graph_state
+        if st is not None and st.get("fused") and st["step"].fused_adam:
+            st["step"].export_state()
 
     def train_step(self):
         out = self.train_steps(1)
@@ -573,6 +589,7 @@ def run_vectorised(args, device, aim_run=None, wandb_run=None, return_agent=Fals
         losses, rec = agent.lockstep(args['num_training_steps'], defer_losses=True)
         it += 1
         if args.get('save_checkpoint') and agent.episodes_done >= next_ckpt:                  # utils.py:54-89 layout
+            agent.sync_optimizer_state()
             if rank == 0:
                 from robotoddler.utils.utils import save_checkpoint
                 save_checkpoint(args['save_checkpoint'], policy_net, target_net, agent.ring, opt, agent.episodes_done,

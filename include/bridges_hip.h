@@ -304,6 +304,12 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
                             void* stream);
+/* Backward of a Linear layer that needs no input gradient (the first layer) with the Adam update folded into the
+ * weight-gradient tiles: W, bias and their moments are updated in place from the tiles in the matrix-core accumulators, the
+ * gradient is never written (rows must be 32: one batch tile).  *step as in bridges_adam_step. */
+int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
+                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, const float* step,
+                                 float lr, float beta1, float beta2, float eps, void* stream);
 /* Input rows of replay batch *counter: x [rows, 4 px + nf] = [block | action | reward | obstacle | binary]
  * (cv.py:100-103) from block_all / action_all [n,px], binary_all [n,nf] (row *counter * batch + b), reward / obstacle [px]. */
 int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
@@ -317,7 +323,15 @@ int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const
 int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* y, const float* reward,
                            const int64_t* counter, const float* q_target_all, const float* sf_target_all, int32_t use_q,
                            int32_t use_sf, float* dy, float* loss_rows, float* q_out, float* losses, int32_t n_losses,
-                           int64_t* counter_inc, void* stream);
+                           int64_t* counter_inc, int32_t* ticket, float* adam_step, void* stream);
+/* `ticket` (device int32, zero before the first call; may be NULL): the logging (losses[*counter_inc] = sum of loss_rows,
+ * ++*counter_inc, and ++*adam_step if given) is done inside the loss kernel by the row workgroup that arrives last
+ * instead of a second launch; the kernel re-arms the ticket.
+ * One Adam step of torch.optim.Adam (successor_dqn.py:640; amsgrad / weight decay / maximize off) over a flat float32
+ * buffer of n parameters with their gradients and moments; *step (device float) is the step number of THIS update,
+ * already incremented by the caller. */
+int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
+                      float lr, float beta1, float beta2, float eps, void* stream);
 
 /* relu(conv3x3(x, w, padding 1) + bias) [then MaxPool2d(2)] for the 64-pixel-wide layers with 16 output channels of
  * the conv Q-networks (cv.py:5-17 ConvBlock(4,16) / (16,16); cv.py:138-254 UNet e11, e12, d41, d42), inference passes:

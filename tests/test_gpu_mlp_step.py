@@ -139,3 +139,61 @@ def test_three_adam_steps_follow_the_autograd_run():
     # the parameters of two correct float32 runs agree to ~lr * 1e-2 only, not to 1e-5 (the gradients themselves do)
     for pa, pb in zip(net_a.parameters(), net_b.parameters()):
         assert rel_err(pb.detach(), pa.detach()) < 2e-4
+
+
+def test_flat_adam_launch_follows_torch_adam():
+    """bridges_adam_step as the last launch of the sequence (FusedSuccessorStep(optimizer=...)): three optimiser steps
+    against torch.optim.Adam fed by autograd on an identically initialised net; the optimiser's own state tensors are the
+    flat moment buffers and export_state() hands the step count back."""
+    from bridges_hip.dqn_ops import FlatParameters
+    from bridges_hip.mlp_ops import FusedSuccessorStep
+    B, size = 32, 64
+    batch = make_batch(3 * B, size, seed=5)
+    block, action, binary, reward, obstacle, q_t, sf_t = batch
+    px = size * size
+    net_a, net_b = make_net(seed=9), make_net(seed=9)
+    net_b._flat_params = FlatParameters(net_b)
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-3, fused=True)
+    opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-3, fused=True)
+    for i in range(3):
+        autograd_step(net_a, batch, slice(i * B, (i + 1) * B), True, True)
+        opt_a.step()
+    fused = FusedSuccessorStep(net_b, B, True, True, optimizer=opt_b)
+    assert fused.fused_adam
+    counter = torch.zeros((), dtype=torch.int64, device=DEV)
+    losses_b = torch.zeros(3, device=DEV)
+    for i in range(3):
+        fused.launch(counter, block.reshape(-1, px), action.reshape(-1, px), binary, reward.reshape(px).contiguous(),
+                     obstacle.reshape(px).contiguous(), q_t, sf_t, losses_b)
+    assert int(counter) == 3 and float(fused.adam_step) == 3.0 and int(fused.ticket[0]) == 0
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert rel_err(pb.detach(), pa.detach()) < 2e-4
+        sa, sb = opt_a.state[pa], opt_b.state[pb]
+        assert rel_err(sb["exp_avg"], sa["exp_avg"]) < 1e-4 and rel_err(sb["exp_avg_sq"], sa["exp_avg_sq"]) < 1e-4
+    fused.export_state()
+    assert all(float(st["step"]) == 3.0 for st in opt_b.state.values())
+    # a fourth step by torch's own optimizer.step() continues from the exported state (same moments, step 4)
+    autograd_step(net_a, batch, slice(0, B), True, True)
+    opt_a.step()
+    for p in net_b.parameters():
+        p.grad = None
+    autograd_step(net_b, batch, slice(0, B), True, True)
+    opt_b.step()
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert rel_err(pb.detach(), pa.detach()) < 3e-4
+    # bridges_adam_step alone against torch's formula on random data (one step, t = 7)
+    from bridges_hip import abi
+    from bridges_hip.ops import _ptr, _stream
+    g = torch.Generator(device=DEV).manual_seed(1)
+    n = 4099
+    p0 = torch.randn(n + 1, device=DEV, generator=g)[:n].contiguous()
+    gr, m0 = torch.randn(n, device=DEV, generator=g), torch.randn(n, device=DEV, generator=g) * 0.1
+    v0 = torch.rand(n, device=DEV, generator=g) * 0.01
+    p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+    step = torch.full((), 7.0, device=DEV)
+    abi.check(abi.lib().bridges_adam_step(_ptr(p1), _ptr(gr), _ptr(m1), _ptr(v1), n, _ptr(step), 1e-3, 0.9, 0.999, 1e-8,
+                                          _stream()), "bridges_adam_step")
+    md = m0.double() + (gr.double() - m0.double()) * (1 - 0.9)
+    vd = 0.999 * v0.double() + (1 - 0.999) * gr.double() ** 2
+    pd = p0.double() - (1e-3 / (1 - 0.9 ** 7)) * md / (vd.sqrt() / (1 - 0.999 ** 7) ** 0.5 + 1e-8)
+    assert rel_err(m1, md.float()) < 1e-6 and rel_err(v1, vd.float()) < 1e-6 and rel_err(p1, pd.float()) < 1e-6

@@ -21,5 +21,5 @@ for mode in "$@"; do
   f=$(find $out -name "*kernel_stats.csv" | head -1)
   echo "== $mode: $f"; head -12 $f | cut -c1-200
   # keep the summaries, drop the raw trace (large)
-  find $out -name "*kernel_trace.csv" -size +20M -delete
+  true
 done
