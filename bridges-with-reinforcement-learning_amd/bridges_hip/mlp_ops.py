@@ -144,7 +144,9 @@ class FusedSuccessorStep:
                                   opt.state[lin.bias]["exp_avg"], opt.state[lin.bias]["exp_avg_sq"]))
         covered = sorted(self._slices)
         assert all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), "layer ranges of the flat buffer overlap"
-        self.side = torch.cuda.Stream(device=self.flat.device)
+        # everything behind the first layer's range: the other layers (and padding, whose gradients and moments stay 0)
+        first = self._slices[0]
+        self._rest = (first[1], self.flat.numel()) if first == covered[0] and first[0] == 0 and self.flat.numel() % 4 == 0 else None
         self.optimizer, self.fused_adam = opt, True
 
     def export_state(self):
@@ -177,16 +179,21 @@ class FusedSuccessorStep:
                                            _ptr(self.dz[-1]), _ptr(self.loss_rows), _ptr(self.q), _ptr(losses),
                                            losses.numel(), _ptr(counter), _ptr(self.ticket),
                                            _ptr(self.adam_step) if self.fused_adam else None, st), "bridges_successor_loss")
-        cur = torch.cuda.current_stream()
-        fold_first = self.fused_adam and rows == 32
+        # the whole optimiser update rides in the LAST backward launch (the first layer's, which has no input gradient):
+        # Adam goes into its weight-gradient tiles and extra workgroups of that launch update the other layers, whose
+        # gradients are complete and whose weights nothing reads any more.  (Adam launches on a parallel branch of the
+        # captured graph were measured: every cross-branch edge costs ~20 us, 245 us per step against 155.)
+        fold_first = self.fused_adam and rows == 32 and self._rest is not None
         for l in range(last, -1, -1):
             lin = self.linears[l]
             if l == 0 and fold_first:
-                # the first layer has no input gradient: Adam goes into its weight-gradient tiles, no gradient is written
                 mw, vw, mb, vb = self._moments[0]
+                lo, hi = self._rest
+                off = lambda t: C.c_void_p(t.data_ptr() + 4 * lo)
                 abi.check(L.bridges_linear_backward_adam(rows, lin.in_features, lin.out_features, _ptr(self.dz[0]), _ptr(self.acts[0]),
                                                          _ptr(lin.weight), _ptr(lin.bias), _ptr(mw), _ptr(vw), _ptr(mb), _ptr(vb),
-                                                         _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),
+                                                         off(self.flat), off(self.grad_flat), off(self.m_flat), off(self.v_flat),
+                                                         hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),
                           "bridges_linear_backward_adam")
                 continue
             abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]), _ptr(self.acts[l]),
@@ -194,15 +201,7 @@ class FusedSuccessorStep:
                                                 _ptr(self.acts[l]) if l > 0 else None,
                                                 _ptr(self.dz[l - 1]) if l > 0 else None, _ptr(self.ws), self.ws.numel(), st),
                       "bridges_linear_backward")
-            if self.fused_adam:
-                # this layer's weights are not read again in the step: its Adam update runs on a side stream beside the
-                # backward launches of the layers below (a parallel branch of the captured graph)
-                lo, hi = self._slices[l]
-                self.side.wait_stream(cur)
-                with torch.cuda.stream(self.side):
-                    abi.check(L.bridges_adam_step(C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad_flat.data_ptr() + 4 * lo),
-                                                  C.c_void_p(self.m_flat.data_ptr() + 4 * lo), C.c_void_p(self.v_flat.data_ptr() + 4 * lo),
-                                                  hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, _stream()),
-                              "bridges_adam_step")
-        if self.fused_adam:
-            cur.wait_stream(self.side)
+        if self.fused_adam and not fold_first:               # larger batches: one flat launch behind the backward pass
+            abi.check(L.bridges_adam_step(_ptr(self.flat), _ptr(self.grad_flat), _ptr(self.m_flat), _ptr(self.v_flat),
+                                          self.flat.numel(), _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),
+                      "bridges_adam_step")

@@ -604,18 +604,27 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
 }
 
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
-                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, const float* step,
-                                 float lr, float beta1, float beta2, float eps, void* stream) {
+                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
+                                 const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
+                                 double lr, double beta1, double beta2, double eps, void* stream) {
     if (rows != 32 || K <= 0 || N <= 0 || !dz || !a_in || !W || !bias || !exp_avg_w || !exp_avg_sq_w || !exp_avg_b || !exp_avg_sq_b || !step)
         return fail_arg("bridges_linear_backward_adam: one 32-row batch tile, all buffers given");
-    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return fail_arg("bridges_linear_backward_adam: hyper-parameters");
+    if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail_arg("bridges_linear_backward_adam: hyper-parameters");
+    if (rest_n < 0 || (rest_n & 3) || (rest_n > 0 && (!rest_param || !rest_grad || !rest_exp_avg || !rest_exp_avg_sq)))
+        return fail_arg("bridges_linear_backward_adam: rest range must be a multiple of 4 floats with all four buffers");
+    if (rest_n > 0 && ((((uintptr_t)rest_param) | ((uintptr_t)rest_grad) | ((uintptr_t)rest_exp_avg) | ((uintptr_t)rest_exp_avg_sq)) & 15))
+        return fail_arg("bridges_linear_backward_adam: rest buffers must be 16-byte aligned");
     const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32);
     int per_job = ceil_div(n_ntiles * n_ktiles, 1024);
     if (per_job < 4) per_job = 4;
     const int n_dw_jobs = n_ntiles * ceil_div(n_ktiles, per_job);
-    AdamFold ad{W, bias, exp_avg_w, exp_avg_sq_w, exp_avg_b, exp_avg_sq_b, step, lr, beta1, beta2, eps};
-    hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in, (const float*)W,
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job, 0, 0, ad);
+    int64_t rest_jobs = ((rest_n >> 2) + 255) / 256;
+    if (rest_jobs > 1024) rest_jobs = 1024;
+    AdamFold ad{W, bias, exp_avg_w, exp_avg_sq_w, exp_avg_b, exp_avg_sq_b, step, lr, beta1, beta2, eps,
+                rest_param, rest_grad, rest_exp_avg, rest_exp_avg_sq, (long long)rest_n};
+    hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
+                       (const float*)W, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job,
+                       0, 0, ad);
     LAUNCH_CHECK("k_lin_bwd<adam>");
     return BRIDGES_OK;
 }
@@ -656,11 +665,11 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
 }
 
 int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
-                      float lr, float beta1, float beta2, float eps, void* stream) {
+                      double lr, double beta1, double beta2, double eps, void* stream) {
     if (n < 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step) return fail_arg("bridges_adam_step");
     if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15)
         return fail_arg("bridges_adam_step: buffers must be 16-byte aligned");
-    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f)) return fail_arg("bridges_adam_step: hyper-parameters");
+    if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail_arg("bridges_adam_step: hyper-parameters");
     if (n == 0) return BRIDGES_OK;
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;

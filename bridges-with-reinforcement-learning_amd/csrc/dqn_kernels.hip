@@ -32,12 +32,14 @@ __global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ target,
 // 7 x 4 B of traffic per parameter (torch's multi-tensor launch moves the same bytes at ~3.9 TB/s: 46 us for the 6.4 M
 // parameters of SuccessorMLP; this launch streams them in one grid).
 __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, const float* __restrict__ step, float lr,
-                                                   float beta1, float beta2, float eps) {
+                                                   float* __restrict__ v, int64_t n, const float* __restrict__ step, double lr,
+                                                   double beta1_d, double beta2_d, double eps_d) {
+    // every coefficient is formed in float64 from the optimiser's float64 hyper-parameters and rounded once (1 - 0.999f is
+    // off by 5e-5 relative, which would show in v)
     const double t = (double)*step;
-    const float step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
-    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    const float step_size = (float)(lr / (1.0 - pow(beta1_d, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, t));
+    const float w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d), beta2 = (float)beta2_d, eps = (float)eps_d;
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float4* p4 = reinterpret_cast<float4*>(p);

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void k_lin_fwd_finish(int rows, int N, int spl
 struct AdamFold {
     float* W; float* bias; float* mW; float* vW; float* mb; float* vb;
     const float* step;                  // device float: number of THIS update (already incremented)
-    float lr, beta1, beta2, eps;
+    double lr, beta1, beta2, eps;
+    // the other layers' parameters (one contiguous range of the flat buffers): updated by extra workgroups of the same
+    // launch -- when the first layer's backward runs, every other gradient is complete and nothing reads those weights
+    // any more, so the whole optimiser update rides in the last launch of the step
+    float* rest_p; const float* rest_g; float* rest_m; float* rest_v; long long rest_n;
 };
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, float beta2,
                                          float w1, float w2, float eps) {
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
             float step_size = 0.f, bc2_sqrt = 1.f, w1 = 0.f, w2 = 0.f;
             if constexpr (ADAM) {
                 const double t = (double)*ad.step;
-                step_size = (float)((double)ad.lr / (1.0 - pow((double)ad.beta1, t)));
-                bc2_sqrt = (float)sqrt(1.0 - pow((double)ad.beta2, t));
-                w1 = 1.f - ad.beta1; w2 = 1.f - ad.beta2;
+                step_size = (float)(ad.lr / (1.0 - pow(ad.beta1, t)));
+                bc2_sqrt = (float)sqrt(1.0 - pow(ad.beta2, t));
+                w1 = (float)(1.0 - ad.beta1); w2 = (float)(1.0 - ad.beta2);
             }
             if (want_db) {
                 float sdb = 0.f;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
                     if constexpr (ADAM) {
                         const int o = n0 + row;
                         float pb = ad.bias[o], mb = ad.mb[o], vb = ad.vb[o];
-                        adam_one(pb, sdb, mb, vb, step_size, bc2_sqrt, ad.beta2, w1, w2, ad.eps);
+                        adam_one(pb, sdb, mb, vb, step_size, bc2_sqrt, (float)ad.beta2, w1, w2, (float)ad.eps);
                         ad.bias[o] = pb; ad.mb[o] = mb; ad.vb[o] = vb;
                     } else {
                         db[n0 + row] = sdb;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
                             const int n = n0 + mfma_row(r, lane);
                             if (n < N) {
                                 const size_t o = (size_t)n * K + k;
-                                adam_one(pw[r], acc[r], pm[r], pv[r], step_size, bc2_sqrt, ad.beta2, w1, w2, ad.eps);
+                                adam_one(pw[r], acc[r], pm[r], pv[r], step_size, bc2_sqrt, (float)ad.beta2, w1, w2, (float)ad.eps);
                                 ad.W[o] = pw[r]; ad.mW[o] = pm[r]; ad.vW[o] = pv[r];
                             }
                         }
@@ -290,6 +294,27 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
         return;
     }
     job -= n_dw_jobs;
+    if constexpr (ADAM) {                                          // flat Adam over the other layers' range
+        const double t = (double)*ad.step;
+        const float step_size = (float)(ad.lr / (1.0 - pow(ad.beta1, t)));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(ad.beta2, t));
+        const float w1 = (float)(1.0 - ad.beta1), w2 = (float)(1.0 - ad.beta2), b2 = (float)ad.beta2, eps = (float)ad.eps;
+        const long long n4 = ad.rest_n >> 2;                       // the range is padded to whole float4s
+        const long long stride = (long long)(gridDim.x - n_dw_jobs) * blockDim.x;
+        float4* p4 = reinterpret_cast<float4*>(ad.rest_p);
+        const float4* g4 = reinterpret_cast<const float4*>(ad.rest_g);
+        float4* m4 = reinterpret_cast<float4*>(ad.rest_m);
+        float4* v4 = reinterpret_cast<float4*>(ad.rest_v);
+        for (long long i = (long long)job * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+            adam_one(pp.x, gg.x, mm.x, vv.x, step_size, bc2_sqrt, b2, w1, w2, eps);
+            adam_one(pp.y, gg.y, mm.y, vv.y, step_size, bc2_sqrt, b2, w1, w2, eps);
+            adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, b2, w1, w2, eps);
+            adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, b2, w1, w2, eps);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        return;
+    }
     const int kt = job % n_ktiles, split = (job / n_ktiles) % nsplit, mt = job / (n_ktiles * nsplit);
     const int k0 = kt * 32, m0 = mt * 32;
     const int kcol = (k0 + row < K) ? k0 + row : K - 1;

@@ -304,12 +304,15 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
                             void* stream);
-/* Backward of a Linear layer that needs no input gradient (the first layer) with the Adam update folded into the
- * weight-gradient tiles: W, bias and their moments are updated in place from the tiles in the matrix-core accumulators, the
- * gradient is never written (rows must be 32: one batch tile).  *step as in bridges_adam_step. */
+/* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
+ * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
+ * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further
+ * parameters (the other layers: one contiguous, 16-byte-aligned range of flat parameter / gradient / moment buffers, rest_n
+ * a multiple of 4; 0 = none) -- valid because this is the last backward launch of a step.  *step as in bridges_adam_step. */
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
-                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, const float* step,
-                                 float lr, float beta1, float beta2, float eps, void* stream);
+                                 float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
+                                 const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
+                                 double lr, double beta1, double beta2, double eps, void* stream);
 /* Input rows of replay batch *counter: x [rows, 4 px + nf] = [block | action | reward | obstacle | binary]
  * (cv.py:100-103) from block_all / action_all [n,px], binary_all [n,nf] (row *counter * batch + b), reward / obstacle [px]. */
 int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
@@ -331,7 +334,7 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
  * buffer of n parameters with their gradients and moments; *step (device float) is the step number of THIS update,
  * already incremented by the caller. */
 int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
-                      float lr, float beta1, float beta2, float eps, void* stream);
+                      double lr, double beta1, double beta2, double eps, void* stream);
 
 /* relu(conv3x3(x, w, padding 1) + bias) [then MaxPool2d(2)] for the 64-pixel-wide layers with 16 output channels of
  * the conv Q-networks (cv.py:5-17 ConvBlock(4,16) / (16,16); cv.py:138-254 UNet e11, e12, d41, d42), inference passes:

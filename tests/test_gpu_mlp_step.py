@@ -196,4 +196,4 @@ def test_flat_adam_launch_follows_torch_adam():
     md = m0.double() + (gr.double() - m0.double()) * (1 - 0.9)
     vd = 0.999 * v0.double() + (1 - 0.999) * gr.double() ** 2
     pd = p0.double() - (1e-3 / (1 - 0.9 ** 7)) * md / (vd.sqrt() / (1 - 0.999 ** 7) ** 0.5 + 1e-8)
-    assert rel_err(m1, md.float()) < 1e-6 and rel_err(v1, vd.float()) < 1e-6 and rel_err(p1, pd.float()) < 1e-6
+    assert rel_err(m1, md.float()) < 1e-6 and rel_err(v1, vd.float()) < 1e-6 and rel_err(p1, pd.float()) < 2e-6

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--replays", type=int, default=400)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="hand-written step + torch's fused Adam launch (the round-2 step)")
     args = ap.parse_args()
     from bridges_hip.mlp_ops import FusedSuccessorStep
     from robotoddler.models.cv import SuccessorMLP
@@ -58,12 +59,14 @@ def main():
     if args.autograd:
         body = autograd_body
     else:
-        step = FusedSuccessorStep(net, B, True, True)
+        from bridges_hip.dqn_ops import FlatParameters
+        net._flat_params = FlatParameters(net)
+        step = FusedSuccessorStep(net, B, True, True, optimizer=None if (args.torch_adam or args.no_adam) else opt)
         rw, ob = reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous()
 
         def body():
             step.launch(counter, block.view(n, px), action.view(n, px), binary, rw, ob, q_t, sf_t, losses)
-            if not args.no_adam:
+            if not args.no_adam and not step.fused_adam:
                 opt.step()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -86,7 +89,8 @@ def main():
         graph.replay()
     b.record()
     torch.cuda.synchronize()
-    print(f"{'autograd' if args.autograd else 'hand-written'} step{'' if not args.no_adam else ' (no Adam)'}: "
+    kind = "autograd" if args.autograd else ("hand-written + torch Adam" if args.torch_adam else "hand-written incl. Adam")
+    print(f"{kind} step{'' if not args.no_adam else ' (no Adam)'}: "
           f"{a.elapsed_time(b) / args.replays * 1e3:.1f} us per optimiser step (batch {B})", flush=True)
 
 

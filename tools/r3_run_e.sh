@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+out=gpurun_out/r3e
+mkdir -p $out
+timeout -k 10 900 python -m pytest tests/test_gpu_mlp_step.py tests/test_gpu_vec_dqn.py tests/test_gpu_dqn.py -m gpu -x -q > $out/tests.log 2>&1; rc=$?
+tail -8 $out/tests.log
+[ $rc -eq 0 ] || exit $rc
+for f in "" "--torch-adam" "--no-adam"; do timeout -k 10 300 python tools/mlp_step_bench.py --replays 200 $f >> $out/mlp_step.txt 2>&1; done; grep "per optimiser" $out/mlp_step.txt
+for i in 1 2; do
+timeout -k 10 300 python tools/train_throughput.py --envs 4096 --tower 4 --max_steps 15 --model SuccessorMLP --loss mse_block_features --locksteps 12 --warmup 6 2>$out/train.err | grep "^{" > $out/train_$i.json; cat $out/train_$i.json
+done
