@@ -33,7 +33,7 @@ IMG = 64
 FLAG_NAMES = ("valid_step", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",
               "no_actions", "lp_error")
 STAT_NAMES = ("sum_cand", "sum_blocks", "env_steps", "reset_only", "lp_errors", "if_overflow", "locksteps",
-              "sum_valid")
+              "sum_valid", "warm_resolved")
 
 
 class BridgesHipError(RuntimeError):

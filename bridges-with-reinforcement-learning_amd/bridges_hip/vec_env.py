@@ -156,7 +156,7 @@ class VecAssemblyGym:
         for name, dt, shape in abi.ENV_BUFFER_FIELDS_TAIL:
             shp = tuple(dims[s] if s in dims else int(s) for s in shape.split(","))
             self.buf[name] = torch.zeros(shp, dtype=getattr(torch, dt), device=self.device)
-        self.stats = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.stats = torch.zeros(16, dtype=torch.int64, device=self.device)
         self.lp_snap = (torch.zeros((E, abi.ENV_LP_SNAP_DOUBLES), dtype=torch.float64, device=self.device)
                         if self.candidate_snapshots else None)
         for k, v in self.buf.items():
@@ -374,7 +374,10 @@ class VecAssemblyGym:
     # ------------------------------------------------------------------ views
     def flags(self):
         f = self.buf["step_flags"]
-        return {n: f[:, i].bool() for i, n in enumerate(abi.FLAG_NAMES)}
+        out = {n: f[:, i].bool() for i, n in enumerate(abi.FLAG_NAMES)}
+        out["lp_error"] = (f[:, 7] & 3) != 0                    # bit 0 solver error, bit 1 contact-list overflow
+        out["warm_resolved"] = (f[:, 7] & 4) != 0               # a continued tableau's marginal 'unstable' was re-solved cold
+        return out
 
     def binary_features(self):
         """get_state_features' binary vector [stable, collision x5] (successor_dqn.py:53-60).  The vector of the

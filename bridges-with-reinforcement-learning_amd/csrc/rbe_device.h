@@ -37,6 +37,8 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_STALL 40           // degenerate pivots before Bland's rule takes over
 #define LP_MAX_PIVOTS 5000
 #define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
+#define LP_MARGIN 1e3         // a continued (warm) tableau's "infeasible" optimum below LP_MARGIN x the threshold is solved again from
+                              // scratch before it is reported (observed optima: <= 3.5e-7 feasible, >= 7.8e-4 infeasible; threshold 1e-5)
 #define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
                               // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
 #ifndef LP_TAB_LDS
@@ -836,13 +838,18 @@ __device__ inline void lp_warm_store(const double* T, int stride, int m, int n_g
 template <bool IN_LDS, typename TP>
 __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S, const AsmView& A, double mu, double density,
                                     int lane, bool warm, bool* st_frozen, bool* st_free, bool* error, int* pivots,
-                                    double* snap) {
+                                    double* snap, bool* marginal) {
     const int m_act = m - 3;
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
+    // an "infeasible" optimum within a factor LP_MARGIN of the threshold is the one verdict a continued tableau could owe
+    // to accumulated round-off (a "feasible" one is re-checked on the original rows): the caller re-solves it from scratch
+    const double near = LP_MARGIN * feas;
+    *marginal = false;
     if (!warm) lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane, m);
     int& piv = *pivots;
     double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, !warm, feas, m);
     *st_frozen = w <= feas;
+    if (w > feas && w < near) *marginal = true;
     if (*st_frozen && m_act > 0 && lp_verify(T, stride, m, m_act, n, S, A, mu, density, lane) > vtol) {
         *st_frozen = false;                 // the verdict does not survive the check on the original rows
         *error = true;
@@ -863,6 +870,7 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
     lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane, m);
     w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas, m);
     *st_free = w <= feas;
+    if (w > feas && w < near) *marginal = true;
     if (*st_free && lp_verify(T, stride, m, m, n, S, A, mu, density, lane) > vtol) {
         *st_free = false;
         *error = true;
@@ -874,7 +882,7 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
 // persisting the result there when `keep`.  *warm_used reports which path produced the verdict.
 __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_t ws_cap, LpScratch& S, const AsmView& A, int n_if_old,
                                 const WarmPre& W, double mu, double density, int lane, bool* st_frozen, bool* st_free,
-                                bool* error, bool* warm_used, int* diag = nullptr, double* snap = nullptr) {
+                                bool* error, bool* warm_used, int* diag = nullptr, double* snap = nullptr, bool* resolved = nullptr) {
     WarmHdr* hdr = reinterpret_cast<WarmHdr*>(ws);
     double* halves = ws + WARM_HDR_DOUBLES;
     *warm_used = false;
@@ -910,11 +918,14 @@ __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_
             if (in_lds) lp_warm_prepare<true>(tab_lds, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
             else lp_warm_prepare<false>(Tg, stride, m, n, src, stride_o, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
         }
-        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap);
-        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap);
+        bool marginal = false;
+        if (in_lds) rbe_both_run<true>(tab_lds, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap, &marginal);
+        else rbe_both_run<false>(Tg, stride, m, n, S, A, mu, density, lane, warm, st_frozen, st_free, &err, &pivots, snap, &marginal);
         if (diag) *diag = pivots * 4 + (in_lds ? 0 : 2) + attempt;     // pivots, global-memory tableau, second attempt
-        if (!(warm && err)) { *error = err; *warm_used = warm; break; }
-        warm = false;                                  // the continued tableau failed its check: solve from scratch
+        if (!(warm && (err || marginal))) { *error = err; *warm_used = warm; break; }
+        if (resolved) *resolved = true;
+        warm = false;                                  // the continued tableau failed its check, or reported "unstable" by a
+                                                       // margin round-off could explain: solve from scratch
         lp_row_map(S, all, lane);
     }
     __syncthreads();
@@ -954,6 +965,7 @@ __device__ inline bool rbe_candidate_warm(double* tab_lds, int lds_cap, int max_
     lp_activate_rows<true>(tab_lds, stride, m, m - 3, n, S, lane, m, grp);
     const double w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots, error, false, feas, m, grp);
     bool stable = w <= feas;
+    if (w > feas && w < LP_MARGIN * feas) *error = true;       // marginal "unstable" of a continued tableau: the caller re-solves cold
     if (stable && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane, grp) > vtol) { *error = true; stable = false; }
     return stable;
 }

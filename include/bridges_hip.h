@@ -109,7 +109,9 @@ typedef struct {
     uint8_t* needs_reset;      /* [E] */
     /* --- per-step results --- */
     int32_t* sel_index;        /* [E] in: candidate to place */
-    uint8_t* step_flags;       /* [E,8] valid_step, stable_frozen, stable_unfrozen, terminated, truncated, done, no_actions, lp_error */
+    uint8_t* step_flags;       /* [E,8] valid_step, stable_frozen, stable_unfrozen, terminated, truncated, done, no_actions,
+                                  lp_error (bit 0 solver error, bit 1 contact-list overflow; bit 2 is not an error: the step's
+                                  continued tableau said 'unstable' by a small margin and was solved again from scratch) */
     float* reward;             /* [E] sparse_reward (gym_env.py:11-22) */
     float* lin_reward;         /* [E] successor_dqn.py:397-401 */
     int32_t* n_reached;        /* [E] */
@@ -143,7 +145,8 @@ typedef struct {
     double* lp_ws;             /* [E, lp_ws_stride] per-env persistent simplex tableau (incremental solve of bridges_env_step):
                                   header + basis + two tableau halves; owned by the library between reset and step calls */
     int64_t lp_ws_stride;      /* >= BRIDGES_LP_WS_DOUBLES */
-    uint64_t* stats;           /* [8] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps */
+    uint64_t* stats;           /* [16] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps,
+                                  sum n_valid, continued (warm) 'unstable' verdicts solved again from scratch; rest reserved */
     /* --- candidate stability (bridges_env_candidate_stability; all three may be NULL if it is never called) --- */
     uint8_t* cand_stable;      /* [C] 1 = stable, 0 = unstable or masked-out candidate, 2 = solver error / contact overflow */
     int32_t* cand_queue;       /* [C] scratch: candidates whose tableau needs the large workspace */

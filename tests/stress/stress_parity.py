@@ -27,7 +27,7 @@ vec = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], set
                      max_steps=max_steps, seed=a.seed, mu=mu, f32_rasters=False)
 gym = OracleGym(**setup, max_steps=max_steps, mu=mu)
 cenvs = [CEnv(gym) for _ in range(a.envs)]
-t0 = time.time(); steps = lps = 0; mism = 0
+t0 = time.time(); steps = lps = 0; mism = 0; resolved = 0
 for it in range(a.locksteps):
     vec.select_random()
     sel = vec.sel_index.cpu().numpy()
@@ -39,8 +39,9 @@ for it in range(a.locksteps):
         ok = bool(fl[e, 0]) == bool(o.valid_step) and bool(fl[e, 6]) == bool(o.no_actions)
         if o.valid_step:
             steps += 1; lps += 2
+            resolved += int(fl[e, 7] >> 2) & 1            # a warm 'unstable' by a small margin was solved again from scratch
             ok = ok and sel[e] == o.action_index and fl[e, 1] == o.stable_frozen and fl[e, 2] == o.stable_unfrozen \
-                and fl[e, 3] == o.terminated and fl[e, 4] == o.truncated and rew[e] == o.reward and fl[e, 7] == 0
+                and fl[e, 3] == o.terminated and fl[e, 4] == o.truncated and rew[e] == o.reward and (fl[e, 7] & 3) == 0
         n_c, n_v = (lambda p: (p[0], p[1]))((lambda: (lambda c: (len(c[0]), c[1]))(ce.candidates()))()) if it % 10 == 0 else (ncand[e], nval[e])
         ok = ok and n_c == ncand[e] and n_v == nval[e]
         if it % 10 == 0:
@@ -51,5 +52,5 @@ for it in range(a.locksteps):
             if mism > 10: sys.exit(1)
     if it % 10 == 9:
         print(f"lock-step {it + 1}: {steps} env-steps compared, {mism} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(f"RESULT task={a.task} envs={a.envs} locksteps={a.locksteps}: {steps} env-steps ({lps} stability decisions) compared, {mism} mismatches")
+print(f"RESULT task={a.task} envs={a.envs} locksteps={a.locksteps}: {steps} env-steps ({lps} stability decisions) compared, {mism} mismatches, {resolved} marginal warm verdicts re-solved from scratch")
 sys.exit(1 if mism else 0)

@@ -1,4 +1,5 @@
-"""Where a k_step workgroup spends its time: per-env phase stamps (debug bit3, 100 MHz wall clock) of one lock-step."""
+"""Where a k_step workgroup spends its time: per-env phase stamps (debug bit3, 100 MHz wall clock) of one lock-step.
+Needs the diagnostic build: tools/build_diag.sh, then BRIDGES_LIB=tools/libbridges_hip_diag.so python tools/kstep_phases.py."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
