@@ -27,23 +27,31 @@ def is_stable_rbe(assembly_env):
 
 
 def is_stable_rbe_penalty(assembly_env, tol=1e-3):
-    """(stable, {'max_tension': ...}) as stability.py:75-88.  ``max_tension`` is the largest net tension of a contact
-    point in the equilibrium found (<= tol by construction) or None when no equilibrium within the tolerance exists --
-    the reference reports the tension of its penalty optimum there, which this feasibility formulation does not produce."""
+    """(stable, {'max_tension': ...}) as stability.py:75-88; an assembly without any contact returns (no free block, None)
+    like the reference (:77-81).  PARITY UNPINNED -- the reference holds no output of this variant -- and not the same
+    predicate near the threshold: the reference solves the penalty QP and tests the LARGEST per-point tension of that one
+    optimum against tol; this build asks whether an equilibrium whose TOTAL tension is <= tol exists (a feasibility
+    question the same simplex answers).  Total <= tol implies every point <= tol, so a True here is an equilibrium the
+    reference's test would accept; several points pulling a little each (each <= tol, sum > tol) pass there and fail here.
+    ``max_tension`` is the largest net tension of a contact point in the equilibrium found, or None when none exists within
+    the tolerance (the reference reports the tension of its penalty optimum there, which a feasibility solve does not have)."""
     from assembly_gym.utils.geometry import maximum_tension
     stable, info = ops.stability(assembly_env.blocks, _fixed(assembly_env), assembly_env.mu, assembly_env.density,
                                  assembly_env.floor_half_width, assembly_env.floor_depth, tension_tol=tol)
     if stable is None:
         return None, info
+    if info.get("n_interfaces", 0) == 0:                 # no edges: (no free node, None), stability.py:77-81
+        return stable, None
     return stable, {'max_tension': maximum_tension(info["forces"]) if stable else None}
 
 
 def is_stable_cra(assembly_env):
-    raise NotImplementedError("compas_cra's CRA solve (stability.py:91-104) is not part of this build: see the module docstring")
+    raise NotImplementedError("compas_cra's CRA solve (stability.py:91-104) is out of scope of this build (DESIGN.md section 9: non-convex "
+                              "program of an un-pinned fork, no recorded output to pin a restatement to)")
 
 
 def is_stable_cra_penalty(assembly_env, tol=1e-3):
-    raise NotImplementedError("compas_cra's CRA penalty solve (stability.py:106-119) is not part of this build: see the module docstring")
+    raise NotImplementedError("compas_cra's CRA penalty solve (stability.py:106-119) is out of scope of this build (DESIGN.md section 9)")
 
 
 def is_action_stable_rbe(gym_env, action):

@@ -291,10 +291,8 @@ int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (est < c.E) est = c.E;
     est += est / 32 + 64;
     if (est > env->max_blocks) est = env->max_blocks;
-    // first pass: two candidates per wave (each 32-lane half its own LP); whatever needs more than 32 tableau rows or a
-    // larger tableau is queued for the second pass
-    hipLaunchKernelGGL((k_candidate_stability_pair<CS_TAB_SMALL, CS_COLS_SMALL>), dim3((unsigned)((est + 1) / 2)), dim3(WAVE), 0, s, c);
-    LAUNCH_CHECK("k_candidate_stability_pair");
+    hipLaunchKernelGGL((k_candidate_stability<CS_TAB_SMALL, CS_COLS_SMALL, false>), dim3((unsigned)est), dim3(WAVE), 0, s, c);
+    LAUNCH_CHECK("k_candidate_stability");
     const int drain = BRIDGES_CAND_WS_SLOTS;          // one cand_ws slot per workgroup
     hipLaunchKernelGGL((k_candidate_stability<CS_TAB_LARGE, LP_MAX_COLS, true>), dim3(drain), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_candidate_stability (queue)");

@@ -117,9 +117,15 @@ __device__ __forceinline__ double readlane_d(double v, int lane_uniform) {
     return readlane_d(v, 63);
 
 __device__ __forceinline__ double add_d_(double a, double b) { return a + b; }
+// v_min_f64 / v_max_f64 as they are: fmin / fmax make the compiler quiet both operands first (two v_max_f64 x, x per call --
+// the operands come out of integer DPP moves, so it cannot know they are not signalling NaNs), which tripled every step of
+// the reductions the simplex pivots on.  The reduced values are never NaN.  The s_nop covers the two wait states a DPP
+// read of the result needs (the next reduction step): the hazard pass does not look into inline assembly.
+__device__ __forceinline__ double min_raw_d(double a, double b) { double r; asm volatile("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_raw_d(double a, double b) { double r; asm volatile("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double wave_sum_d(double v) { WAVE_REDUCE_D(add_d_, 0.0) }
-__device__ __forceinline__ double wave_min_d(double v) { WAVE_REDUCE_D(fmin, v) }
-__device__ __forceinline__ double wave_max_d(double v) { WAVE_REDUCE_D(fmax, v) }
+__device__ __forceinline__ double wave_min_d(double v) { WAVE_REDUCE_D(min_raw_d, v) }
+__device__ __forceinline__ double wave_max_d(double v) { WAVE_REDUCE_D(max_raw_d, v) }
 __device__ __forceinline__ int wave_min_i(int v) {
     v = min(v, dpp_i<DPP_QUAD_XOR1, 0xF>(v, v));
     v = min(v, dpp_i<DPP_QUAD_XOR2, 0xF>(v, v));

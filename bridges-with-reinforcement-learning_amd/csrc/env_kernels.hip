@@ -635,15 +635,17 @@ __device__ __forceinline__ uint64_t raster_rows_nv(double fr0, double fr1, doubl
 
 // sum(raster * reward_map) from the row runs: the pixels of a row of a convex outline are one run [lo, hi), so the
 // row's sum is prefix[r][hi] - prefix[r][lo] on the float64 row prefix sums of the reward map (reward_prefix, [64][65]).
-__device__ __forceinline__ double raster_reward(uint64_t rowbits, const double* prefix, int lane) {
-    double v = 0.0;
+// Two steps, so that the caller can put the image's 16 KiB of stores between the two gathers and their use (the loads
+// are in flight under the stores instead of in front of them).
+__device__ __forceinline__ void raster_reward_fetch(uint64_t rowbits, const double* prefix, int lane, double& p_hi, double& p_lo) {
+    p_hi = 0.0; p_lo = 0.0;
     if (rowbits) {
         const int lo = __builtin_ctzll(rowbits), hi = 64 - __builtin_clzll(rowbits);
         const double* p = prefix + lane * (IMG + 1);
-        v = p[hi] - p[lo];
+        p_hi = p[hi]; p_lo = p[lo];
     }
-    return wave_sum_d(v);
 }
+__device__ __forceinline__ double raster_reward_sum(double p_hi, double p_lo) { return wave_sum_d(p_hi - p_lo); }
 
 // Same from world vertices (stand-alone operator): frames are derived first (oracle/raster.py contains_2d).
 __device__ __forceinline__ uint64_t raster_outline(const double* v /*[6,2]*/, int nv, const int32_t* fa,
@@ -694,14 +696,16 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
             if (!DIAG(c, 2)) bits = (NF == 4 || nv <= 4) ? raster_rows<4>(fr0, fr1, fr2, fr3, c.img, X, Y, lane)
                                                          : raster_rows<MAXV>(fr0, fr1, fr2, fr3, c.img, X, Y, lane);
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
-            const double lin = raster_reward(bits, c.b.reward_prefix, lane);
+            double p_hi, p_lo;
+            raster_reward_fetch(bits, c.b.reward_prefix, lane, p_hi, p_lo);
             c.b.cand_bits[ci * IMG + lane] = bits;
+            if (c.b.cand_raster && !DIAG(c, 4))
+                write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane, c.b.cand_raster_nz ? c.b.cand_raster_nz + ci : nullptr);
+            const double lin = raster_reward_sum(p_hi, p_lo);
             if (lane == 0) {
                 c.b.cand_lin[ci] = (float)lin;
                 c.b.cand_mask[ci] = (uint8_t)(inb && !overlap);
             }
-            if (c.b.cand_raster && !DIAG(c, 4))
-                write_f32_image(c.b.cand_raster + ci * IMG * IMG, bits, lane, c.b.cand_raster_nz ? c.b.cand_raster_nz + ci : nullptr);
         } else {
             const int e = it - total;
             write_f32_image(c.b.state_raster + (size_t)e * IMG * IMG, c.b.state_bits[(size_t)e * IMG + lane], lane,
@@ -899,132 +903,6 @@ __global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
                     }
                     err = true;
                 }
-            }
-            res = err ? 2 : (st ? 1 : 0);
-        }
-        if (lane == 0) c.b.cand_stable[ci] = res;
-    }
-}
-
-// The first pass of bridges_env_candidate_stability with TWO candidates per wave: each 32-lane half (GrpHalf, rbe_device.h)
-// takes its own candidate -- detection of its contacts, continuation of the env's snapshot tableau, simplex, check -- in its
-// own LDS tableau, the halves diverging freely.  A pivot costs the same ~750 wave instructions whatever the tableau size
-// and the kernel is bound by instruction issue, so on the typical candidate (tableau of <= 32 rows, a few dozen columns,
-// more than half of a wave's lanes idle in every step) two LPs per wave nearly halve the instructions per decision.
-// Candidates whose tableau has more than 32 rows or does not fit TAB doubles go to the queue of the second pass (one LP per
-// wave, large LDS tableau), exactly like the candidates that did not fit before.  Same decisions as the one-per-wave
-// kernel: every pivot choice is a total order within the LP (tests/test_gpu_env_parity.py, stress_candidate_stability.py).
-template <int TAB, int MAXCOLS>
-__global__ __launch_bounds__(WAVE) void k_candidate_stability_pair(DevCtx c) {
-    __shared__ __attribute__((aligned(16))) double tab2[2][TAB];
-    __shared__ LpScratchT<MAXCOLS> S2[2];
-    __shared__ double new_geom2[2][CS_NEW_IF * 8];
-    __shared__ int32_t new_body2[2][CS_NEW_IF * 2];
-    typedef GrpHalf G;
-    const int half = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    double* tab = tab2[half];
-    LpScratchT<MAXCOLS>& S = S2[half];
-    double* new_geom = new_geom2[half];
-    int32_t* new_body = new_body2[half];
-    const int K = c.K;
-    const bridges_shape* shapes = c.tt->shapes;
-    const int total = c.b.cand_offset[c.E];
-    int32_t* cnt = c.b.cand_counters;                 // [0] queue length, [1] queue head
-    for (int ci = 2 * blockIdx.x + half; ci < total; ci += 2 * gridDim.x) {
-        if (!c.b.cand_mask[ci] || DIAG(c, 16)) {
-            if (lane == 0) c.b.cand_stable[ci] = 0;
-            continue;
-        }
-        grp_sync<G>();                                 // LDS lists of the previous item are dead
-        const int e = c.b.cand_env[ci];
-        const int nb = c.b.n_blocks[e];                // index the candidate would take
-        const int32_t* shape_id = c.b.blk_shape + (size_t)e * K;
-        const double* pose = c.b.blk_pose + (size_t)e * K * 4;
-        const double* verts = c.b.blk_verts + (size_t)e * K * MAXV * 2;
-        const int csh = c.b.cand_desc[(size_t)ci * 4 + 2];
-        const bridges_shape& shn = shapes[csh];
-        const double* cverts = c.b.cand_verts + (size_t)ci * MAXV * 2;
-        const double* cframes = c.b.cand_frames + (size_t)ci * MAXV * 4;
-        const int n_if0 = c.b.n_if[e];
-        // ---- interfaces candidate <-> floor and blocks < nb (same pair order as the one-per-wave kernel) ----
-        const int totalp = (1 + nb * MAXV) * MAXV;
-        int n_new = 0;
-        for (int p0 = 0; p0 < totalp; p0 += G::W_) {
-            const int p = p0 + lane;
-            bool hit = false;
-            double g[8];
-            int bodyA = -1;
-            if (p < totalp) {
-                const int qa = p / MAXV, fn = p % MAXV;
-                if (fn < shn.nv) {
-                    const int ia = shn.fa[fn], ib = shn.fb[fn];
-                    const double aBx = cverts[2 * ia], aBz = cverts[2 * ia + 1], bBx = cverts[2 * ib], bBz = cverts[2 * ib + 1];
-                    const double cBx = cframes[4 * fn], cBz = cframes[4 * fn + 1], nBx = cframes[4 * fn + 2], nBz = cframes[4 * fn + 3];
-                    if (qa == 0) {
-                        hit = face_pair_contact_v(-c.floor_hw, 0.0, c.floor_hw, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, aBx, aBz, bBx,
-                                                  bBz, cBx, cBz, nBx, nBz, fmin(c.floor_depth, shn.depth), g);
-                    } else {
-                        bodyA = (qa - 1) / MAXV;
-                        const int f = (qa - 1) % MAXV;
-                        const bridges_shape& sa = shapes[shape_id[bodyA]];
-                        if (f < sa.nv) {
-                            const double* v = verts + (size_t)bodyA * MAXV * 2;
-                            const double ax = v[2 * sa.fa[f]], az = v[2 * sa.fa[f] + 1], bx = v[2 * sa.fb[f]], bz = v[2 * sa.fb[f] + 1];
-                            const Frame2 fr = edge_frame(ax, az, bx, bz);
-                            hit = face_pair_contact_v(ax, az, bx, bz, fr.cx, fr.cz, fr.tx, fr.tz, fr.nx, fr.nz, aBx, aBz, bBx, bBz,
-                                                      cBx, cBz, nBx, nBz, fmin(sa.depth, shn.depth), g);
-                        }
-                    }
-                }
-            }
-            const uint64_t bal = grp_ballot<G>(hit);
-            const int idx = n_new + __popcll(bal & ((1ull << lane) - 1ull));
-            if (hit && idx < CS_NEW_IF) {
-                new_body[2 * idx] = bodyA;
-                new_body[2 * idx + 1] = nb;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) new_geom[8 * idx + k] = g[k];
-            }
-            n_new += __popcll(bal);
-        }
-        grp_sync<G>();
-        uint8_t res;
-        if (n_new > CS_NEW_IF || n_if0 + n_new > MAXIF) {
-            res = 2;                                   // contact list overflow (k_step would flag the same placement)
-        } else {
-            AsmView A;
-            A.pose = pose; A.shape_id = shape_id; A.shapes = shapes; A.n_blocks = nb + 1;
-            A.cand_b = nb; A.cand_pose = c.b.cand_pose + (size_t)ci * 4; A.cand_shape = csh; A.cen = nullptr; A.vol = nullptr; A.n_tens = 0; A.tens_coef = 1.0;
-            A.n_if = n_if0 + n_new; A.n_if0 = n_if0;
-            A.if_body0 = c.b.if_body + (size_t)e * MAXIF * 2; A.if_geom0 = c.b.if_geom + (size_t)e * MAXIF * 8;
-            A.if_body1 = new_body; A.if_geom1 = new_geom;
-            const uint32_t fixed = nb > 0 ? (1u << (nb - 1)) : 0u;
-            bool err = false, too_big = false, queued = false;
-            double w = 0.0;
-            int piv = 0;
-            bool st = false, solved = false;
-            if (c.b.lp_snap && nb > 0) {               // continue from the env's snapshot tableau (see the one-per-wave kernel)
-                const double* snap = c.b.lp_snap + (size_t)e * c.b.lp_snap_stride;
-                WarmPre W;
-                warm_header(W, snap, lane);
-                W.ok = warm_matches(W, nb, n_if0);
-                W.n_pre = 0;
-                if (W.ok) {
-                    bool fits = false, werr = false;
-                    st = rbe_candidate_warm(tab, TAB, MAXCOLS, S, A, n_if0, W, snap, c.mu, c.density, lane, &fits, &werr, &piv, G{});
-                    if (!fits) queued = true;
-                    else if (!werr) solved = true;
-                    grp_sync<G>();
-                }
-            }
-            if (!solved && !queued) {                  // no snapshot (first block, foreign state) or a failed check: from scratch
-                st = rbe_stable(tab, TAB, MAXCOLS, (double*)nullptr, (int64_t)0, S, A, fixed, c.mu, c.density, lane, &w, &piv, &err,
-                                &too_big, G{});
-                if (too_big) queued = true;
-            }
-            if (queued) {                              // decided by the second pass
-                if (lane == 0) c.b.cand_queue[atomicAdd(&cnt[0], 1)] = ci;
-                continue;
             }
             res = err ? 2 : (st ? 1 : 0);
         }

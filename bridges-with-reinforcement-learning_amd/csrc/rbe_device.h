@@ -195,73 +195,6 @@ __device__ __forceinline__ AsmView env_view(int n_blocks, const double* pose, co
     return A;
 }
 
-// ---- lane group that owns one LP ---------------------------------------------------------------------------------
-// Grp<64>: the whole wave works on one LP; every cross-lane result (ballots, reductions, broadcasts) is wave-uniform and
-// lives in scalar registers -- the arrangement of k_step and of the large-tableau pass.
-// Grp<32>: each 32-lane half of the wave works on its OWN LP (small tableaux: at most 32 rows).  A pivot costs the same
-// ~750 wave instructions whatever the tableau size, and on the typical tableau (a few blocks, a handful of contacts) more
-// than half of the 64 lanes idle in every step of it; with two LPs per wave every instruction serves both.  "Uniform"
-// values are then uniform per half and live in vector registers, control flow diverges per half (ordinary SIMT), ballots
-// are the half's 32 bits, reductions stop at the half (DPP row steps + one cross-row step), broadcasts go through
-// ds_bpermute.  Decisions use the same total orders, so the pivot sequence of an LP -- and its boolean -- does not depend
-// on the group width.
-template <int W> struct Grp { static constexpr int W_ = W; };
-typedef Grp<64> GrpWave;
-typedef Grp<32> GrpHalf;
-
-template <typename G> __device__ __forceinline__ uint64_t grp_ballot(bool p) {
-    const uint64_t b = __ballot(p);
-    if constexpr (G::W_ == 64) return b;
-    else return (threadIdx.x & 32) ? (b >> 32) : (b & 0xffffffffull);
-}
-template <typename G> __device__ __forceinline__ int grp_bcast_i(int v, int src) {
-    if constexpr (G::W_ == 64) return __builtin_amdgcn_readlane(v, src);
-    else return __shfl(v, (int)(threadIdx.x & 32) + src, WAVE);
-}
-template <typename G> __device__ __forceinline__ double grp_bcast_d(double v, int src) {
-    if constexpr (G::W_ == 64) return readlane_d(v, src);
-    else {
-        const int s = (int)(threadIdx.x & 32) + src;
-        return __hiloint2double(__shfl(__double2hiint(v), s, WAVE), __shfl(__double2loint(v), s, WAVE));
-    }
-}
-// reduction over a 32-lane half: the four in-row DPP steps, then lane 15 of rows 0 / 2 into rows 1 / 3; lanes 31 / 63 hold
-// the halves' results, handed to every lane of the half through scalar registers
-#define HALF_REDUCE_D(OP, IDENT_OLD)                                                   \
-    v = OP(v, dpp_d<DPP_QUAD_XOR1, 0xF>(v, v));                                        \
-    v = OP(v, dpp_d<DPP_QUAD_XOR2, 0xF>(v, v));                                        \
-    v = OP(v, dpp_d<DPP_ROW_HALF_MIRROR, 0xF>(v, v));                                  \
-    v = OP(v, dpp_d<DPP_ROW_MIRROR, 0xF>(v, v));                                       \
-    v = OP(v, dpp_d<DPP_ROW_BCAST15, 0xA>(IDENT_OLD, v));                              \
-    { const double r0 = readlane_d(v, 31), r1 = readlane_d(v, 63); return (threadIdx.x & 32) ? r1 : r0; }
-__device__ __forceinline__ double half_sum_d(double v) { HALF_REDUCE_D(add_d_, 0.0) }
-__device__ __forceinline__ double half_min_d(double v) { HALF_REDUCE_D(fmin, v) }
-__device__ __forceinline__ double half_max_d(double v) { HALF_REDUCE_D(fmax, v) }
-__device__ __forceinline__ int half_min_i(int v) {
-    v = min(v, dpp_i<DPP_QUAD_XOR1, 0xF>(v, v));
-    v = min(v, dpp_i<DPP_QUAD_XOR2, 0xF>(v, v));
-    v = min(v, dpp_i<DPP_ROW_HALF_MIRROR, 0xF>(v, v));
-    v = min(v, dpp_i<DPP_ROW_MIRROR, 0xF>(v, v));
-    v = min(v, dpp_i<DPP_ROW_BCAST15, 0xA>(v, v));
-    const int r0 = __builtin_amdgcn_readlane(v, 31), r1 = __builtin_amdgcn_readlane(v, 63);
-    return (threadIdx.x & 32) ? r1 : r0;
-}
-template <typename G> __device__ __forceinline__ double grp_sum_d(double v) { if constexpr (G::W_ == 64) return wave_sum_d(v); else return half_sum_d(v); }
-template <typename G> __device__ __forceinline__ double grp_min_d(double v) { if constexpr (G::W_ == 64) return wave_min_d(v); else return half_min_d(v); }
-template <typename G> __device__ __forceinline__ double grp_max_d(double v) { if constexpr (G::W_ == 64) return wave_max_d(v); else return half_max_d(v); }
-template <typename G> __device__ __forceinline__ int grp_min_i(int v) { if constexpr (G::W_ == 64) return wave_min_i(v); else return half_min_i(v); }
-// ordering point between the lanes of a group: the one-wave workgroup's barrier, or -- for a half, whose LDS tableau is only
-// ever touched by its own lanes, in program order -- a compiler fence (the halves are in divergent control flow)
-template <typename G> __device__ __forceinline__ void grp_sync() {
-    if constexpr (G::W_ == 64) {
-        __syncthreads();
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // Build the phase-1 tableau.  Rows 3*b..3*b+2 = (Fx, Fz, My) of free block b (< n_free), row m = the force budget
 // sum_j x_j + s = LP_S_MAX, row m+1 = cost.  Columns [0, n) = cone generators, column n = the budget slack s,
 // column n+1 = right-hand side.
@@ -277,16 +210,15 @@ template <typename G> __device__ __forceinline__ void grp_sync() {
 // explicit artificial of row i).  Row operations keep  tableau = R * [M | slack | w | I], so carrier i always holds
 // R e_i: what a column that arrives later (a new contact of a later block) must be multiplied with to enter the tableau
 // in its current coordinates (lp_warm_prepare).  Carriers are never priced.
-template <typename TP, typename G = GrpWave>
+template <typename TP>
 __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const AsmView& A, const int* row_of /*LDS [K]*/,
-                                double mu, double density, int lane, int ncarr = 0, G = G{}) {
-    constexpr int GW = G::W_;
+                                double mu, double density, int lane, int ncarr = 0) {
     const int nn = n + 1;                              // structural columns incl. the budget slack; rhs column index
     int cells = (m + 2) * stride;
-    for (int i = lane; i < cells; i += GW) T[i] = 0.0;
-    grp_sync<G>();
+    for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
+    __syncthreads();
     const int n4 = 4 * A.n_if;                         // cone generators; columns [n4, n) are tension columns
-    for (int j = lane; j < n; j += GW) {
+    for (int j = lane; j < n; j += WAVE) {
         const bool tens = j >= n4;
         int k = tens ? (j - n4) >> 1 : j >> 2, ip = tens ? (j - n4) & 1 : (j >> 1) & 1, ig = j & 1;
         const double* g = A.ig(k);
@@ -311,20 +243,20 @@ __device__ inline void lp_build(TP T, int stride, int m, int m_act, int n, const
             }
         }
     }
-    for (int i = lane; i < m; i += GW)
+    for (int i = lane; i < m; i += WAVE)
         T[i * stride + nn] = (LP_PERTURB * density) * (1.0 + 0.37 * (double)(i % 7) + 0.0618 * (double)(i % 11));
-    for (int q = lane; q <= nn; q += GW) T[m * stride + q] = q < nn ? ((q >= n4 && q < n) ? A.tens_coef : 1.0) : LP_S_MAX * density;
-    for (int i = lane; i < ncarr; i += GW) T[i * stride + nn + 1 + i] = 1.0;
-    grp_sync<G>();
-    for (int b = lane; b < A.n_blocks; b += GW)
+    for (int q = lane; q <= nn; q += WAVE) T[m * stride + q] = q < nn ? ((q >= n4 && q < n) ? A.tens_coef : 1.0) : LP_S_MAX * density;
+    for (int i = lane; i < ncarr; i += WAVE) T[i * stride + nn + 1 + i] = 1.0;
+    __syncthreads();
+    for (int b = lane; b < A.n_blocks; b += WAVE)
         if (row_of[b] >= 0) T[(row_of[b] + 1) * stride + nn] += density * A.volume(b);
-    grp_sync<G>();
-    for (int q = lane; q <= nn; q += GW) {         // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
+    __syncthreads();
+    for (int q = lane; q <= nn; q += WAVE) {         // phase-1 cost row over the ACTIVE rows (rows >= m_act are passive)
         double s = 0.0;
         for (int i = 0; i < m_act; ++i) s += T[i * stride + q];
         T[(m + 1) * stride + q] = -s;
     }
-    grp_sync<G>();
+    __syncthreads();
 }
 
 template <int MAXCOLS>
@@ -352,14 +284,14 @@ __device__ __forceinline__ void wave_sync() {
     }
 }
 
-template <typename G = GrpWave, typename TP>
+template <typename TP>
 __device__ __forceinline__ double artificial_sum(TP T, int stride, int m, int n, const int* basis, int lane) {
     double v = 0.0;
     if (lane < m && basis[lane] >= n) {
         double rhs = T[lane * stride + n];
         v = rhs > 0.0 ? rhs : 0.0;
     }
-    return grp_sum_d<G>(v);
+    return wave_sum_d(v);
 }
 
 // 1/x to ~1e-16 relative: hardware v_rcp_f64 seed + one Newton step (the LP needs no correctly rounded quotient;
@@ -381,10 +313,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // read from the cost row (the exact artificial sum is recomputed only to confirm a "feasible" exit).
 // `feas` = the feasibility threshold (RBE_FEAS_TOL x density).
 // Returns w = sum of the artificial basics (<= feas <=> stable).  All lanes return the same value.
-template <bool IN_LDS, typename TP, typename SC, typename G = GrpWave>
+template <bool IN_LDS, typename TP, typename SC>
 __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int* pivots_out,
-                                   bool* error, bool init_basis, double feas, int ncarr = 0, G = G{}) {
-    constexpr int GW = G::W_;                          // lanes of the group that owns this LP (rows: m + 2 <= GW)
+                                   bool* error, bool init_basis, double feas, int ncarr = 0) {
     // m equilibrium rows are stored and swept; only ACTIVE rows take part in the ratio test and carry artificials
     // (the others are "passive": equality rows that are transformed along but not enforced, see rbe_both).  A row is
     // passive iff its basis entry is -1: with init_basis that is rows >= m_act, otherwise whatever the caller set up
@@ -394,20 +325,20 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
     const int n = n_gen + 1;                           // structural columns incl. the slack; also the rhs column index
     const int mb = m, mc = m + 1;                      // budget row, cost row
     if (init_basis) {
-        for (int i = lane; i <= mb; i += GW) basis[i] = (i < m_act) ? n + i : (i == mb ? n_gen : -1);
+        for (int i = lane; i <= mb; i += WAVE) basis[i] = (i < m_act) ? n + i : (i == mb ? n_gen : -1);
         wave_sync<IN_LDS>();
     }
     int pivots = *pivots_out, stall = 0;
     bool bland = false;
-    const int nchunk = (n + GW - 1) / GW;
+    const int nchunk = (n + WAVE - 1) / WAVE;
     const int ncols = n + 1 + ncarr;                   // swept columns: structural, rhs, carriers
     const double progress = 1e-7 * feas;               // 1e-12 at density 1
     LP_PROF_DECL;
     (void)m_act;                                       // from here on activity is read off the basis
-    double w = artificial_sum<G>(T, stride, m, n, basis, lane);
+    double w = artificial_sum(T, stride, m, n, basis, lane);
     for (;;) {
         if (w <= feas) {                                           // confirm with the exact artificial sum
-            w = artificial_sum<G>(T, stride, m, n, basis, lane);
+            w = artificial_sum(T, stride, m, n, basis, lane);
             if (w <= feas) break;
         }
         LP_STAMP(t_a);
@@ -415,26 +346,26 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         int jin = -1;
         if (bland) {
             for (int c = 0; c < nchunk && jin < 0; ++c) {
-                int j = c * GW + lane;
+                int j = c * WAVE + lane;
                 bool neg = (j < n) && (T[mc * stride + j] < -LP_EPS_COST);
-                uint64_t bal = grp_ballot<G>(neg);
-                if (bal) jin = c * GW + (__ffsll((long long)bal) - 1);
+                uint64_t bal = __ballot(neg);
+                if (bal) jin = c * WAVE + (__ffsll((long long)bal) - 1);
             }
         } else {
             double dbest = 0.0;
             int jbest = 0;
-            for (int j = lane; j < n; j += GW) {
+            for (int j = lane; j < n; j += WAVE) {
                 double d = T[mc * stride + j];
                 if (d < dbest) { dbest = d; jbest = j; }           // strict: keeps the lane's lowest column of a tie
             }
-            double dmin = grp_min_d<G>(dbest);
+            double dmin = wave_min_d(dbest);
             if (dmin < -LP_EPS_COST) {
-                int src = __ffsll((long long)grp_ballot<G>(dbest == dmin)) - 1;
-                jin = grp_bcast_i<G>(jbest, src);
+                int src = __ffsll((long long)__ballot(dbest == dmin)) - 1;
+                jin = __builtin_amdgcn_readlane(jbest, src);
             }
         }
         if (jin < 0) {                                             // optimal: w is the true minimum
-            w = artificial_sum<G>(T, stride, m, n, basis, lane);
+            w = artificial_sum(T, stride, m, n, basis, lane);
             break;
         }
         LP_STAMP(t_b);
@@ -446,40 +377,43 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
             double rhs = T[lane * stride + n];
             ratio = (rhs > 0.0 ? rhs : 0.0) * fast_rcp(col);
         }
-        const double rmin = grp_min_d<G>(ratio);
+        const double rmin = wave_min_d(ratio);
         if (rmin >= 1e300) {                                       // no usable pivot in this column: retire it
             if (lane == 0) T[mc * stride + jin] = 0.0;
             wave_sync<IN_LDS>();
             continue;
         }
         const bool tie = ratio <= rmin + LP_TIE * (1.0 + rmin);
+        const uint64_t tbal = __ballot(tie);
         int r;
-        if (bland) {
+        if ((tbal & (tbal - 1ull)) == 0ull) {                      // a single candidate row (the common case): no tie to break
+            r = __ffsll((long long)tbal) - 1;
+        } else if (bland) {
             int var = tie ? basis[lane] : 0x7fffffff;
-            int vmin = grp_min_i<G>(var);
-            r = __ffsll((long long)grp_ballot<G>(tie && var == vmin)) - 1;
+            int vmin = wave_min_i(var);
+            r = __ffsll((long long)__ballot(tie && var == vmin)) - 1;
         } else {
-            double cmax = grp_max_d<G>(tie ? col : -1e300);
-            r = __ffsll((long long)grp_ballot<G>(tie && col == cmax)) - 1;
+            double cmax = wave_max_d(tie ? col : -1e300);
+            r = __ffsll((long long)__ballot(tie && col == cmax)) - 1;
         }
-        const double ipiv = fast_rcp(grp_bcast_d<G>(col, r));
+        const double ipiv = fast_rcp(readlane_d(col, r));
         LP_STAMP(t_c);
         LP_ACC(1, t_b, t_c);
         // ---- stage the entering column, the normalised pivot row and the lists of rows / columns the rank-1
         //      update actually touches (equilibrium tableaux are sparse: typically a fraction of the cells) ----
         S.col[lane] = col;
-        const uint64_t rbal = grp_ballot<G>(lane <= mc && (col != 0.0 || lane == r));
+        const uint64_t rbal = __ballot(lane <= mc && (col != 0.0 || lane == r));
         if ((rbal >> lane) & 1ull) S.rows_nz[__popcll(rbal & ((1ull << lane) - 1ull))] = (short)lane;
         const int nr = __popcll(rbal);
         int nc = 0;
-        for (int c = 0; c * GW < ncols; ++c) {
-            const int q = c * GW + lane;
+        for (int c = 0; c * WAVE < ncols; ++c) {
+            const int q = c * WAVE + lane;
             double v = 0.0;
             if (q < ncols) {
                 v = (q == jin) ? 1.0 : T[r * stride + q] * ipiv;
                 S.rowr[q] = v;
             }
-            const uint64_t cbal = grp_ballot<G>(q < ncols && v != 0.0);
+            const uint64_t cbal = __ballot(q < ncols && v != 0.0);
             if ((cbal >> lane) & 1ull) S.cols_nz[nc + __popcll(cbal & ((1ull << lane) - 1ull))] = (short)q;
             nc += __popcll(cbal);
         }
@@ -490,14 +424,14 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         //      stores: the cells are distinct, which the compiler cannot prove, so the batching is explicit) ----
         {
             const int cells = nr * nc;
-            const int di = GW / nc, dq = GW - di * nc;
+            const int di = WAVE / nc, dq = WAVE - di * nc;
             int a = lane / nc, b = lane - a * nc;
-            for (int idx = lane; idx < cells; idx += 4 * GW) {
+            for (int idx = lane; idx < cells; idx += 4 * WAVE) {
                 int ii[4], qq[4];
                 double tv[4], cv[4], rv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool ok = idx + u * GW < cells;
+                    const bool ok = idx + u * WAVE < cells;
                     const int i = ok ? S.rows_nz[a] : 0, q = ok ? S.cols_nz[b] : 0;
                     ii[u] = i; qq[u] = q;
                     tv[u] = ok ? T[i * stride + q] : 0.0;
@@ -508,7 +442,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (idx + u * GW < cells) {
+                    if (idx + u * WAVE < cells) {
                         double v;
                         if (ii[u] == r) v = rv[u];
                         else if (qq[u] == jin) v = 0.0;
@@ -527,7 +461,7 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
         if (wn < w - progress) { stall = 0; bland = false; }
         else if (++stall > LP_STALL) bland = true;
         w = wn;
-        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum<G>(T, stride, m, n, basis, lane); break; }
+        if (++pivots >= LP_MAX_PIVOTS) { *error = true; w = artificial_sum(T, stride, m, n, basis, lane); break; }
     }
     *pivots_out = pivots;
     LP_PROF_FLUSH;
@@ -537,16 +471,16 @@ __device__ inline double lp_phase1(TP T, int stride, int m, int m_act, int n_gen
 // Independent check of a "feasible" verdict: read the basic solution x off the tableau and evaluate the ORIGINAL
 // equilibrium rows  sum_j M_ij x_j - w_i  again from the contact list (nothing of the pivoted tableau is reused).
 // A tableau damaged by an ill-conditioned pivot cannot pass this.  Returns the L1 residual over rows < m_chk.
-template <typename TP, typename SC, typename G = GrpWave>
+template <typename TP, typename SC>
 __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC& S, const AsmView& A, double mu,
-                                   double density, int lane, G = G{}) {
-    for (int q = lane; q < n; q += G::W_) S.rowr[q] = 0.0;
-    grp_sync<G>();
+                                   double density, int lane) {
+    for (int q = lane; q < n; q += WAVE) S.rowr[q] = 0.0;
+    __syncthreads();
     if (lane <= m && S.basis[lane] >= 0 && S.basis[lane] < n) {     // rows incl. the budget row; generators only
         double v = T[lane * stride + n + 1];
         S.rowr[S.basis[lane]] = v > 0.0 ? v : 0.0;
     }
-    grp_sync<G>();
+    __syncthreads();
     double res = 0.0;
     if (lane < m_chk && S.basis[lane] != -1) {                      // enforced rows only (passive rows have basis -1)
         // row -> (block, component): rows are 3 per free block in block order (row_of)
@@ -588,18 +522,18 @@ __device__ inline double lp_verify(TP T, int stride, int m, int m_chk, int n, SC
         const double rhs = comp == 1 ? density * A.volume(b) : 0.0;
         res = fabs(acc - rhs);
     }
-    return grp_sum_d<G>(res);
+    return wave_sum_d(res);
 }
 
 // Enforce the passive rows [m_act, m): give each an artificial (negating the row if its rhs went negative) and
 // price it into the cost row.  The tableau then continues from the basis reached so far (warm start).
-template <bool IN_LDS, typename TP, typename SC, typename G = GrpWave>
-__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int ncarr = 0, G = G{}) {
+template <bool IN_LDS, typename TP, typename SC>
+__device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int n_gen, SC& S, int lane, int ncarr = 0) {
     const int n = n_gen + 1;
     for (int i = m_act; i < m; ++i) {
         const bool neg = T[i * stride + n] < 0.0;                  // uniform
         wave_sync<IN_LDS>();
-        for (int q = lane; q <= n + ncarr; q += G::W_) {
+        for (int q = lane; q <= n + ncarr; q += WAVE) {
             double v = T[i * stride + q];
             if (neg) { v = -v; T[i * stride + q] = v; }
             T[(m + 1) * stride + q] -= v;
@@ -610,12 +544,12 @@ __device__ inline void lp_activate_rows(TP T, int stride, int m, int m_act, int 
 }
 
 // Shared setup of a solve: row map of the free blocks.
-template <typename SC, typename G = GrpWave>
-__device__ inline void lp_row_map(SC& S, uint32_t free_mask, int lane, G = G{}) {
-    grp_sync<G>();
+template <typename SC>
+__device__ inline void lp_row_map(SC& S, uint32_t free_mask, int lane) {
+    __syncthreads();
     if (lane < MAXK)
         S.row_of[lane] = ((free_mask >> lane) & 1u) ? 3 * __popc(free_mask & ((1u << lane) - 1u)) : -1;
-    grp_sync<G>();
+    __syncthreads();
 }
 
 // Tableau geometry of an assembly with n_free free blocks and n_if interfaces: rows m = 3 n_free (+ budget + cost),
@@ -632,10 +566,10 @@ __device__ __forceinline__ void lp_dims(int n_free, int n_if, int& m, int& n, in
 // Stability of one assembly variant.  fixed_mask bit b = block b is_static (fixed).  tab_lds holds lds_cap doubles
 // and the scratch MAXCOLS generator columns; a tableau that does not fit goes to tab_ws (ws_cap doubles, may be 0).
 // *too_big is set (and false returned, without an error) when neither fits -- the caller decides what that means.
-template <typename SC, typename G = GrpWave>
+template <typename SC>
 __device__ inline bool rbe_stable(double* tab_lds, int lds_cap, int max_cols, double* tab_ws, int64_t ws_cap, SC& S,
                                   const AsmView& A, uint32_t fixed_mask, double mu, double density, int lane,
-                                  double* w_out, int* pivots_out, bool* error, bool* too_big, G grp = G{}) {
+                                  double* w_out, int* pivots_out, bool* error, bool* too_big) {
     *w_out = 0.0;
     *pivots_out = 0;
     const int n_blocks = A.n_blocks;
@@ -649,14 +583,11 @@ __device__ inline bool rbe_stable(double* tab_lds, int lds_cap, int max_cols, do
     lp_dims(n_free, A.n_if, m, n, stride, cells, false, A.n_tens);
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
     double w;
-    if (cells <= lds_cap && n <= max_cols && m + 2 <= G::W_) {   // LDS path: address space known at compile time (ds_read/ds_write)
-        lp_row_map(S, free_mask, lane, grp);
-        lp_build(tab_lds, stride, m, m, n, A, S.row_of, mu, density, lane, 0, grp);
-        w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true, feas, 0, grp);
-        if (w <= feas && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane, grp) > vtol) { *error = true; w = 1e300; }
-    } else if constexpr (G::W_ != 64) {
-        *too_big = true;                                // a half-wave group works on LDS tableaux only
-        return false;
+    if (cells <= lds_cap && n <= max_cols) {          // LDS path: address space known at compile time (ds_read/ds_write)
+        lp_row_map(S, free_mask, lane);
+        lp_build(tab_lds, stride, m, m, n, A, S.row_of, mu, density, lane);
+        w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots_out, error, true, feas);
+        if (w <= feas && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; w = 1e300; }
     } else {
         if (cells > ws_cap || n > max_cols) { *too_big = true; return false; }
         lp_row_map(S, free_mask, lane);
@@ -722,49 +653,59 @@ __device__ __forceinline__ void warm_prefetch(WarmPre& W, const double* ws, int 
     const int m_o = 3 * n_old_blocks, ncols_o = 4 * n_if_old + 2 + m_o;
     const int cells_o = W.ok ? (m_o + 1) * ncols_o : 0;
     const double* src = ws + WARM_HDR_DOUBLES + (int64_t)(W.half & 1) * WARM_HALF;
+    const int di = WAVE / ncols_o, dq = WAVE - di * ncols_o;     // same stepping as lp_warm_prepare
+    int i = lane / ncols_o, q = lane - i * ncols_o;
 #pragma unroll
     for (int u = 0; u < WARM_PRE; ++u) {
         const int idx = lane + WAVE * u;
         double v = 0.0;
-        if (idx < cells_o) {
-            const int i = idx / ncols_o, q = idx - i * ncols_o;
-            v = src[(size_t)i * W.stride + q];
-        }
+        if (idx < cells_o) v = src[(size_t)i * W.stride + q];
         W.cell[u] = v;
+        i += di; q += dq;
+        if (q >= ncols_o) { q -= ncols_o; ++i; }
     }
 }
 
 // Continue from the persisted tableau `src` (stride_o, m_o rows + budget, n_gen_o generators, carriers for its m_o
 // rows): fill T (stride, m = m_o + 3 rows, n_gen generators) and S.basis, rebuild the cost row for stage 1 (active
 // rows = the old ones).  A.n_blocks - 1 is the new block, interfaces >= n_gen_o / 4 are its contacts.
-template <bool IN_LDS, typename TP, typename SC, typename G = GrpWave>
+template <bool IN_LDS, typename TP, typename SC>
 __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const double* src, int stride_o, int m_o,
                                        int n_gen_o, const WarmPre& W, SC& S, const AsmView& A, double mu,
-                                       double density, int lane, G = G{}) {
-    constexpr int GW = G::W_;
+                                       double density, int lane) {
     const int n = n_gen + 1, n_o = n_gen_o + 1;                 // rhs column index (new / old)
     const int ncols_o = n_o + 1 + m_o;
     const int cells = (m + 2) * stride;
-    for (int i = lane; i < cells; i += GW) T[i] = 0.0;
+    for (int i = lane; i < cells; i += WAVE) T[i] = 0.0;
     wave_sync<IN_LDS>();
     // old rows (equilibrium rows keep their index, the budget row moves from m_o to m), old columns remapped
     const int cells_o = (m_o + 1) * ncols_o;
+    // cell idx = lane + 64 u of the old tableau <-> (row i, column q) = (idx / ncols_o, idx % ncols_o), stepped from one
+    // division per lane (a division per cell was ~25 instructions each)
+    const int di_o = WAVE / ncols_o, dq_o = WAVE - di_o * ncols_o;
+    int ci_o = lane / ncols_o, cq_o = lane - ci_o * ncols_o;
 #pragma unroll
     for (int u = 0; u < WARM_PRE; ++u) {                         // the prefetched cells
-        const int idx = lane + GW * u;
+        const int idx = lane + WAVE * u;
         if (u < W.n_pre && idx < cells_o) {
-            const int i = idx / ncols_o, q = idx - i * ncols_o;
+            const int i = ci_o, q = cq_o;
             const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
             const int in = i < m_o ? i : m;
             T[in * stride + qn] = W.cell[u];
         }
+        if (u < W.n_pre) {
+            ci_o += di_o; cq_o += dq_o;
+            if (cq_o >= ncols_o) { cq_o -= ncols_o; ++ci_o; }
+        }
     }
-    for (int idx = lane + GW * W.n_pre; idx < cells_o; idx += GW) {     // the rest (everything without a prefetch)
-        const int i = idx / ncols_o, q = idx - i * ncols_o;
+    for (int idx = lane + WAVE * W.n_pre; idx < cells_o; idx += WAVE) {     // the rest (everything without a prefetch)
+        const int i = ci_o, q = cq_o;
         const double v = src[(size_t)i * stride_o + q];
         const int qn = q < n_gen_o ? q : (q == n_gen_o ? n_gen : (q == n_o ? n : n + 1 + (q - n_o - 1)));
         const int in = i < m_o ? i : m;
         T[in * stride + qn] = v;
+        ci_o += di_o; cq_o += dq_o;
+        if (cq_o >= ncols_o) { cq_o -= ncols_o; ++ci_o; }
     }
     if (lane <= m_o) {
         const int b = W.basis_lane;
@@ -782,39 +723,64 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
         T[i * stride + n] = rhs;
         T[i * stride + n + 1 + i] = 1.0;
     }
-    // new generator columns: R * a for the old rows and the budget row, raw entries in the new rows
-    for (int j = n_gen_o; j < n_gen; ++j) {
-        const int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
-        const double* g = A.ig(k);
-        const int32_t* bd = A.ib(k);
-        const double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
-        const double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
-        const double gx = ig ? nx - mu * tx : nx + mu * tx;
-        const double gz = ig ? nz - mu * tz : nz + mu * tz;
-        const int bodyA = bd[0];                                 // floor (-1) or an older block; body B is the new block
-        if (lane <= m_o) {
-            const int row = lane < m_o ? lane : m;
-            double v = T[row * stride + n_gen];                  // budget coefficient 1 times the slack column
-            if (bodyA >= 0) {
-                double gcx, gcz;
-                A.centroid(bodyA, gcx, gcz);
-                const double rx = px - gcx, rz = pz - gcz;
-                const double a0 = -gx, a1 = -gz, a2 = rx * a1 - rz * a0;
-                const int c0 = n + 1 + 3 * bodyA;
-                v += a0 * T[row * stride + c0] + a1 * T[row * stride + c0 + 1] + a2 * T[row * stride + c0 + 2];
+    // new generator columns: R * a for the old rows and the budget row, raw entries in the new rows.  16 columns at a time:
+    // lanes over COLUMNS build each column's descriptor once (what it adds to the carriers of body A, its three entries in
+    // the new block's rows) into LDS scratch, then lanes over ROWS apply the descriptors -- the per-column geometry
+    // (contact point, cone generator, two centroids) was evaluated by every lane for every column before (~60 wave
+    // instructions per column, a third of a continued solve's set-up).  Same expressions, same order: the tableau is
+    // bit for bit the one the column-by-column loop built.
+    {
+        const int n_newc = n_gen - n_gen_o;
+        double ncx = 0.0, ncz = 0.0;
+        A.centroid(nbn, ncx, ncz);
+        for (int j0 = 0; j0 < n_newc; j0 += 16) {
+            wave_sync<IN_LDS>();
+            if (lane < 16 && j0 + lane < n_newc) {
+                const int j = n_gen_o + j0 + lane;
+                const int k = j >> 2, ip = (j >> 1) & 1, ig = j & 1;
+                const double* g = A.ig(k);
+                const int32_t* bd = A.ib(k);
+                const double px = ip ? g[2] : g[0], pz = ip ? g[3] : g[1];
+                const double nx = g[4], nz = g[5], tx = g[6], tz = g[7];
+                const double gx = ig ? nx - mu * tx : nx + mu * tx;
+                const double gz = ig ? nz - mu * tz : nz + mu * tz;
+                const int bodyA = bd[0];                             // floor (-1) or an older block; body B is the new block
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                if (bodyA >= 0) {
+                    double gcx, gcz;
+                    A.centroid(bodyA, gcx, gcz);
+                    const double rx = px - gcx, rz = pz - gcz;
+                    a0 = -gx; a1 = -gz; a2 = rx * a1 - rz * a0;
+                }
+                const double rxn = px - ncx, rzn = pz - ncz;
+                double* d = S.rowr + 7 * lane;
+                d[0] = a0; d[1] = a1; d[2] = a2; d[3] = (double)bodyA;
+                d[4] = gx; d[5] = gz; d[6] = rxn * gz - rzn * gx;
             }
-            T[row * stride + j] = v;
-        } else if (lane < m_o + 4) {
-            const int cmp = lane - m_o - 1;                      // 0, 1, 2: Fx, Fz, My of the new block
-            double gcx, gcz;
-            A.centroid(nbn, gcx, gcz);
-            const double rx = px - gcx, rz = pz - gcz;
-            T[(m_o + cmp) * stride + j] = cmp == 0 ? gx : (cmp == 1 ? gz : rx * gz - rz * gx);
+            wave_sync<IN_LDS>();
+            const int nb16 = (n_newc - j0) < 16 ? (n_newc - j0) : 16;
+            if (lane <= m_o) {
+                const int row = lane < m_o ? lane : m;
+                const double slack = T[row * stride + n_gen];        // budget coefficient 1 times the slack column
+                for (int u = 0; u < nb16; ++u) {
+                    const double* d = S.rowr + 7 * u;
+                    const int bodyA = (int)d[3];
+                    double v = slack;
+                    if (bodyA >= 0) {
+                        const int c0 = n + 1 + 3 * bodyA;
+                        v += d[0] * T[row * stride + c0] + d[1] * T[row * stride + c0 + 1] + d[2] * T[row * stride + c0 + 2];
+                    }
+                    T[row * stride + n_gen_o + j0 + u] = v;
+                }
+            } else if (lane < m_o + 4) {
+                const int cmp = lane - m_o - 1;                      // 0, 1, 2: Fx, Fz, My of the new block
+                for (int u = 0; u < nb16; ++u) T[(m_o + cmp) * stride + n_gen_o + j0 + u] = S.rowr[7 * u + 4 + cmp];
+            }
         }
     }
     wave_sync<IN_LDS>();
     // phase-1 cost row over the structural columns and the rhs: minus the rows whose artificial is still basic
-    for (int q = lane; q <= n; q += GW) {
+    for (int q = lane; q <= n; q += WAVE) {
         double sacc = 0.0;
         for (int i = 0; i < m_o; ++i)
             if (S.basis[i] >= n) sacc += T[i * stride + q];
@@ -827,9 +793,12 @@ __device__ inline void lp_warm_prepare(TP T, int stride, int m, int n_gen, const
 __device__ inline void lp_warm_store(const double* T, int stride, int m, int n_gen, double* dst, int lane) {
     const int ncols = n_gen + 2 + m;
     const int cells = (m + 1) * ncols;
+    const int di = WAVE / ncols, dq = WAVE - di * ncols;         // (row, column) of cell idx stepped, not divided per cell
+    int i = lane / ncols, q = lane - i * ncols;
     for (int idx = lane; idx < cells; idx += WAVE) {
-        const int i = idx / ncols, q = idx - i * ncols;
         dst[(size_t)i * stride + q] = T[i * stride + q];
+        i += di; q += dq;
+        if (q >= ncols) { q -= ncols; ++i; }
     }
 }
 
@@ -948,25 +917,25 @@ __device__ inline void rbe_both(double* tab_lds, int lds_cap, double* ws, int64_
 // passive, the candidate's three rows are activated right away.  Returns false in *fits when the tableau (with
 // carriers) exceeds lds_cap doubles or the scratch's columns; *error when the verdict fails its check on the original
 // rows (the caller then solves from scratch).
-template <typename SC, typename G = GrpWave>
+template <typename SC>
 __device__ inline bool rbe_candidate_warm(double* tab_lds, int lds_cap, int max_cols, SC& S, const AsmView& A, int n_if_old,
                                           const WarmPre& W, const double* snap, double mu, double density, int lane,
-                                          bool* fits, bool* error, int* pivots, G grp = G{}) {
+                                          bool* fits, bool* error, int* pivots) {
     const int nb = A.n_blocks;                          // incl. the candidate
     int m, n, stride;
     int64_t cells;
     lp_dims(nb, A.n_if, m, n, stride, cells, true);
-    *fits = cells <= lds_cap && n + 2 + m <= max_cols + 4 + 3 * MAXK && m + 2 <= G::W_;
+    *fits = cells <= lds_cap && n + 2 + m <= max_cols + 4 + 3 * MAXK;
     if (!*fits) return false;
     const uint32_t all = (1u << nb) - 1u;
-    lp_row_map(S, all, lane, grp);
+    lp_row_map(S, all, lane);
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
-    lp_warm_prepare<true>(tab_lds, stride, m, n, snap + WARM_HDR_DOUBLES, W.stride, m - 3, 4 * n_if_old, W, S, A, mu, density, lane, grp);
-    lp_activate_rows<true>(tab_lds, stride, m, m - 3, n, S, lane, m, grp);
-    const double w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots, error, false, feas, m, grp);
+    lp_warm_prepare<true>(tab_lds, stride, m, n, snap + WARM_HDR_DOUBLES, W.stride, m - 3, 4 * n_if_old, W, S, A, mu, density, lane);
+    lp_activate_rows<true>(tab_lds, stride, m, m - 3, n, S, lane, m);
+    const double w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots, error, false, feas, m);
     bool stable = w <= feas;
     if (w > feas && w < LP_MARGIN * feas) *error = true;       // marginal "unstable" of a continued tableau: the caller re-solves cold
-    if (stable && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane, grp) > vtol) { *error = true; stable = false; }
+    if (stable && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; stable = false; }
     return stable;
 }
 

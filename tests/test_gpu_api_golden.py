@@ -212,7 +212,9 @@ def test_rbe_penalty_variant_against_the_oracle(golden_dir):
                 assert loose == ORB.is_stable_rbe_penalty(blocks, fixed, mu=mu, tol=50.0), (name, kw, mu, step)
                 if rbe:
                     assert pen
-                if pen:
+                if extra is None:                          # an assembly without contacts: (no free block, None), stability.py:77-81
+                    assert len(ORB.find_interfaces(blocks)) == 0
+                elif pen:
                     assert extra["max_tension"] is not None and extra["max_tension"] <= 1e-3 + 1e-9
                 else:
                     assert extra["max_tension"] is None and (info["min_tension"] is None or info["min_tension"] > 1e-3)
