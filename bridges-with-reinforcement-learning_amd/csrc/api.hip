@@ -134,7 +134,10 @@ int bridges_env_create(const bridges_task* t, const bridges_env_buffers* buf, br
     int cus = 256;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     (void)cus;
-    e = hipHostMalloc((void**)&env->h_total, sizeof(int32_t), hipHostMallocDefault);
+    // mapped, coherent host word: k_scan stores the candidate count of the lock-step straight into it (no copy command
+    // in the stream); the host reads it as a hint for the next grid, so a late value costs time, never correctness
+    e = hipHostMalloc((void**)&env->h_total, sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&c.h_total, env->h_total, 0);
     if (e != hipSuccess) { (void)hipFree(env->tt_dev); delete env; return fail_hip(e, "hipHostMalloc"); }
     *env->h_total = t->n_envs * 64;        // first guess; replaced after every scan
     env->max_blocks = 1 << 22;
@@ -231,11 +234,10 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     hipLaunchKernelGGL(k_enumerate, dim3(c.E), dim3(WAVE), 0, s, c);
     LAUNCH_CHECK("k_enumerate");
     // grids from the previous lock-step's candidate count (+3 %); the kernels grid-stride, so a stale or low
-    // estimate costs time, never correctness.  The fresh count is copied back asynchronously for the next call.
+    // estimate costs time, never correctness.  k_scan stores the fresh count into the mapped host word for the next call.
     long long est = (long long)(*(volatile int32_t*)env->h_total);
     if (est < c.E) est = c.E;
     est += est / 32 + 64;
-    HIP_TRY(hipMemcpyAsync(env->h_total, c.b.cand_offset + c.E, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     const long long items_est = est + c.E;            // one wave per image (candidates + state rasters)
     long long rblocks = (items_est + 3) / 4;
     if (rblocks > env->max_blocks) rblocks = env->max_blocks;
@@ -276,7 +278,7 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
-#define CS_TAB_SMALL 1152    // 9 KiB: with carriers, candidates on up to 5 placed blocks; 148 VGPRs allow 12 waves per CU anyway
+#define CS_TAB_SMALL 768     // 6 KiB: with carriers, candidates on up to ~4 placed blocks; 9.5 KB of LDS and <= 128 VGPRs per wave: 16 waves per CU
 #define CS_COLS_SMALL 92
 #define CS_TAB_LARGE 4096
 int bridges_env_candidate_stability(bridges_env* env, void* stream) {

@@ -149,6 +149,7 @@ struct TaskTable {
 struct DevCtx {
     bridges_env_buffers b;
     const TaskTable* tt;
+    int32_t* h_total;               // mapped host word: total raw candidates of the last scan (sizes the next raster grid)
     int32_t E, K, max_steps, a_max, n_groups, n_ground, n_offsets, n_targets;
     int32_t debug, env_id_base;     // debug: BRIDGES_DIAG builds only (bit0 skip the LPs, bit1 / bit2 skip the half-plane runs / the f32
                                     // stores of the rasteriser, bit3 per-env phase stamps, bit4 empty candidate-stability grid)

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
         for (int w = 0; w < SCAN_WAVES; ++w)
             for (int k = 0; k < 7; ++k) tot[k] += red[w][k];
         c.b.cand_offset[c.E] = carry_s;
+        if (c.h_total) *c.h_total = carry_s;
         c.b.stats[ST_SUM_CAND] += (uint64_t)carry_s;
         c.b.stats[ST_SUM_BLOCKS] += tot[0];
         c.b.stats[ST_ENV_STEPS] += tot[1];
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
 // lp_ws (one slot per workgroup) behind it; every wave leaves when the queue head passes the count.
 #define CS_NEW_IF 16
 template <int TAB, int MAXCOLS, bool QUEUE>
-__global__ __launch_bounds__(WAVE) void k_candidate_stability(DevCtx c) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(QUEUE ? 1 : 4, QUEUE ? 2 : 4))) void k_candidate_stability(DevCtx c) {
     __shared__ __attribute__((aligned(16))) double tab[TAB];
     __shared__ LpScratchT<MAXCOLS> S;
     __shared__ double new_geom[CS_NEW_IF * 8];
