@@ -159,10 +159,22 @@ def self_launch(args):
 
 # ------------------------------------------------------------------------- side modes (child processes)
 def _child_json(cmd, timeout, env=None):
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-    line = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    if res.returncode != 0 or not line:
-        return None, (res.stderr or "no output")[-300:]
+    """Run a child job (its own process group, so that a time-out takes its grandchildren -- torchrun's ranks -- with it)
+    and return (the last JSON line it printed, None) or (None, what went wrong)."""
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)           # the exact process group started above
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        return None, f"timed out after {timeout} s"
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not line:
+        return None, (err or "no output")[-300:]
     return json.loads(line[-1]), None
 
 
@@ -328,6 +340,8 @@ def parse_args():
                     help="kernel timing experiments of a diagnostic build (BRIDGES_LIB=tools/libbridges_hip_diag.so) -- invalidates the run")
     ap.add_argument("--no-f32-rasters", action="store_true", help="bit-packed rasters only (reported as its own mode)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the child runs of the side modes")
+    ap.add_argument("--config4-leg", action="store_true",
+                    help="(internal) run only BASELINE configs[3]'s training leg on the ranks of this job and print its JSON")
     ap.add_argument("--sparse-raster-update", action="store_true",
                     help="f32 rasters, but only the row groups that change are stored (reported as its own mode)")
     return ap.parse_args()
@@ -368,6 +382,14 @@ def main():
             dist.init_process_group(backend)
         ranks_seen = dist.get_world_size()
     red_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    if args.config4_leg:                                # child job of an N > 1 run: only the training leg, its own process group
+        leg = train_config4_leg(args, dev, rank, world, backend)
+        if rank == 0:
+            print(json.dumps(leg), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     names, obstacles, targets, task_label = task_of(args)
     geoms = [load_urdf(f"shapes/{n}.urdf") for n in names]
@@ -564,19 +586,35 @@ def main():
                 out["other_modes"] = side_modes(args)
             except Exception as exc:                     # the headline line must survive whatever happens here
                 out["other_modes"] = {"error": repr(exc)[:200]}
-    if world > 1 and args.mode == "sim" and os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
-        # every rank takes part (collectives inside); only rank 0 holds `out`
-        try:
-            release()
-            leg = train_config4_leg(args, dev, rank, world, backend)
-        except Exception as exc:                         # the headline line must survive whatever happens here
-            leg = {"error": repr(exc)[:300]}
-        if rank == 0:
-            out.setdefault("other_modes", {})["train_config4"] = leg
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # BASELINE.json configs[3] on the same N ranks, as a CHILD job with its own process group and a timeout: the
+    # collectives of the training loop have never run on more than one physical GPU from inside this build, and a hang or
+    # a crash in there must not cost the headline line.  Every rank of this job leaves its GPU first.
+    want_leg = world > 1 and args.mode == "sim" and os.environ.get("BENCH_TRAIN_MODES", "1") != "0"
     if world > 1:
+        release()
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if want_leg:
+            try:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                       "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--config4-leg",
+                       "--gpus", str(world), "--envs", str(args.envs)]
+                env_c = {k: v for k, v in os.environ.items()
+                         if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                                      "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                                      "TORCHELASTIC_MAX_RESTARTS")}
+                env_c.update(MASTER_ADDR="127.0.0.1")
+                leg, err = _child_json(cmd, int(os.environ.get("BENCH_CONFIG4_TIMEOUT", "600")), env=env_c)
+                if leg is None:
+                    leg = {"error": err}
+            except Exception as exc:                     # the headline line must survive whatever happens here
+                leg = {"error": repr(exc)[:300]}
+            out.setdefault("other_modes", {})["train_config4"] = leg
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
