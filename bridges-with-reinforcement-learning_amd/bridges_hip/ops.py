@@ -115,6 +115,41 @@ def raster_bits(blocks, xlim, ylim, img_size=(64, 64)):
     return bits
 
 
+def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, reward_map=None, img_size=(64, 64), want_f32=False):
+    """bridges_action_features for a list of posed candidate blocks against one state: -> (bits [n,64] int64, img
+    [n,64,64] f32 or None, mask [n] bool, lin [n] f32 or None) on the device.  state_bits / obstacle_bits: [64] int64 bit
+    rasters (None = empty); reward_map: [64,64] f32 tensor (None: no linear reward)."""
+    S = image_size(img_size)
+    L = abi.require_gpu()
+    dev = device()
+    n = len(blocks)
+    bits = torch.empty((n, 64), dtype=torch.int64, device=dev)
+    img = torch.empty((n, 64, 64), dtype=torch.float32, device=dev) if want_f32 else None
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    lin = torch.zeros(n, dtype=torch.float32, device=dev) if reward_map is not None else None
+    if n == 0:
+        return bits, img, mask.bool(), lin
+    verts = np.zeros((n, 6, 2))
+    ids = np.zeros(n, dtype=np.int32)
+    for i, b in enumerate(blocks):
+        verts[i, :len(b.verts_2d)] = b.verts_2d
+        ids[i] = REGISTRY.id_of(b.geometry)
+    tab = REGISTRY.device_table()
+    v = torch.tensor(verts, dtype=torch.float64, device=dev)
+    s_ = torch.tensor(ids, dtype=torch.int32, device=dev)
+    gx = torch.tensor(np.linspace(xlim[0], xlim[1], S), dtype=torch.float64, device=dev)
+    gy = torch.tensor(np.linspace(ylim[1], ylim[0], S), dtype=torch.float64, device=dev)
+    prefix = None
+    if reward_map is not None:
+        pre = np.zeros((64, 65), dtype=np.float64)
+        pre[:, 1:] = np.cumsum(reward_map.detach().cpu().numpy().astype(np.float64).reshape(64, 64), axis=1)
+        prefix = torch.from_numpy(pre).to(dev)
+    abi.check(L.bridges_action_features(tab, n, _ptr(v), _ptr(s_), _ptr(gx), _ptr(gy), S, float(xlim[0]), float(xlim[1]),
+                                        float(ylim[0]), float(ylim[1]), _ptr(state_bits), _ptr(obstacle_bits), _ptr(prefix),
+                                        _ptr(bits), _ptr(img), _ptr(mask), _ptr(lin), _stream()), "bridges_action_features")
+    return bits, img, mask.bool(), lin
+
+
 def bits_or(bits):
     L = abi.require_gpu()
     dev = bits.device

@@ -402,6 +402,21 @@ int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* ver
     return bridges_raster_sized(shapes_dev, n, verts, shape_id, grid_x, grid_y, IMG, bits, img, stream);
 }
 
+int bridges_action_features(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                            const double* grid_x, const double* grid_y, int32_t size, double xlim0, double xlim1, double ylim0,
+                            double ylim1, const uint64_t* state_bits, const uint64_t* obstacle_bits, const double* reward_prefix,
+                            uint64_t* bits, float* img, uint8_t* mask, float* lin_reward, void* stream) {
+    if (n < 0 || !shapes_dev || !verts || !shape_id || !grid_x || !grid_y) return fail_arg("bridges_action_features");
+    if (size < 2 || size > IMG) return fail_arg("bridges_action_features: image size must be 2..64");
+    if (lin_reward && !reward_prefix) return fail_arg("bridges_action_features: lin_reward needs reward_prefix");
+    if (n == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_action_features, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, shapes_dev, n, verts,
+                       shape_id, grid_x, grid_y, (int)size, xlim0, xlim1, ylim0, ylim1, state_bits, obstacle_bits, reward_prefix, bits,
+                       img, mask, lin_reward);
+    LAUNCH_CHECK("k_action_features");
+    return BRIDGES_OK;
+}
+
 int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream) {
     if (n_groups < 0) return fail_arg("bridges_bits_or");
     if (n_groups == 0) return BRIDGES_OK;

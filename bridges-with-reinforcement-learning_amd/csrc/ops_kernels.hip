@@ -143,6 +143,44 @@ __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* sha
     }
 }
 
+// get_action_features + filter_actions + the linear reward for n posed candidate outlines against ONE state (the
+// stand-alone form of what k_raster does inside the lock-step; robotoddler/training/successor_dqn.py:84-94, 397-401,
+// robotoddler/utils/actions.py:71-82, gym_env.py:304-323): raster of every outline, mask[i] = all vertices inside
+// [xlim, ylim] (and z >= 0) within 1e-6 AND no pixel shared with the state or the obstacle raster, lin[i] = sum(raster *
+// reward_map) through the map's float64 row prefix sums.  One wave per candidate.
+__global__ __launch_bounds__(256) void k_action_features(const bridges_shape* shapes, int n, const double* verts,
+                                                         const int32_t* shape_id, const double* gx, const double* gy, int size,
+                                                         double xlim0, double xlim1, double ylim0, double ylim1,
+                                                         const uint64_t* state_bits, const uint64_t* obstacle_bits,
+                                                         const double* reward_prefix, uint64_t* bits, float* img,
+                                                         uint8_t* mask, float* lin) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    const uint64_t occ = (state_bits ? state_bits[lane] : 0ull) | (obstacle_bits ? obstacle_bits[lane] : 0ull);
+    for (int it = wave; it < n; it += nwaves) {
+        const bridges_shape& sh = shapes[shape_id[it]];
+        const double* v = verts + (size_t)it * MAXV * 2;
+        const uint64_t b = raster_outline(v, sh.nv, sh.fa, sh.fb, gx, gy, size, lane);
+        bool out_of_bounds = false;
+        if (lane < sh.nv) {
+            const double eps = 1e-6, vx = v[2 * lane], vz = v[2 * lane + 1];
+            out_of_bounds = vx < xlim0 - eps || vx > xlim1 + eps || vz < ylim0 - eps || vz > ylim1 + eps || vz < -eps;
+        }
+        const bool inb = __ballot(out_of_bounds) == 0ull;
+        const bool overlap = __ballot((b & occ) != 0ull) != 0ull;
+        double p_hi = 0.0, p_lo = 0.0;
+        if (reward_prefix) raster_reward_fetch(b, reward_prefix, lane, p_hi, p_lo);
+        if (bits) bits[(size_t)it * IMG + lane] = b;
+        if (img) write_f32_image(img + (size_t)it * IMG * IMG, b, lane);
+        const double l = raster_reward_sum(p_hi, p_lo);
+        if (lane == 0) {
+            if (mask) mask[it] = (uint8_t)(inb && !overlap);
+            if (lin) lin[it] = (float)l;
+        }
+    }
+}
+
 __global__ void k_bits_or(int n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out) {
     int g = blockIdx.x, lane = threadIdx.x;
     uint64_t acc = 0ull;

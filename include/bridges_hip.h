@@ -231,6 +231,16 @@ int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* ver
 int bridges_raster_sized(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
                          const double* grid_x, const double* grid_y, int32_t size, uint64_t* bits, float* img,
                          void* stream);
+/* get_action_features + filter_actions + the rollout's linear reward, fused, for n posed candidate outlines against one
+ * state (successor_dqn.py:84-94, 397-401; actions.py:71-82; gym_env.py:304-323): bits [n,64] u64 and / or img [n,64,64] f32
+ * (either may be NULL) = the rasters; mask [n] u8 = every vertex inside [xlim, ylim] and above z = 0 (tolerance 1e-6) and
+ * no pixel in common with state_bits | obstacle_bits ([64] u64 each, may be NULL = empty); lin_reward [n] f32 =
+ * sum(raster * reward_map) taken from reward_prefix ([64,65] f64 row prefix sums of the map, see bridges_env_buffers).
+ * size = S of an S x S image (grid_x / grid_y hold S samples).  The lock-step does the same inside bridges_env_step. */
+int bridges_action_features(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                            const double* grid_x, const double* grid_y, int32_t size, double xlim0, double xlim1, double ylim0,
+                            double ylim1, const uint64_t* state_bits, const uint64_t* obstacle_bits, const double* reward_prefix,
+                            uint64_t* bits, float* img, uint8_t* mask, float* lin_reward, void* stream);
 /* OR-reduce groups of bit rasters: out[g] = OR bits[ranges[g][0] .. ranges[g][1]);  ranges int32 [n_groups,2]. */
 int bridges_bits_or(int32_t n_groups, const int32_t* ranges, const uint64_t* bits, uint64_t* out, void* stream);
 /* bit raster -> f32 image. */

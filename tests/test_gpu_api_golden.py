@@ -227,3 +227,95 @@ def test_rbe_penalty_variant_against_the_oracle(golden_dir):
         is_stable_cra(env)
     with pytest.raises(NotImplementedError):
         AssemblyEnv(render=False, stability="cra")
+
+
+def test_action_features_operator_equals_the_reference_composition():
+    """bridges_action_features (rasters + in-bounds / no-overlap mask + linear reward in one call) against what
+    the reference composes from get_action_features, filter_actions and sum(action * reward) (successor_dqn.py:84-94,
+    397-401; actions.py:71-82), through the drop-in functions and against the numpy oracle, at 64x64 and 32x32."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import Action, AssemblyGym, bridge_setup, sparse_reward
+    from assembly_gym.utils.rendering import render_blocks_2d_bits
+    from bridges_hip import ops
+    from oracle.env import OracleGym
+    from oracle.env import bridge_setup as o_bridge_setup
+    from robotoddler.training.successor_dqn import get_action_features, get_state_features, get_task_features
+    from robotoddler.utils.actions import filter_actions
+    for size in ((64, 64), (32, 32)):
+        lim = dict(xlim=(-3, 7), ylim=(0, 10))
+        env = AssemblyGym(**bridge_setup(num_stories=2), reward_fct=sparse_reward, restrict_2d=True, max_steps=10,
+                          assembly_env=AssemblyEnv(render=False))
+        og = OracleGym(**o_bridge_setup(num_stories=2), max_steps=10, img_size=size)
+        obs, _ = env.reset()
+        for a in ((-1, 0, 0, 3, -1.3333333333333335, 0.0), (0, 1, 0, 3, 0.0, 0.0)):
+            obs, *_ = env.step(Action(*a))
+            og.step(a)
+        cand = og.candidates()
+        actions = [Action(*a) for a in cand["actions"]]
+        blocks = env.create_blocks(actions)
+        state_bits = render_blocks_2d_bits(obs["blocks"], lim["xlim"], lim["ylim"], size).reshape(64)
+        obst_bits = render_blocks_2d_bits(obs["obstacle_blocks"], lim["xlim"], lim["ylim"], size).reshape(64)
+        reward, obstacle = get_task_features(obs, img_size=size, **lim)
+        canvas = torch.zeros((64, 64), dtype=torch.float32, device=reward.device)
+        canvas[:size[0], :size[1]] = reward[0]
+        bits, img, mask, lin = ops.action_features(blocks, lim["xlim"], lim["ylim"], state_bits=state_bits, obstacle_bits=obst_bits,
+                                                   reward_map=canvas, img_size=size, want_f32=True)
+        S = size[0]
+        # rasters: the oracle's and get_action_features'
+        assert np.array_equal(img[:, :S, :S].cpu().numpy().astype(bool), cand["rasters"])
+        feats = get_action_features(env, actions, img_size=size, **lim)
+        assert torch.equal(img[:, :S, :S], feats[:, 0])
+        assert torch.equal(ops.bits_to_f32(bits), img)
+        # mask: the oracle's and filter_actions'
+        assert np.array_equal(mask.cpu().numpy(), cand["mask"])
+        block_f, _ = get_state_features(obs, img_size=size, **lim)
+        kept, _ = filter_actions(env, actions, feats, block_features=block_f, obstacle_features=obstacle, **lim)
+        assert [a for a, m in zip(actions, mask.tolist()) if m] == kept
+        # linear reward: sum(action raster * reward map) of the rollout, 1e-5
+        want = (feats[:, 0] * reward).sum(dim=(1, 2))
+        assert torch.allclose(lin, want, rtol=1e-5, atol=1e-6), float((lin - want).abs().max())
+
+
+def test_raster_with_edges_through_pixel_centres():
+    """The row-run rasteriser evaluates the reference's comparison  ((X - c.x) n.x) + ((Y - c.z) n.z) <= 0  through a
+    binary search per face and row: the cases where it decides pixel by pixel -- edges that pass EXACTLY through sample
+    points, axis-aligned and diagonal, blocks hanging over every border of the image -- against the per-pixel numpy oracle,
+    at three image sizes."""
+    from bridges_hip import ops
+    from oracle import raster as o_raster
+    from oracle.geometry import Block as OBlock
+    from oracle.shapes import get_shape
+    from assembly_gym.envs.assembly_env import Block, Shape
+    import math
+    rng = np.random.default_rng(3)
+    for S in (64, 33, 17):
+        xlim, ylim = (-3.0, 7.0), (0.0, 10.0)
+        X, Y = o_raster.pixel_grid(xlim, ylim, (S, S))
+        cases = []
+        for name in ("cube06", "cube1", "trapezoid", "hexagon", "block"):
+            for k in range(12):
+                gxi, gyi = rng.integers(0, S), rng.integers(0, S)
+                ang = [0.0, math.pi / 2, math.pi / 4, math.pi, rng.uniform(0, 2 * math.pi)][k % 5]
+                # centre chosen so that a vertex or an edge midpoint of the (rotated) block lands on a sample point
+                cases.append((name, float(X[gxi]) + (0.3 if name == "cube06" and k % 2 else 0.0), float(Y[gyi]), ang))
+            cases.append((name, xlim[0] - 0.2, 5.0, 0.3)); cases.append((name, 6.9, ylim[1] + 0.1, 1.1)); cases.append((name, 2.0, -0.2, 0.0))
+        blocks, oblocks = [], []
+        for name, x, z, ang in cases:
+            c, s_ = math.cos(ang), math.sin(ang)
+            ob = OBlock(get_shape(name), (x, z), (c, s_))
+            from assembly_gym.envs.assembly_env import Quaternion
+            b = Block(Shape(urdf_file=f"shapes/{name}.urdf"), position=[x, 0.0, z], orientation=Quaternion.from_cos_sin(c, s_))
+            assert np.array_equal(b.verts_2d, np.array(ob.verts))
+            blocks.append(b); oblocks.append(ob)
+        bits = ops.raster_bits(blocks, xlim, ylim, (S, S))
+        img = ops.bits_to_f32(bits)[:, :S, :S].cpu().numpy().astype(bool)
+        on_edge = 0
+        for i, ob in enumerate(oblocks):
+            want = o_raster.contains_2d(ob, X, Y)
+            assert np.array_equal(img[i], want), (S, cases[i])
+            for (c, _t, n) in ob.frames:                    # how many sample points sit exactly on an edge line
+                d = ((X - c[0]) * n[0])[None, :] + ((Y - c[1]) * n[1])[:, None]
+                on_edge += int((d == 0).sum())
+        assert on_edge > 50                                  # the degenerate cases are really in there
+        canvas = ops.bits_to_f32(bits).cpu().numpy()
+        assert not canvas[:, S:, :].any() and not canvas[:, :, S:].any()
