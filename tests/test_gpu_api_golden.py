@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -302,9 +303,9 @@ def test_raster_with_edges_through_pixel_centres():
         blocks, oblocks = [], []
         for name, x, z, ang in cases:
             c, s_ = math.cos(ang), math.sin(ang)
-            ob = OBlock(get_shape(name), (x, z), (c, s_))
             from assembly_gym.envs.assembly_env import Quaternion
             b = Block(Shape(urdf_file=f"shapes/{name}.urdf"), position=[x, 0.0, z], orientation=Quaternion.from_cos_sin(c, s_))
+            ob = OBlock(get_shape(name), (b.pose[0], b.pose[1]), (b.pose[2], b.pose[3]))     # the pose the drop-in block holds
             assert np.array_equal(b.verts_2d, np.array(ob.verts))
             blocks.append(b); oblocks.append(ob)
         bits = ops.raster_bits(blocks, xlim, ylim, (S, S))
