@@ -407,21 +407,18 @@ __global__ __launch_bounds__(256) void k_mlp_input(int batch, int rows, int px, 
 
 // What k_loss_log does, inside the loss kernel: the row workgroup that arrives LAST sums the per-row losses in row order
 // (the same order, hence the same float), logs them, advances the batch counter and the optimiser's step count, and
-// re-arms the ticket.  Inter-workgroup hand-off by the counter form of the release / acquire recipe
-// (cdna_hip_programming.md, Guideline 16): thread 0 is the only thread of its workgroup that stored a handed-off value
-// (loss_rows[b]); it drains its stores, releases at agent scope, drains again, then draws its ticket with an agent-scope
-// atomic; the last arriver acquires at agent scope and reads every row with agent-scope (sc1) loads.  The batch counter
-// is read by every workgroup BEFORE it draws its ticket, so the last arriver may advance it.
+// re-arms the ticket.  Inter-workgroup hand-off in the write-through form of cdna_hip_programming.md, Guideline 16 /
+// "In-launch split-K reduction": the one handed-off value of a workgroup, loss_rows[b], is stored by thread 0 with an
+// agent-scope (sc1, write-through) store -- no release fence, which would write the whole L2 back, the 1 MB of dy this
+// launch has just stored included --, thread 0 drains its stores (s_waitcnt vmcnt(0)) and draws its ticket with an
+// agent-scope atomic; the last arriver reads every row with agent-scope (sc1) loads.  The batch counter is read by every
+// workgroup BEFORE it draws its ticket, so the last arriver may advance it.
 __device__ __forceinline__ void loss_log_ticket(int batch, float* loss_rows, float* losses, int n_losses, int64_t* counter,
                                                 int32_t* ticket, float* adam_step, int t) {
     if (t != 0) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (drawn != (int)gridDim.x - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float l = 0.f;
     for (int b = 0; b < batch; ++b) l += __hip_atomic_load(&loss_rows[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t c = *counter;
@@ -453,7 +450,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int 
     float* dyr = dy + (size_t)b * N;
     if (b >= batch) {
         for (int j = t; j < N; j += LOSS_THREADS) dyr[j] = 0.f;
-        if (t == 0) { loss_rows[b] = 0.f; q_out[b] = 0.f; }
+        if (t == 0) { __hip_atomic_store(&loss_rows[b], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q_out[b] = 0.f; }
         if (ticket) loss_log_ticket(batch, loss_rows, losses, n_losses, counter_inc, ticket, adam_step, t);
         return;
     }
@@ -514,7 +511,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_successor_loss(int batch, int 
         float l = 0.f;
         if (use_q) { const float d = q - q_target_all[src]; l += d * d * inv_b; }
         if (use_sf) l += lsf * inv_b / (float)px;
-        loss_rows[b] = l;
+        __hip_atomic_store(&loss_rows[b], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through: read by the last arriver
         q_out[b] = q;
     }
     if (ticket) loss_log_ticket(batch, loss_rows, losses, n_losses, counter_inc, ticket, adam_step, t);
