@@ -21,7 +21,7 @@ def linear_forward(x, weight, bias, relu, out=None, ws=None):
     out = torch.empty((rows, N), dtype=torch.float32, device=x.device) if out is None else out
     ws = torch.empty(1 << 20, dtype=torch.float32, device=x.device) if ws is None else ws
     abi.check(L.bridges_linear_forward(rows, K, N, _ptr(x), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(out), _ptr(ws),
-                                       ws.numel(), _stream()), "bridges_linear_forward")
+                                       ws.numel(), None, _stream()), "bridges_linear_forward")
     return out
 
 
@@ -35,7 +35,7 @@ def linear_backward(dz, a_in, weight, act_below=None, need_input_grad=True, ws=N
     below = torch.empty((rows, K), dtype=torch.float32, device=dz.device) if need_input_grad else None
     ws = torch.empty(1 << 20, dtype=torch.float32, device=dz.device) if ws is None else ws
     abi.check(L.bridges_linear_backward(rows, K, N, _ptr(dz), _ptr(a_in), _ptr(weight), _ptr(dW), _ptr(db), _ptr(act_below),
-                                        _ptr(below), _ptr(ws), ws.numel(), _stream()), "bridges_linear_backward")
+                                        _ptr(below), _ptr(ws), ws.numel(), None, _stream()), "bridges_linear_backward")
     return dW, db, below
 
 
@@ -72,6 +72,7 @@ class FusedSuccessorStep:
         self.dz = [z(self.rows, d) for d in dims[1:]]                # gradient at the pre-activation of every layer
         self.ws = torch.empty(self.WS_FLOATS, dtype=torch.float32, device=dev)
         self.loss_rows, self.q = z(self.rows), z(self.rows)
+        self.x_all, self._prepared, self._n_alloc = None, False, 0
         self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)  # word 0: arrival ticket of the loss kernel (re-armed by it)
         # the gradient tensors the launches write.  With flattened parameters (dqn_ops.FlatParameters) they are views of
         # ONE flat buffer laid out like the parameter buffer; either way they are referenced here as well, so a later
@@ -95,6 +96,24 @@ class FusedSuccessorStep:
         if (optimizer is not None and self.grad_flat is not None and self._adam_applies(optimizer, net)
                 and {id(p) for p in params} == {id(p) for p in net.parameters()}):
             self._adopt_adam(optimizer, params)
+
+    def allocate_inputs(self, n_batches):
+        """Room for the first layer's input rows of n_batches batches (52 MB for 25 batches of 32 rows of 64x64 images): after
+        this, ``prepare_inputs`` + ``launch`` replace the per-step build of the rows (one launch per optimiser step)."""
+        K = self.linears[0].in_features
+        self.x_all = torch.zeros((int(n_batches) * self.rows, K), dtype=torch.float32, device=self.linears[0].weight.device)
+        self._n_alloc, self._prepared = int(n_batches), False
+
+    def prepare_inputs(self, n_batches, block_all, action_all, binary_all, reward, obstacle):
+        """Build the input rows of batches 0 .. n_batches - 1 of the per-call arrays in ONE launch (bridges_mlp_input_batches);
+        ``launch`` then reads batch ``counter`` of them."""
+        assert self.x_all is not None and n_batches <= self._n_alloc
+        for t in (block_all, action_all, binary_all, reward, obstacle):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        abi.check(self.L.bridges_mlp_input_batches(int(n_batches), self.batch, self.rows, self.px, self.nf, _ptr(block_all),
+                                                   _ptr(action_all), _ptr(binary_all), _ptr(reward), _ptr(obstacle), _ptr(self.x_all),
+                                                   _stream()), "bridges_mlp_input_batches")
+        self._prepared = True
 
     @staticmethod
     def _offset(flat, p):
@@ -165,13 +184,17 @@ class FusedSuccessorStep:
         for t in (block_all, action_all, binary_all, reward, obstacle):
             assert t.dtype == torch.float32 and t.is_contiguous()
         assert counter.dtype == torch.int64 and losses.dtype == torch.float32
-        abi.check(L.bridges_mlp_input(B, rows, px, nf, _ptr(counter), _ptr(block_all), _ptr(action_all), _ptr(binary_all),
-                                      _ptr(reward), _ptr(obstacle), _ptr(self.acts[0]), st), "bridges_mlp_input")
+        # the first layer's input: batch `counter` of the pre-built rows of all batches (prepare_inputs), else built here
+        pre = self.x_all is not None and self._prepared
+        x0, blk = (self.x_all, _ptr(counter)) if pre else (self.acts[0], None)
+        if not pre:
+            abi.check(L.bridges_mlp_input(B, rows, px, nf, _ptr(counter), _ptr(block_all), _ptr(action_all), _ptr(binary_all),
+                                          _ptr(reward), _ptr(obstacle), _ptr(self.acts[0]), st), "bridges_mlp_input")
         last = len(self.linears) - 1
         for l, lin in enumerate(self.linears):
-            abi.check(L.bridges_linear_forward(rows, lin.in_features, lin.out_features, _ptr(self.acts[l]), _ptr(lin.weight),
-                                               _ptr(lin.bias), int(l < last), _ptr(self.acts[l + 1]), _ptr(self.ws),
-                                               self.ws.numel(), st), "bridges_linear_forward")
+            abi.check(L.bridges_linear_forward(rows, lin.in_features, lin.out_features, _ptr(x0 if l == 0 else self.acts[l]),
+                                               _ptr(lin.weight), _ptr(lin.bias), int(l < last), _ptr(self.acts[l + 1]), _ptr(self.ws),
+                                               self.ws.numel(), blk if l == 0 else None, st), "bridges_linear_forward")
         # the loss kernel's last-arriving row workgroup logs the loss, advances the batch counter and the Adam step count
         abi.check(L.bridges_successor_loss(B, rows, px, nf, _ptr(self.acts[-1]), _ptr(reward), _ptr(counter),
                                            _ptr(q_target_all) if self.use_q else None,
@@ -190,17 +213,17 @@ class FusedSuccessorStep:
                 mw, vw, mb, vb = self._moments[0]
                 lo, hi = self._rest
                 off = lambda t: C.c_void_p(t.data_ptr() + 4 * lo)
-                abi.check(L.bridges_linear_backward_adam(rows, lin.in_features, lin.out_features, _ptr(self.dz[0]), _ptr(self.acts[0]),
+                abi.check(L.bridges_linear_backward_adam(rows, lin.in_features, lin.out_features, _ptr(self.dz[0]), _ptr(x0),
                                                          _ptr(lin.weight), _ptr(lin.bias), _ptr(mw), _ptr(vw), _ptr(mb), _ptr(vb),
                                                          off(self.flat), off(self.grad_flat), off(self.m_flat), off(self.v_flat),
-                                                         hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),
-                          "bridges_linear_backward_adam")
+                                                         hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, blk,
+                                                         st), "bridges_linear_backward_adam")
                 continue
-            abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]), _ptr(self.acts[l]),
-                                                _ptr(lin.weight), _ptr(lin.weight.grad), _ptr(lin.bias.grad),
-                                                _ptr(self.acts[l]) if l > 0 else None,
-                                                _ptr(self.dz[l - 1]) if l > 0 else None, _ptr(self.ws), self.ws.numel(), st),
-                      "bridges_linear_backward")
+            abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]),
+                                                _ptr(x0 if l == 0 else self.acts[l]), _ptr(lin.weight), _ptr(lin.weight.grad),
+                                                _ptr(lin.bias.grad), _ptr(self.acts[l]) if l > 0 else None,
+                                                _ptr(self.dz[l - 1]) if l > 0 else None, _ptr(self.ws), self.ws.numel(),
+                                                blk if l == 0 else None, st), "bridges_linear_backward")
         if self.fused_adam and not fold_first:               # larger batches: one flat launch behind the backward pass
             abi.check(L.bridges_adam_step(_ptr(self.flat), _ptr(self.grad_flat), _ptr(self.m_flat), _ptr(self.v_flat),
                                           self.flat.numel(), _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),

@@ -195,6 +195,40 @@ def bits_linear(bits, wt, bits_row=None, base=None, base_row=None):
     return out
 
 
+def bits_dot(bits, img, slot, bits_row=None):
+    """out[r] = sum(img[slot[r]] * raster(bits[bits_row[r]])) for bit-packed 64x64 rasters (bridges_bits_dot): img
+    [n_slots,64,64] float32, slot [n] int64 -> [n] float32."""
+    L = abi.require_gpu()
+    bits = bits.reshape(-1, 64)
+    assert bits.is_contiguous() and bits.dtype == torch.int64 and img.dtype == torch.float32 and img.is_contiguous()
+    assert tuple(img.shape[-2:]) == (64, 64)
+    slot = slot.to(torch.int64).contiguous()
+    n = slot.numel()
+    if bits_row is not None:
+        bits_row = bits_row.to(torch.int64).contiguous()
+        assert bits_row.numel() == n
+    out = torch.empty(n, dtype=torch.float32, device=bits.device)
+    abi.check(L.bridges_bits_dot(n, _ptr(bits), _ptr(bits_row), _ptr(img), _ptr(slot), _ptr(out), _stream()), "bridges_bits_dot")
+    return out
+
+
+def bits_accumulate_(img, bits, slot, weight=None, bits_row=None):
+    """img[slot[r]] += weight[r] * raster(bits[bits_row[r]]) in place (bridges_bits_accumulate)."""
+    L = abi.require_gpu()
+    bits = bits.reshape(-1, 64)
+    assert bits.is_contiguous() and bits.dtype == torch.int64 and img.dtype == torch.float32 and img.is_contiguous()
+    assert tuple(img.shape[-2:]) == (64, 64)
+    slot = slot.to(torch.int64).contiguous()
+    n = slot.numel()
+    if bits_row is not None:
+        bits_row = bits_row.to(torch.int64).contiguous()
+    if weight is not None:
+        weight = weight.to(torch.float32).contiguous()
+    abi.check(L.bridges_bits_accumulate(n, _ptr(bits), _ptr(bits_row), _ptr(weight), _ptr(slot), _ptr(img), _stream()),
+              "bridges_bits_accumulate")
+    return img
+
+
 def sigmoid_dot(d, w):
     """out[r] = sum_j w[j] * sigmoid(d[r, j]) in one pass over ``d`` ([n, k] float32, k % 4 == 0; bridges_sigmoid_dot)."""
     L = abi.require_gpu()

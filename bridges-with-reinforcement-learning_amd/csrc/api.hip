@@ -519,6 +519,26 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
+int bridges_bits_dot(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* img, const int64_t* slot,
+                     float* out, void* stream) {
+    if (n_rows < 0 || !bits || !img || !slot || !out) return fail_arg("bridges_bits_dot");
+    if (n_rows == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_bits_dot, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n_rows, bits, bits_row,
+                       img, slot, out);
+    LAUNCH_CHECK("k_bits_dot");
+    return BRIDGES_OK;
+}
+
+int bridges_bits_accumulate(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* weight,
+                            const int64_t* slot, float* img, void* stream) {
+    if (n_rows < 0 || !bits || !img || !slot) return fail_arg("bridges_bits_accumulate");
+    if (n_rows == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_bits_accumulate, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n_rows, bits,
+                       bits_row, weight, slot, img);
+    LAUNCH_CHECK("k_bits_accumulate");
+    return BRIDGES_OK;
+}
+
 int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, const float* w, int32_t k, float* out,
                         void* stream) {
     if (n_rows < 0 || k <= 0 || (k & 3) || (row_stride & 3) || !d || !w || !out) return fail_arg("bridges_sigmoid_dot");
@@ -559,7 +579,7 @@ int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, const float* W, const float* bias,
-                           int32_t relu, float* y, float* ws, int64_t ws_floats, void* stream) {
+                           int32_t relu, float* y, float* ws, int64_t ws_floats, const int64_t* x_block, void* stream) {
     if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !x || !W || !bias || !y) return fail_arg("bridges_linear_forward: rows must be a positive multiple of 32");
     const int n_tiles = ceil_div(N, 32), m_tiles = rows / 32;
     // enough workgroups to fill the chip; a split holds at least 64 k values and its partial sums must fit in ws
@@ -574,7 +594,7 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
     splits = ceil_div(K, kchunk);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_lin_fwd, dim3(n_tiles, splits, m_tiles), dim3(256), 0, st, K, N, kchunk, x, W, bias, relu, y,
-                       splits > 1 ? ws : (float*)nullptr);
+                       splits > 1 ? ws : (float*)nullptr, x_block);
     LAUNCH_CHECK("k_lin_fwd");
     if (splits > 1) {
         int blocks = ceil_div(rows * N, 256);
@@ -587,7 +607,7 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
 
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
-                            void* stream) {
+                            const int64_t* a_block, void* stream) {
     if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !dz || !a_in || !W || !dW || !db) return fail_arg("bridges_linear_backward");
     const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32), m_tiles = rows / 32;
     int per_job = ceil_div(n_ntiles * n_ktiles, 1024);           // k tiles per dW job: ~1024 jobs on the big layers
@@ -610,7 +630,7 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
     // one split: the input gradient goes straight to dz_below (masked), no partial sums
     hipLaunchKernelGGL(k_lin_bwd<false>, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
                        !dz_below ? (float*)nullptr : (nsplit == 1 ? dz_below : ws), nsplit == 1 ? act_below : (const float*)nullptr,
-                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{});
+                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{}, a_block);
     LAUNCH_CHECK("k_lin_bwd");
     if (dz_below && nsplit > 1) {
         int blocks = ceil_div(rows * K, 256);
@@ -624,7 +644,7 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
                                  float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
                                  const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
-                                 double lr, double beta1, double beta2, double eps, void* stream) {
+                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, void* stream) {
     if (rows != 32 || K <= 0 || N <= 0 || !dz || !a_in || !W || !bias || !exp_avg_w || !exp_avg_sq_w || !exp_avg_b || !exp_avg_sq_b || !step)
         return fail_arg("bridges_linear_backward_adam: one 32-row batch tile, all buffers given");
     if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail_arg("bridges_linear_backward_adam: hyper-parameters");
@@ -645,7 +665,7 @@ int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float
                 rest_param, rest_grad, rest_exp_avg, rest_exp_avg_sq, (long long)rest_n};
     hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
                        (const float*)W, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job,
-                       0, 0, ad);
+                       0, 0, ad, a_block);
     LAUNCH_CHECK("k_lin_bwd<adam>");
     return BRIDGES_OK;
 }
@@ -660,6 +680,19 @@ int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const
     hipLaunchKernelGGL(k_mlp_input, dim3(blocks), dim3(256), 0, (hipStream_t)stream, batch, rows, px, nf, counter, block_all,
                        action_all, binary_all, reward, obstacle, x);
     LAUNCH_CHECK("k_mlp_input");
+    return BRIDGES_OK;
+}
+
+int bridges_mlp_input_batches(int32_t n_batches, int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* block_all,
+                              const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
+                              float* x_all, void* stream) {
+    if (n_batches <= 0 || batch <= 0 || rows < batch || (rows & 31) || px <= 0 || nf < 0 || !block_all || !action_all || !reward || !obstacle || !x_all)
+        return fail_arg("bridges_mlp_input_batches");
+    int blocks = ceil_div(rows * (4 * px + nf), 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_mlp_input, dim3(blocks, n_batches), dim3(256), 0, (hipStream_t)stream, batch, rows, px, nf,
+                       (const int64_t*)nullptr, block_all, action_all, binary_all, reward, obstacle, x_all);
+    LAUNCH_CHECK("k_mlp_input (all batches)");
     return BRIDGES_OK;
 }
 

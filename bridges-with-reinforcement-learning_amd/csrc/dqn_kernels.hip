@@ -164,6 +164,55 @@ __global__ __launch_bounds__(256) void k_bits_linear(int n_rows, const uint64_t*
     }
 }
 
+// Count-based exploration of EpsilonGreedy (successor_dqn.py:112-131) on the bit-packed rasters, both directions:
+//   k_bits_dot:        out[r] = sum over the set pixels of bits[bits_row[r]] of img[slot[r]]  (= sum(step_images[step] * a_r))
+//   k_bits_accumulate: img[slot[r]] += weight[r] * raster(bits[bits_row[r]])                  (= step_images[step] += a_sel)
+// One wave per row, lane = image row: a raster holds ~35 pixels, so a lane walks the handful of set bits of its own row
+// instead of a [n, 4096] product / a [n, 64, 64] float image.  The images hold small integer counts: float sums of them
+// are exact in any order, so neither the wave reduction nor the float atomics change a bit of the result.
+__global__ __launch_bounds__(256) void k_bits_dot(int n_rows, const uint64_t* __restrict__ bits, const int64_t* __restrict__ bits_row,
+                                                  const float* __restrict__ img, const int64_t* __restrict__ slot,
+                                                  float* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int rv = wave; rv < n_rows; rv += nwaves) {
+        const int r = __builtin_amdgcn_readfirstlane(rv);
+        const int64_t src = bits_row ? bits_row[r] : (int64_t)r;
+        uint64_t m = bits[(size_t)src * IMG + lane];
+        const float* row = img + ((size_t)slot[r] * IMG + lane) * IMG;
+        double acc = 0.0;
+        while (m) {
+            const int x = __builtin_ctzll(m);
+            m &= m - 1ull;
+            acc += (double)row[x];
+        }
+        acc = wave_sum_d(acc);
+        if (lane == 0) out[r] = (float)acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bits_accumulate(int n_rows, const uint64_t* __restrict__ bits,
+                                                         const int64_t* __restrict__ bits_row, const float* __restrict__ weight,
+                                                         const int64_t* __restrict__ slot, float* __restrict__ img) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const int nwaves = (gridDim.x * blockDim.x) / WAVE;
+    for (int rv = wave; rv < n_rows; rv += nwaves) {
+        const int r = __builtin_amdgcn_readfirstlane(rv);
+        const float w = weight ? weight[r] : 1.f;
+        if (w == 0.f) continue;
+        const int64_t src = bits_row ? bits_row[r] : (int64_t)r;
+        uint64_t m = bits[(size_t)src * IMG + lane];
+        float* row = img + ((size_t)slot[r] * IMG + lane) * IMG;
+        while (m) {
+            const int x = __builtin_ctzll(m);
+            m &= m - 1ull;
+            atomicAdd(row + x, w);
+        }
+    }
+}
+
 // Head of the factored acting forward: q[r] = sum_j w[j] * sigmoid(d[r, j])  (cv.py:101-104: softmax over the two successor
 // channels, channel 1, times the reward map, summed over the image) in ONE pass over d instead of sigmoid / mul / sum
 // passes.  One wave per row, 16 B per lane per trip; lane partial sums in f32, the 64 partials added in f64.

@@ -59,11 +59,13 @@ __device__ __forceinline__ void reduce_to_wave0(f32x16& acc, float (*red)[16][64
 // else part[split][m][n] = out and k_lin_fwd_finish adds the splits up.
 __global__ __launch_bounds__(256) void k_lin_fwd(int K, int N, int kchunk, const float* __restrict__ x,
                                                  const float* __restrict__ W, const float* __restrict__ bias, int relu,
-                                                 float* __restrict__ y, float* __restrict__ part) {
+                                                 float* __restrict__ y, float* __restrict__ part,
+                                                 const int64_t* __restrict__ x_block) {
     __shared__ float red[3][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 32, split = blockIdx.y, m0 = blockIdx.z * 32;
     const int rows = gridDim.z * 32;
+    if (x_block) x += (size_t)(*x_block) * rows * K;              // block *x_block of a [n_blocks * rows, K] array of inputs
     const int kbeg = split * kchunk;
     const int kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
     const int kq = ((kend - kbeg + 31) / 32) * 8;                 // k values per wave, a multiple of 8
@@ -172,8 +174,10 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
                                                  const float* __restrict__ a, const float* __restrict__ W,
                                                  float* __restrict__ dW, float* __restrict__ db,
                                                  float* __restrict__ dxpart, const float* __restrict__ act_mask,
-                                                 int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk, AdamFold ad) {
+                                                 int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk, AdamFold ad,
+                                                 const int64_t* __restrict__ a_block) {
     __shared__ float red[3][16][64];
+    if (a_block) a += (size_t)(*a_block) * rows * K;              // block *a_block of a [n_blocks * rows, K] array of layer inputs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, half = lane >> 5;
     const int n_ntiles = (N + 31) / 32, n_ktiles = (K + 31) / 32;
@@ -389,7 +393,10 @@ __global__ __launch_bounds__(256) void k_mlp_input(int batch, int rows, int px, 
                                                    const float* __restrict__ obstacle, float* __restrict__ x) {
     const int K = 4 * px + nf;
     const size_t total = (size_t)rows * K;
-    const size_t base = (size_t)(*counter) * batch;
+    // counter == nullptr: blockIdx.y = the batch, x the [n_batches * rows, K] array of all batches of a train_policy_net call
+    const size_t cb = counter ? (size_t)(*counter) : (size_t)blockIdx.y;
+    if (!counter) x += cb * total;
+    const size_t base = cb * batch;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / K), c = (int)(i % K);
         float v = 0.f;

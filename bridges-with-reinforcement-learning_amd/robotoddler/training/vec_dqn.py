@@ -180,11 +180,9 @@ class VecDQN:
             step_of_row = env.n_blocks[row_env].long()
             q = self._policy_q(env, idx, row_env, stable)
             if self._factored(self.policy_net):
-                # overlap of every candidate with the count image of its episode step (exact: integer-valued sums)
-                px, ks = 64 * 64, self.step_images.shape[0]
-                counts_t = torch.zeros((px, (ks + 3) // 4 * 4), dtype=torch.float32, device=self.device)
-                counts_t[:, :ks] = self.step_images.reshape(ks, px).T
-                join = ops.bits_linear(env.cand_bits, counts_t, bits_row=idx).gather(1, step_of_row[:, None])[:, 0]
+                # overlap of every candidate with the count image of its episode step, straight from the bit-packed
+                # rasters (exact: integer-valued sums)
+                join = ops.bits_dot(env.cand_bits, self.step_images, step_of_row, bits_row=idx)
             else:
                 join = (self.step_images[step_of_row] * env.crop(env.cand_raster[idx])).sum(dim=(1, 2))
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
@@ -199,8 +197,11 @@ class VecDQN:
             # count images of the explored choices; every env takes part with weight 0 or 1, so no host decision
             # (an `if ex.any()` here would make the host wait for the Q pass it has just queued)
             rows = sel_row.clamp(max=idx.numel() - 1)
-            picked = env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])) * ex[:, None, None].to(torch.float32)
-            self.step_images.index_add_(0, step_of_row[rows], picked)
+            if env.img == 64:                                     # the set pixels of the chosen rasters, by float atomics
+                ops.bits_accumulate_(self.step_images, env.cand_bits, step_of_row[rows], weight=ex.to(torch.float32), bits_row=idx[rows])
+            else:
+                picked = env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])) * ex[:, None, None].to(torch.float32)
+                self.step_images.index_add_(0, step_of_row[rows], picked)
             sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
             self._q_sel = torch.where(has, q.float()[sel_row.clamp(max=idx.numel() - 1)], self._q_sel)
         else:
@@ -345,6 +346,10 @@ class VecDQN:
                                             optimizer=self.opt if os.environ.get("BRIDGES_FUSED_ADAM", "1") != "0" else None)
             st["reward"] = self.env.reward_features.reshape(-1).contiguous()
             st["obstacle"] = self.env.obstacle_raster.reshape(-1).contiguous()
+            # the first layer's input rows of all batches of a call are built by ONE launch before the replays
+            # (train_steps), a replayed step reads batch `counter` of them: one launch per optimiser step less
+            st["step"].allocate_inputs(n_max)
+            st["step"]._prepared = True                  # captured in the form that reads the pre-built rows
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body_fused() if st["fused"] else body()
@@ -407,6 +412,9 @@ class VecDQN:
                 st["sf"][:n].copy_(sf_target.reshape(n, -1))
             st["counter"].zero_()
             st["losses"].zero_()
+            if st.get("fused"):
+                st["step"].prepare_inputs(n_steps, st["block"].view(st["n_max"] * B, -1), st["action"].view(st["n_max"] * B, -1),
+                                          st["binary"], st["reward"], st["obstacle"])
             for _ in range(n_steps):
                 st["graph"].replay()
             if defer:

@@ -253,6 +253,15 @@ int bridges_bits_to_f32(int32_t n, const uint64_t* bits, float* img, void* strea
  * ascending p, so the result is deterministic. */
 int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* wt, int32_t d,
                         const float* base, const int64_t* base_row, float* out, void* stream);
+/* EpsilonGreedy's count-based exploration (successor_dqn.py:112-131) on bit-packed rasters, for many environments at once:
+ * bridges_bits_dot: out[r] = sum(img[slot[r]] * raster(bits[bits_row[r]])) -- the overlap of candidate r with the count image of
+ * its episode step (img [n_slots,64,64] f32, slot [n] i64; bits_row NULL = identity);
+ * bridges_bits_accumulate: img[slot[r]] += weight[r] * raster(bits[bits_row[r]]) (weight NULL = 1; float atomics on the set
+ * pixels).  The count images hold small integers, so both are exact whatever the order of the additions. */
+int bridges_bits_dot(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* img, const int64_t* slot,
+                     float* out, void* stream);
+int bridges_bits_accumulate(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* weight,
+                            const int64_t* slot, float* img, void* stream);
 /* out[r] = sum_j w[j] * sigmoid(d[r * row_stride + j]), j < k: the q head of SuccessorMLP's factored forward
  * (q = sum(softmax(psi)[:, 1] * reward_map), cv.py:101-104, with psi1 - psi0 = d) in one pass.  k % 4 == 0. */
 int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, const float* w, int32_t k, float* out,
@@ -309,14 +318,14 @@ int bridges_bias_relu_pool2(const float* x, const float* bias, float* out, int64
  * `ws` = scratch for split partial sums (ws_floats floats; the split count adapts to it). */
 /* y [rows,N] = act(x [rows,K] . W [N,K]^T + bias), act = ReLU if relu else identity (nn.Linear [+ nn.ReLU], cv.py:20-38). */
 int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, const float* W, const float* bias,
-                           int32_t relu, float* y, float* ws, int64_t ws_floats, void* stream);
+                           int32_t relu, float* y, float* ws, int64_t ws_floats, const int64_t* x_block, void* stream);
 /* Backward of the same layer from dz [rows,N] (gradient at its pre-activation) and its input a_in [rows,K]:
  * dW [N,K] = dz^T . a_in, db [N] = column sums of dz, and -- unless dz_below is NULL (first layer) --
  * dz_below [rows,K] = (dz . W) masked by act_below > 0 (act_below = the ReLU output that was this layer's input; NULL =
  * no mask). */
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
-                            void* stream);
+                            const int64_t* a_block, void* stream);
 /* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
  * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
  * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further
@@ -325,12 +334,19 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
                                  float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
                                  const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
-                                 double lr, double beta1, double beta2, double eps, void* stream);
+                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, void* stream);
 /* Input rows of replay batch *counter: x [rows, 4 px + nf] = [block | action | reward | obstacle | binary]
  * (cv.py:100-103) from block_all / action_all [n,px], binary_all [n,nf] (row *counter * batch + b), reward / obstacle [px]. */
 int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
                       const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
                       float* x, void* stream);
+/* The same rows for ALL n_batches batches of a train_policy_net call in one launch: x_all [n_batches * rows, 4 px + nf], batch c in
+ * rows [c * rows, (c + 1) * rows).  bridges_linear_forward / _backward / _backward_adam take a device word `x_block` /
+ * `a_block` (may be NULL = 0) that selects the block of such an array (x + *x_block * rows * K), so a replayed graph of one
+ * optimiser step reads batch *counter of the pre-built inputs instead of building its rows first. */
+int bridges_mlp_input_batches(int32_t n_batches, int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* block_all,
+                              const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
+                              float* x_all, void* stream);
 /* Head + loss + its gradient (cv.py:104-108; successor_dqn.py:215-232): y [rows, 2 px + 2 nf] = (psi0 | psi1 | binary),
  * q = sum_j softmax(psi)[1][j] * reward[j], loss = [use_q] mean (q - q_target)^2 + [use_sf] mean (psi0 - sf_target)^2
  * with the targets of batch *counter (q_target_all [n], sf_target_all [n,px]).  Writes dy [rows, 2 px + 2 nf],

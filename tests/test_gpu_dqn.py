@@ -191,6 +191,38 @@ def test_bits_linear_matches_the_dense_product(d):
     assert torch.equal(got.cpu(), dense.reshape(n_img, 4096).float() @ cnt)
 
 
+def test_bits_dot_and_accumulate_match_the_dense_count_images():
+    """bridges_bits_dot / bridges_bits_accumulate: EpsilonGreedy's overlap  sum(step_images[step] * a)  and its update
+    step_images[step] += a_sel  (successor_dqn.py:127-131) on bit-packed rasters, against the dense float images -- exact
+    (the count images hold small integers)."""
+    from bridges_hip import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_img, n, slots = 60, 500, 11
+    dense = (torch.rand((n_img, 64, 64), generator=g) < 0.02)
+    dense[3] = False
+    dense[4] = True
+    weights = (1 << torch.arange(63, dtype=torch.int64))
+    bits = (dense[:, :, :63].to(torch.int64) * weights).sum(dim=2)
+    bits = torch.where(dense[:, :, 63], bits | torch.tensor(-(1 << 63), dtype=torch.int64), bits)
+    img = torch.randint(0, 7, (slots, 64, 64), generator=g).float()
+    rows = torch.randint(0, n_img, (n,), generator=g)
+    slot = torch.randint(0, slots, (n,), generator=g)
+    got = ops.bits_dot(bits.to(dev), img.to(dev), slot.to(dev), bits_row=rows.to(dev))
+    want = (img[slot] * dense[rows].float()).sum(dim=(1, 2))
+    assert torch.equal(got.cpu(), want)
+    w = (torch.rand(n, generator=g) < 0.6).float()
+    acc = img.clone().to(dev)
+    ops.bits_accumulate_(acc, bits.to(dev), slot.to(dev), weight=w.to(dev), bits_row=rows.to(dev))
+    ref = img.clone()
+    ref.index_add_(0, slot, dense[rows].float() * w[:, None, None])
+    assert torch.equal(acc.cpu(), ref)
+    # identity rows, unit weights
+    acc2 = torch.zeros((n_img, 64, 64), device=dev)
+    ops.bits_accumulate_(acc2, bits.to(dev), torch.arange(n_img, device=dev))
+    assert torch.equal(acc2.cpu(), dense.float())
+
+
 def test_sigmoid_dot_matches_torch():
     """bridges_sigmoid_dot: sum_j w[j] * sigmoid(d[r, j]) in one pass (the q head of the factored SuccessorMLP forward)."""
     from bridges_hip import ops

@@ -197,3 +197,33 @@ def test_flat_adam_launch_follows_torch_adam():
     vd = 0.999 * v0.double() + (1 - 0.999) * gr.double() ** 2
     pd = p0.double() - (1e-3 / (1 - 0.9 ** 7)) * md / (vd.sqrt() / (1 - 0.999 ** 7) ** 0.5 + 1e-8)
     assert rel_err(m1, md.float()) < 1e-6 and rel_err(v1, vd.float()) < 1e-6 and rel_err(p1, pd.float()) < 2e-6
+
+
+def test_prebuilt_input_rows_give_the_same_steps():
+    """allocate_inputs / prepare_inputs (all batches' first-layer rows in one launch, a step reads block `counter` of them)
+    against the per-step build of the rows: identical losses, q values and gradients, bit for bit."""
+    from bridges_hip.mlp_ops import FusedSuccessorStep
+    B, size, n_batches = 32, 64, 3
+    batch = make_batch(n_batches * B, size, seed=21)
+    block, action, binary, reward, obstacle, q_t, sf_t = batch
+    px = size * size
+    rw, ob = reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous()
+    out = {}
+    for mode in ("per_step", "prebuilt"):
+        net = make_net(seed=4)
+        fused = FusedSuccessorStep(net, B, True, True)
+        if mode == "prebuilt":
+            fused.allocate_inputs(n_batches)
+            fused.prepare_inputs(n_batches, block.reshape(-1, px), action.reshape(-1, px), binary, rw, ob)
+        counter = torch.zeros((), dtype=torch.int64, device=DEV)
+        losses = torch.zeros(n_batches, device=DEV)
+        rec = []
+        for i in range(n_batches):
+            fused.launch(counter, block.reshape(-1, px), action.reshape(-1, px), binary, rw, ob, q_t, sf_t, losses)
+            rec.append((fused.q[:B].clone(), [p.grad.clone() for p in net.parameters()]))
+        out[mode] = (losses.clone(), rec)
+    assert torch.equal(out["per_step"][0], out["prebuilt"][0])
+    for (qa, ga), (qb, gb) in zip(out["per_step"][1], out["prebuilt"][1]):
+        assert torch.equal(qa, qb)
+        for x, y in zip(ga, gb):
+            assert torch.equal(x, y)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--replays", type=int, default=400)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--per-step-inputs", action="store_true", help="build the first layer's input rows inside every step (round 2)")
     ap.add_argument("--torch-adam", action="store_true", help="hand-written step + torch's fused Adam launch (the round-2 step)")
     args = ap.parse_args()
     from bridges_hip.mlp_ops import FusedSuccessorStep
@@ -63,6 +64,9 @@ def main():
         net._flat_params = FlatParameters(net)
         step = FusedSuccessorStep(net, B, True, True, optimizer=None if (args.torch_adam or args.no_adam) else opt)
         rw, ob = reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous()
+        if not args.per_step_inputs:                     # as VecDQN.train_steps does: all batches' input rows in one launch
+            step.allocate_inputs(n_b)
+            step.prepare_inputs(n_b, block.view(n, px), action.view(n, px), binary, rw, ob)
 
         def body():
             step.launch(counter, block.view(n, px), action.view(n, px), binary, rw, ob, q_t, sf_t, losses)
