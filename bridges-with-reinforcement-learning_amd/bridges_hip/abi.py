@@ -187,12 +187,12 @@ def lib():
         "bridges_conv3x3_relu_o16_ex": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
         "bridges_upconv2x2": [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp],
         "bridges_linear_forward": [i32, i32, i32, vp, vp, vp, i32, vp, vp, i64, vp, vp],
-        "bridges_linear_backward": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp],
+        "bridges_linear_backward": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, vp],
         "bridges_mlp_input": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_mlp_input_batches": [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
         "bridges_successor_loss": [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp],
         "bridges_adam_step": [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp],
-        "bridges_linear_backward_adam": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp, vp],
+        "bridges_linear_backward_adam": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp, i32, vp],
         "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
     }
     for name, argtypes in sigs.items():

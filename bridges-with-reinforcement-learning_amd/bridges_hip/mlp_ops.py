@@ -35,7 +35,7 @@ def linear_backward(dz, a_in, weight, act_below=None, need_input_grad=True, ws=N
     below = torch.empty((rows, K), dtype=torch.float32, device=dz.device) if need_input_grad else None
     ws = torch.empty(1 << 20, dtype=torch.float32, device=dz.device) if ws is None else ws
     abi.check(L.bridges_linear_backward(rows, K, N, _ptr(dz), _ptr(a_in), _ptr(weight), _ptr(dW), _ptr(db), _ptr(act_below),
-                                        _ptr(below), _ptr(ws), ws.numel(), None, _stream()), "bridges_linear_backward")
+                                        _ptr(below), _ptr(ws), ws.numel(), None, 0, _stream()), "bridges_linear_backward")
     return dW, db, below
 
 
@@ -217,13 +217,13 @@ class FusedSuccessorStep:
                                                          _ptr(lin.weight), _ptr(lin.bias), _ptr(mw), _ptr(vw), _ptr(mb), _ptr(vb),
                                                          off(self.flat), off(self.grad_flat), off(self.m_flat), off(self.v_flat),
                                                          hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, blk,
-                                                         st), "bridges_linear_backward_adam")
+                                                         -1, st), "bridges_linear_backward_adam")      # -1: the loss kernel advanced the counter
                 continue
             abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]),
                                                 _ptr(x0 if l == 0 else self.acts[l]), _ptr(lin.weight), _ptr(lin.weight.grad),
                                                 _ptr(lin.bias.grad), _ptr(self.acts[l]) if l > 0 else None,
                                                 _ptr(self.dz[l - 1]) if l > 0 else None, _ptr(self.ws), self.ws.numel(),
-                                                blk if l == 0 else None, st), "bridges_linear_backward")
+                                                blk if l == 0 else None, -1 if l == 0 else 0, st), "bridges_linear_backward")
         if self.fused_adam and not fold_first:               # larger batches: one flat launch behind the backward pass
             abi.check(L.bridges_adam_step(_ptr(self.flat), _ptr(self.grad_flat), _ptr(self.m_flat), _ptr(self.v_flat),
                                           self.flat.numel(), _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, st),

@@ -607,7 +607,7 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
 
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
-                            const int64_t* a_block, void* stream) {
+                            const int64_t* a_block, int32_t a_block_bias, void* stream) {
     if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !dz || !a_in || !W || !dW || !db) return fail_arg("bridges_linear_backward");
     const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32), m_tiles = rows / 32;
     int per_job = ceil_div(n_ntiles * n_ktiles, 1024);           // k tiles per dW job: ~1024 jobs on the big layers
@@ -630,7 +630,7 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
     // one split: the input gradient goes straight to dz_below (masked), no partial sums
     hipLaunchKernelGGL(k_lin_bwd<false>, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
                        !dz_below ? (float*)nullptr : (nsplit == 1 ? dz_below : ws), nsplit == 1 ? act_below : (const float*)nullptr,
-                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{}, a_block);
+                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{}, a_block, (int)a_block_bias);
     LAUNCH_CHECK("k_lin_bwd");
     if (dz_below && nsplit > 1) {
         int blocks = ceil_div(rows * K, 256);
@@ -644,7 +644,8 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
                                  float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
                                  const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
-                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, void* stream) {
+                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, int32_t a_block_bias,
+                                 void* stream) {
     if (rows != 32 || K <= 0 || N <= 0 || !dz || !a_in || !W || !bias || !exp_avg_w || !exp_avg_sq_w || !exp_avg_b || !exp_avg_sq_b || !step)
         return fail_arg("bridges_linear_backward_adam: one 32-row batch tile, all buffers given");
     if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail_arg("bridges_linear_backward_adam: hyper-parameters");
@@ -665,7 +666,7 @@ int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float
                 rest_param, rest_grad, rest_exp_avg, rest_exp_avg_sq, (long long)rest_n};
     hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
                        (const float*)W, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job,
-                       0, 0, ad, a_block);
+                       0, 0, ad, a_block, (int)a_block_bias);
     LAUNCH_CHECK("k_lin_bwd<adam>");
     return BRIDGES_OK;
 }

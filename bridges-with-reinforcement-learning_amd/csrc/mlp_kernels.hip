@@ -175,9 +175,11 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
                                                  float* __restrict__ dW, float* __restrict__ db,
                                                  float* __restrict__ dxpart, const float* __restrict__ act_mask,
                                                  int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk, AdamFold ad,
-                                                 const int64_t* __restrict__ a_block) {
+                                                 const int64_t* __restrict__ a_block, int a_block_bias) {
     __shared__ float red[3][16][64];
-    if (a_block) a += (size_t)(*a_block) * rows * K;              // block *a_block of a [n_blocks * rows, K] array of layer inputs
+    // block *a_block + a_block_bias of a [n_blocks * rows, K] array of layer inputs (bias -1: the step's loss kernel has
+    // already advanced the batch counter the forward pass read)
+    if (a_block) a += (size_t)(*a_block + a_block_bias) * rows * K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, half = lane >> 5;
     const int n_ntiles = (N + 31) / 32, n_ktiles = (K + 31) / 32;

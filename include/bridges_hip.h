@@ -325,7 +325,7 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
  * no mask). */
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
-                            const int64_t* a_block, void* stream);
+                            const int64_t* a_block, int32_t a_block_bias, void* stream);
 /* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
  * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
  * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further
@@ -334,7 +334,8 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
                                  float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
                                  const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,
-                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, void* stream);
+                                 double lr, double beta1, double beta2, double eps, const int64_t* a_block, int32_t a_block_bias,
+                                 void* stream);
 /* Input rows of replay batch *counter: x [rows, 4 px + nf] = [block | action | reward | obstacle | binary]
  * (cv.py:100-103) from block_all / action_all [n,px], binary_all [n,nf] (row *counter * batch + b), reward / obstacle [px]. */
 int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const int64_t* counter, const float* block_all,
@@ -342,8 +343,9 @@ int bridges_mlp_input(int32_t batch, int32_t rows, int32_t px, int32_t nf, const
                       float* x, void* stream);
 /* The same rows for ALL n_batches batches of a train_policy_net call in one launch: x_all [n_batches * rows, 4 px + nf], batch c in
  * rows [c * rows, (c + 1) * rows).  bridges_linear_forward / _backward / _backward_adam take a device word `x_block` /
- * `a_block` (may be NULL = 0) that selects the block of such an array (x + *x_block * rows * K), so a replayed graph of one
- * optimiser step reads batch *counter of the pre-built inputs instead of building its rows first. */
+ * `a_block` (may be NULL = 0) that selects the block of such an array (x + *x_block * rows * K; the backward entry points add the
+ * host constant a_block_bias to the word: -1 when the step's loss kernel has advanced the counter in between), so a replayed
+ * graph of one optimiser step reads batch *counter of the pre-built inputs instead of building its rows first. */
 int bridges_mlp_input_batches(int32_t n_batches, int32_t batch, int32_t rows, int32_t px, int32_t nf, const float* block_all,
                               const float* action_all, const float* binary_all, const float* reward, const float* obstacle,
                               float* x_all, void* stream);
