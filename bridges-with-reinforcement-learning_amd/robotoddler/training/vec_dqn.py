@@ -406,15 +406,18 @@ class VecDQN:
         st = self._train_graph(n_steps, use_sf)
         if st is not None:
             n = n_steps * B
-            st["block"][:n].copy_(block_f); st["binary"][:n].copy_(binary); st["action"][:n].copy_(action_f)
+            if st.get("fused"):
+                # the first layer's input rows of all n_steps batches in one launch, straight from the target pass's tensors
+                # (no staging copy of the 13 MB block / action images: a replayed step reads only x_all, q and sf)
+                st["step"].prepare_inputs(n_steps, block_f.reshape(n, -1).contiguous(), action_f.reshape(n, -1).contiguous(),
+                                          binary.contiguous(), st["reward"], st["obstacle"])
+            else:
+                st["block"][:n].copy_(block_f); st["binary"][:n].copy_(binary); st["action"][:n].copy_(action_f)
             st["q"][:n].copy_(q_target)
             if use_sf:
                 st["sf"][:n].copy_(sf_target.reshape(n, -1))
             st["counter"].zero_()
             st["losses"].zero_()
-            if st.get("fused"):
-                st["step"].prepare_inputs(n_steps, st["block"].view(st["n_max"] * B, -1), st["action"].view(st["n_max"] * B, -1),
-                                          st["binary"], st["reward"], st["obstacle"])
             for _ in range(n_steps):
                 st["graph"].replay()
             if defer:
