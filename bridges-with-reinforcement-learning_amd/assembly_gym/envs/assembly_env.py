@@ -160,6 +160,57 @@ def is_stable_rbe(assembly_env):
     return f(assembly_env)
 
 
+class _StateInfo(dict):
+    """AssemblyEnv.state_info with the stability verdict computed on first access ('stable' / 'stability_info'), for the
+    (blocks, frozen set) the environment held when the dictionary was made."""
+    _LAZY = ("stable", "stability_info")
+
+    def __init__(self, env, base):
+        super().__init__(base)
+        self._env = env
+        self._snapshot = [(b, bool(b.is_static)) for b in env.blocks]
+        self._solved = False
+
+    def _solve(self, memo=True):
+        if not self._solved:
+            self._solved = True
+            is_stable, info = self._env._solve_state(self._snapshot, memo=memo)
+            dict.__setitem__(self, "stable", is_stable)
+            dict.__setitem__(self, "stability_info", info)
+
+    def __getitem__(self, key):
+        if key in self._LAZY:
+            self._solve()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key in self._LAZY:
+            self._solve()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key in self._LAZY or dict.__contains__(self, key)
+
+    def _all(self):
+        self._solve()
+        return self
+
+    def keys(self):
+        return dict.keys(self._all())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+    def __iter__(self):
+        return dict.__iter__(self._all())
+
+    def __repr__(self):
+        return dict.__repr__(self._all())
+
+
 class AssemblyEnv:
     """assembly_env.py:160-438 without the optional pybullet client."""
 
@@ -201,25 +252,41 @@ class AssemblyEnv:
         return self.bounds[1][1] - self.bounds[0][1]
 
     def _update_state_info(self):
-        self._state_info = {
+        """assembly_env.py:306-331: the state dictionary incl. the stability verdict.  The verdict of a state that nobody
+        reads is never computed (``add_block`` updates the state and ``AssemblyGym.step`` updates it again before anything
+        looks: one of the reference's five solves per env-step), and a (blocks, frozen set) pair that was solved before
+        is looked up -- the solver is a pure function of the pair (three of the remaining four)."""
+        self._state_info = _StateInfo(self, {
             "last_block": self.blocks[-1] if self.blocks else None,
             "collision": False,                                        # no pybullet client (assembly_env.py:311-312)
             "collision_info": {"obstacles": [], "blocks": [], "floor": False, "bounding_box": False},
             "frozen_block": self.frozen_block_index,
-        }
-        # the reference re-solves the same assembly several times per env-step (add_block, step's _update_state_info and
-        # the three calls of stabilities_freezing see only two or three distinct (blocks, frozen set) pairs); the
-        # solver is a pure function of those, so a verdict is computed once per distinct pair and looked up afterwards
-        key = (tuple(id(b) for b in self.blocks), tuple(bool(b.is_static) for b in self.blocks), float(self.mu),
-               float(self.density), id(self.stability_fct))
-        memo = self._stability_memo
-        if key not in memo or os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":
-            if len(memo) > 64:
-                memo.clear()
-            memo[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique
-        (is_stable, info), _ = memo[key]
-        self._state_info["stable"] = is_stable
-        self._state_info["stability_info"] = info
+        })
+        if os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":     # A/B switch: solve at once, every time
+            self._state_info._solve(memo=False)
+
+    def _solve_state(self, snapshot, memo=True):
+        """(is_stable, info) of the assembly as it was when ``snapshot`` = [(block, is_static), ...] was taken."""
+        blocks_now, flags_now = self.blocks, [b.is_static for b in self.blocks]
+        same = len(snapshot) == len(blocks_now) and all(b is c and f == g for (b, f), c, g in zip(snapshot, blocks_now, flags_now))
+        if not same:                                                   # evaluate the recorded state, then put the present one back
+            self.blocks = [b for b, _ in snapshot]
+            for b, f in snapshot:
+                b.is_static = f
+        try:
+            key = (tuple(id(b) for b in self.blocks), tuple(bool(b.is_static) for b in self.blocks), float(self.mu),
+                   float(self.density), id(self.stability_fct))
+            cache = self._stability_memo
+            if not memo or key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                cache[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique
+            return cache[key][0]
+        finally:
+            if not same:
+                self.blocks = blocks_now
+                for b, f in zip(blocks_now, flags_now):
+                    b.is_static = f
 
     def add_block(self, block):
         self.blocks.append(block)

@@ -224,14 +224,27 @@ __global__ __launch_bounds__(256) void k_sigmoid_dot(int n_rows, const float* __
     for (int r = wave; r < n_rows; r += nwaves) {
         const float* row = d + (size_t)r * row_stride;
         float acc = 0.f;
-        for (int j = 4 * lane; j < k; j += 4 * WAVE) {
+        // four 16-B loads of the row in flight per lane and trip (a 64 x 64 image: four trips), the sigmoid through the
+        // hardware reciprocal (1 ulp; a full float32 division is ~10 instructions per pixel and made the pass ALU-heavy)
+#define SIGDOT_ONE(X, WW)                                                     \
+    acc += WW.x * __builtin_amdgcn_rcpf(1.f + __expf(-X.x));                 \
+    acc += WW.y * __builtin_amdgcn_rcpf(1.f + __expf(-X.y));                 \
+    acc += WW.z * __builtin_amdgcn_rcpf(1.f + __expf(-X.z));                 \
+    acc += WW.w * __builtin_amdgcn_rcpf(1.f + __expf(-X.w));
+        int j = 4 * lane;
+        for (; j + 12 * WAVE < k; j += 16 * WAVE) {
+            const float4 x0 = *reinterpret_cast<const float4*>(row + j), x1 = *reinterpret_cast<const float4*>(row + j + 4 * WAVE);
+            const float4 x2 = *reinterpret_cast<const float4*>(row + j + 8 * WAVE), x3 = *reinterpret_cast<const float4*>(row + j + 12 * WAVE);
+            const float4 w0 = *reinterpret_cast<const float4*>(w + j), w1 = *reinterpret_cast<const float4*>(w + j + 4 * WAVE);
+            const float4 w2 = *reinterpret_cast<const float4*>(w + j + 8 * WAVE), w3 = *reinterpret_cast<const float4*>(w + j + 12 * WAVE);
+            SIGDOT_ONE(x0, w0) SIGDOT_ONE(x1, w1) SIGDOT_ONE(x2, w2) SIGDOT_ONE(x3, w3)
+        }
+        for (; j < k; j += 4 * WAVE) {
             const float4 x = *reinterpret_cast<const float4*>(row + j);
             const float4 ww = *reinterpret_cast<const float4*>(w + j);
-            acc += ww.x / (1.f + __expf(-x.x));
-            acc += ww.y / (1.f + __expf(-x.y));
-            acc += ww.z / (1.f + __expf(-x.z));
-            acc += ww.w / (1.f + __expf(-x.w));
+            SIGDOT_ONE(x, ww)
         }
+#undef SIGDOT_ONE
         const double total = wave_sum_d((double)acc);
         if (lane == 0) out[r] = (float)total;
     }
