@@ -593,7 +593,7 @@ __device__ __forceinline__ void write_f32_image(float* img, uint64_t rowbits, in
 // X / Y: this lane's column / row coordinate (lanes >= n_img repeat the last grid value); n_img = S <= 64.
 __device__ __forceinline__ uint64_t low_mask64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
 
-template <int NF>
+template <int NF, int F0 = 0>
 __device__ __forceinline__ uint64_t raster_rows(double fr0, double fr1, double fr2, double fr3, int n_img, double X, double Y,
                                                 int lane) {
     int alo[NF], ahi[NF], pos[NF];
@@ -601,7 +601,7 @@ __device__ __forceinline__ uint64_t raster_rows(double fr0, double fr1, double f
     bool rev[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const double cxf = readlane_d(fr0, f), czf = readlane_d(fr1, f), nxf = readlane_d(fr2, f), nzf = readlane_d(fr3, f);
+        const double cxf = readlane_d(fr0, F0 + f), czf = readlane_d(fr1, F0 + f), nxf = readlane_d(fr2, F0 + f), nzf = readlane_d(fr3, F0 + f);
         const double a = (X - cxf) * nxf;               // column role
         t[f] = -((Y - czf) * nzf);                      // row role: pixel (r, x) passes face f iff a[x] <= t[r]
         alo[f] = __double2loint(a);
@@ -629,9 +629,15 @@ __device__ __forceinline__ uint64_t raster_rows(double fr0, double fr1, double f
     return lane < n_img ? bits : 0ull;                  // rows >= S stay empty
 }
 
+// six faces as two batches of three (the searches of a batch run interleaved; one batch of six keeps 30 values per lane
+// alive and costs the kernel two of its eight waves per SIMD)
+__device__ __forceinline__ uint64_t raster_rows6(double fr0, double fr1, double fr2, double fr3, int n_img, double X, double Y, int lane) {
+    return raster_rows<3, 0>(fr0, fr1, fr2, fr3, n_img, X, Y, lane) & raster_rows<3, 3>(fr0, fr1, fr2, fr3, n_img, X, Y, lane);
+}
+
 __device__ __forceinline__ uint64_t raster_rows_nv(double fr0, double fr1, double fr2, double fr3, int nv, int n_img, double X,
                                                    double Y, int lane) {
-    return nv <= 4 ? raster_rows<4>(fr0, fr1, fr2, fr3, n_img, X, Y, lane) : raster_rows<MAXV>(fr0, fr1, fr2, fr3, n_img, X, Y, lane);
+    return nv <= 4 ? raster_rows<4>(fr0, fr1, fr2, fr3, n_img, X, Y, lane) : raster_rows6(fr0, fr1, fr2, fr3, n_img, X, Y, lane);
 }
 
 // sum(raster * reward_map) from the row runs: the pixels of a row of a convex outline are one run [lo, hi), so the
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(256) void k_raster(DevCtx c) {
             const uint64_t occ = c.b.state_bits[(size_t)e * IMG + lane] | obst;
             uint64_t bits = 0ull;
             if (!DIAG(c, 2)) bits = (NF == 4 || nv <= 4) ? raster_rows<4>(fr0, fr1, fr2, fr3, c.img, X, Y, lane)
-                                                         : raster_rows<MAXV>(fr0, fr1, fr2, fr3, c.img, X, Y, lane);
+                                                         : raster_rows6(fr0, fr1, fr2, fr3, c.img, X, Y, lane);
             const bool overlap = __ballot((bits & occ) != 0ull) != 0ull;
             double p_hi, p_lo;
             raster_reward_fetch(bits, c.b.reward_prefix, lane, p_hi, p_lo);
