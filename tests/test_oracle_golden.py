@@ -103,3 +103,62 @@ def test_shape_tables_match_reference_meshes(name):
     assert edges_ref == edges_tab
     assert [tuple(v) for v in verts] == s.verts and [tuple(f) for f in faces] == s.faces
     assert depth == s.depth
+
+
+def test_row_run_rasteriser_algorithm_equals_the_per_pixel_test():
+    """The HIP rasteriser (csrc/env_kernels.hip: raster_rows) does not visit pixels: per face it compares a[x] = fl(fl(X[x] -
+    c.x) n.x) with t[r] = -fl(fl(Y[r] - c.z) n.z) and finds, by a binary search over the monotone a[.], the prefix (n.x >= 0)
+    or suffix (n.x < 0) of row r that passes.  This is that algorithm in numpy, probe for probe, against the reference's
+    per-pixel test  fl(a + b) <= 0  (oracle/raster.py: contains_2d) on random and degenerate placements (edges through
+    sample points, axis-aligned faces, blocks outside the image) at three image sizes: identical rasters."""
+    import math
+    from oracle import raster as o_raster
+    from oracle.geometry import Block
+    from oracle.shapes import get_shape
+
+    def row_runs(block, X, Y):
+        S = len(X)
+        Xp = np.concatenate([X, np.full(64 - S, X[-1])])             # lanes beyond the image repeat the last grid value
+        Yp = np.concatenate([Y, np.full(64 - S, Y[-1])])
+        bits = np.full(64, (1 << S) - 1, dtype=object)
+        for (c, _t, n) in block.frames:
+            a = (Xp - c[0]) * n[0]
+            t = -((Yp - c[1]) * n[1])
+            rev = n[0] < 0.0
+            pos = np.zeros(64, dtype=int)
+            for s, inc in ((31, 32), (15, 16), (7, 8), (3, 4), (1, 2), (0, 1), (0, 1)):
+                j = pos + s
+                src = 63 - j if rev else j
+                pos = pos + np.where(a[src] <= t, inc, 0)
+            for r in range(64):
+                p = int(pos[r])
+                run = ((1 << 64) - 1) if p >= 64 else ((1 << p) - 1)
+                if rev:
+                    run = 0 if p == 0 else (((1 << 64) - 1) & ~((1 << (64 - p)) - 1) if p < 64 else (1 << 64) - 1)
+                bits[r] = bits[r] & run
+        img = np.zeros((S, S), dtype=bool)
+        for r in range(S):
+            for x in range(S):
+                img[r, x] = bool((int(bits[r]) >> x) & 1)
+        return img
+
+    rng = np.random.default_rng(11)
+    checked = on_edge = 0
+    for S in (64, 33, 17):
+        X, Y = o_raster.pixel_grid((-3.0, 7.0), (0.0, 10.0), (S, S))
+        for name in ("trapezoid", "hexagon", "cube06", "cube1", "block"):
+            for k in range(8):
+                ang = [0.0, math.pi / 2, math.pi / 4, math.pi, rng.uniform(0, 2 * math.pi)][k % 5]
+                x, z = float(X[rng.integers(0, S)]), float(Y[rng.integers(0, S)])
+                if k == 6:
+                    x, z = -3.3, 5.0                                     # hanging over the left border
+                if k == 7:
+                    x, z = 6.9, 10.2                                     # over the top right corner
+                b = Block(get_shape(name), (x, z), (math.cos(ang), math.sin(ang)))
+                want = o_raster.contains_2d(b, X, Y)
+                assert np.array_equal(row_runs(b, X, Y), want), (S, name, x, z, ang)
+                checked += 1
+                for (c, _t, n) in b.frames:
+                    d = ((X - c[0]) * n[0])[None, :] + ((Y - c[1]) * n[1])[:, None]
+                    on_edge += int((d == 0).sum())
+    assert checked == 120 and on_edge > 20

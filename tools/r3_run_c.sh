@@ -5,7 +5,7 @@ mkdir -p $out
 timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; rc=$?
 tail -8 $out/tests.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python tools/single_env_throughput.py --count_syncs > $out/single_env.json 2> $out/single_env.err; tail -2 $out/single_env.json $out/single_env.err
+timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -1; timeout -k 10 300 python tools/single_env_throughput.py --count_syncs > $out/single_env.json 2> $out/single_env.err; cut -c1-300 $out/single_env.json
 timeout -k 10 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err; rc=$?
 python - <<PY
 import json
