@@ -519,6 +519,26 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
+int bridges_head_sigmoid_dot(int32_t n_rows, int32_t K, int32_t N, const float* h, int64_t h_stride, const float* Wd,
+                             const float* bd, const float* w, float* out, float* part, int32_t splits, void* stream) {
+    if (n_rows < 0 || N <= 0 || !h || !Wd || !bd || !w || !out || splits < 1 || (splits > 1 && !part))
+        return fail_arg("bridges_head_sigmoid_dot");
+    if (K != HEAD_K) return fail_arg("bridges_head_sigmoid_dot: the hidden width must be 256");
+    if ((h_stride & 3) || h_stride < K || ((((uintptr_t)h) | ((uintptr_t)Wd)) & 15)) return fail_arg("bridges_head_sigmoid_dot: rows must be 16-byte aligned");
+    if (n_rows == 0) return BRIDGES_OK;
+    const int tiles = (N + HEAD_BN - 1) / HEAD_BN;
+    const int per = (tiles + splits - 1) / splits;
+    const int used = (tiles + per - 1) / per;                             // ranges that hold at least one tile
+    hipLaunchKernelGGL(k_head_sigmoid_dot, dim3((unsigned)((n_rows + 127) / 128), (unsigned)used), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, N, h, h_stride, Wd, bd, w, used > 1 ? part : out, per);
+    LAUNCH_CHECK("k_head_sigmoid_dot");
+    if (used > 1) {
+        hipLaunchKernelGGL(k_head_sum, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_rows, used, part, out);
+        LAUNCH_CHECK("k_head_sum");
+    }
+    return BRIDGES_OK;
+}
+
 int bridges_bits_dot(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* img, const int64_t* slot,
                      float* out, void* stream) {
     if (n_rows < 0 || !bits || !img || !slot || !out) return fail_arg("bridges_bits_dot");

@@ -538,4 +538,110 @@ __global__ void k_loss_log(int batch, const float* __restrict__ loss_rows, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Head of the factored acting forward, fused: q[r] = sum_j w[j] * sigmoid(h[r,:] . Wd[j,:] + bd[j]) for n rows, K = 256
+// hidden units, N = px outputs (cv.py:101-104 with channel 1 of the softmax over the two successor channels =
+// sigmoid(psi1 - psi0); SuccessorMLP.q_from_first_layer).  The [n, 4096] product is never written: the library GEMM
+// stored 737 MB for the 45 k candidate rows of a lock-step and k_sigmoid_dot read them back.
+// One workgroup = 128 rows (a 32-row slab per wave, held in 128 VGPRs for the whole kernel: lane l keeps
+// A[row = l & 31][k = 8u + 4 (l >> 5) + {0..3}], u < 32) x all N columns in tiles of 32: the tile of Wd (32 x 256) is staged
+// in LDS (row stride 260 floats: conflict-free 16-B reads), double-buffered, the next tile's global loads in flight under
+// this tile's 128 v_mfma_f32_32x32x2_f32; the sigmoid-weighted sum of a tile runs on the vector pipes from the accumulators.
+#define HEAD_K 256
+#define HEAD_BN 32
+#define HEAD_LDS_STRIDE (HEAD_K + 4)
+__global__ __launch_bounds__(256) void k_head_sigmoid_dot(int n_rows, int N, const float* __restrict__ h, int64_t h_stride,
+                                                          const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                          const float* __restrict__ w, float* __restrict__ out,
+                                                          int tiles_per_split) {
+    __shared__ __attribute__((aligned(16))) float sB[2][HEAD_BN * HEAD_LDS_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, half = lane >> 5;
+    const int r0 = blockIdx.x * 128 + wave * 32;
+    const int my_row = (r0 + row < n_rows) ? r0 + row : n_rows - 1;      // rows beyond n are computed on a valid row, never stored
+    // A slab of this wave in registers
+    f4u a[HEAD_K / 8];
+    {
+        const float* hp = h + (size_t)my_row * h_stride + 4 * half;
+#pragma unroll
+        for (int u = 0; u < HEAD_K / 8; ++u) a[u] = *reinterpret_cast<const f4u*>(hp + 8 * u);
+    }
+    // staging of a Wd tile: thread t copies 32 floats of row t >> 3
+    const int srow = threadIdx.x >> 3, sseg = threadIdx.x & 7;
+    float4 s0, s1, s2, s3, s4, s5, s6, s7;                               // named, not an array behind a lambda: that went to scratch
+#define HEAD_LOAD_TILE(n0_)                                                                                             \
+    {                                                                                                                   \
+        const int nr_ = ((n0_) + srow < N) ? (n0_) + srow : N - 1;                                                      \
+        const float4* src_ = reinterpret_cast<const float4*>(Wd + (size_t)nr_ * HEAD_K + sseg * 32);                    \
+        s0 = src_[0]; s1 = src_[1]; s2 = src_[2]; s3 = src_[3]; s4 = src_[4]; s5 = src_[5]; s6 = src_[6]; s7 = src_[7]; \
+    }
+#define HEAD_STORE_TILE(buf_)                                                                                           \
+    {                                                                                                                   \
+        float4* dst_ = reinterpret_cast<float4*>(&sB[buf_][srow * HEAD_LDS_STRIDE + sseg * 32]);                        \
+        dst_[0] = s0; dst_[1] = s1; dst_[2] = s2; dst_[3] = s3; dst_[4] = s4; dst_[5] = s5; dst_[6] = s6; dst_[7] = s7; \
+    }
+    float qacc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
+    // blockIdx.y = a range of column tiles (the launch is cut so that the workgroups fill the CUs evenly); its sums go to
+    // out[blockIdx.y * n_rows + r] and k_head_sum adds the ranges up in a fixed order
+    const int all_tiles = (N + HEAD_BN - 1) / HEAD_BN;
+    const int t_beg = blockIdx.y * tiles_per_split;
+    const int n_tiles = (t_beg + tiles_per_split < all_tiles) ? t_beg + tiles_per_split : all_tiles;
+    out += (size_t)blockIdx.y * n_rows;
+    HEAD_LOAD_TILE(t_beg * HEAD_BN);
+    HEAD_STORE_TILE(t_beg & 1);
+    __syncthreads();
+    for (int t = t_beg; t < n_tiles; ++t) {
+        const int buf = t & 1, n0 = t * HEAD_BN;
+        if (t + 1 < n_tiles) HEAD_LOAD_TILE(n0 + HEAD_BN);                  // in flight under the MFMAs below
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bp = &sB[buf][row * HEAD_LDS_STRIDE + 4 * half];
+        float4 b[4], bn[4];                                             // four LDS reads ahead of the MFMAs that use them
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(bp + 8 * j);
+#pragma unroll
+        for (int u = 0; u < HEAD_K / 8; u += 4) {
+            if (u + 4 < HEAD_K / 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const float4*>(bp + 8 * (u + 4 + j));
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // keep the reads above the 16 MFMAs they hide under
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = mfma32(a[u + j].x, b[j].x, acc);
+                acc = mfma32(a[u + j].y, b[j].y, acc);
+                acc = mfma32(a[u + j].z, b[j].z, acc);
+                acc = mfma32(a[u + j].w, b[j].w, acc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = bn[j];
+        }
+        const int col = n0 + row;
+        const float wj = col < N ? w[col] : 0.f, bj = col < N ? bd[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qacc[r] += wj * __builtin_amdgcn_rcpf(1.f + __expf(-(acc[r] + bj)));
+        if (t + 1 < n_tiles) HEAD_STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+    // sum over the 32 columns a half-wave holds (lanes of one half share the rows mfma_row(r, lane))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = qacc[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+        const int rr = r0 + mfma_row(r, lane);
+        if (row == 0 && rr < n_rows) out[rr] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_head_sum(int n_rows, int splits, const float* __restrict__ part, float* __restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    float v = part[r];
+    for (int s = 1; s < splits; ++s) v += part[(size_t)s * n_rows + r];
+    out[r] = v;
+}
+
 }  // namespace bridges

@@ -157,15 +157,18 @@ class SuccessorMLP(nn.Module):
         return torch.addmm(lin[-1].bias[:px], h, lin[-1].weight[:px].T)
 
     @torch.no_grad()
-    def q_from_first_layer(self, h_pre, reward_features, head=None):
+    def q_from_first_layer(self, h_pre, reward_features, head=None, fused_head=None):
         """q from the pre-activation of the first layer ([n, hidden]): the remaining layers and the factored head.
-        ``head(d, w) -> sum_j w[j] * sigmoid(d[:, j])`` may be supplied as a fused operator."""
+        ``head(d, w) -> sum_j w[j] * sigmoid(d[:, j])`` may be supplied as a fused operator, or -- for a last hidden width of
+        256 -- ``fused_head(h, Wd, bd, w) -> sum_j w[j] * sigmoid(h . Wd[j] + bd[j])``, which never stores the [n, px] product."""
         lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
         h = F.relu(h_pre)
         for layer in lin[1:-1]:
             h = F.relu(layer(h))
         Wo, bo = lin[-1].weight, lin[-1].bias
+        if fused_head is not None and h.shape[1] == 256:
+            return fused_head(h, Wo[px:2 * px] - Wo[:px], bo[px:2 * px] - bo[:px], reward_features.reshape(px))
         d = torch.addmm(bo[px:2 * px] - bo[:px], h, (Wo[px:2 * px] - Wo[:px]).T)
         if head is not None:
             return head(d, reward_features.reshape(px))

@@ -148,7 +148,7 @@ class VecDQN:
                                base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
                                base_row=torch.arange(E, device=self.device))
         h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
-        q = net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot)
+        q = net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot, fused_head=ops.head_sigmoid_dot)
         return (q, h_pre) if return_h else q
 
     @torch.no_grad()

@@ -262,6 +262,12 @@ int bridges_bits_dot(int32_t n_rows, const uint64_t* bits, const int64_t* bits_r
                      float* out, void* stream);
 int bridges_bits_accumulate(int32_t n_rows, const uint64_t* bits, const int64_t* bits_row, const float* weight,
                             const int64_t* slot, float* img, void* stream);
+/* The same head with the product inside: out[r] = sum_j w[j] * sigmoid(h[r,:] . Wd[j,:] + bd[j]), h [n, K = 256] (row stride
+ * h_stride floats), Wd [N, 256] row-major (= W_out[px:2px] - W_out[:px] of SuccessorMLP), on the f32 matrix cores; the [n, N]
+ * product is never written.  splits > 1 cuts the N columns into that many ranges per 128-row workgroup (so that a launch fills
+ * the 256 CUs evenly; the ranges' sums go to part [splits, n] and are added in a fixed order: no atomics, deterministic). */
+int bridges_head_sigmoid_dot(int32_t n_rows, int32_t K, int32_t N, const float* h, int64_t h_stride, const float* Wd,
+                             const float* bd, const float* w, float* out, float* part, int32_t splits, void* stream);
 /* out[r] = sum_j w[j] * sigmoid(d[r * row_stride + j]), j < k: the q head of SuccessorMLP's factored forward
  * (q = sum(softmax(psi)[:, 1] * reward_map), cv.py:101-104, with psi1 - psi0 = d) in one pass.  k % 4 == 0. */
 int bridges_sigmoid_dot(int32_t n_rows, const float* d, int64_t row_stride, const float* w, int32_t k, float* out,

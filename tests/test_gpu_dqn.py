@@ -237,6 +237,25 @@ def test_sigmoid_dot_matches_torch():
     assert torch.allclose(ops.sigmoid_dot(view, w).double(), (torch.sigmoid(view.double()) * w.double()).sum(dim=1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,N", [(1, 4096), (129, 4096), (1000, 100), (4099, 4096)])
+def test_head_sigmoid_dot_matches_the_two_pass_head(n, N):
+    """bridges_head_sigmoid_dot: sum_j w[j] * sigmoid(h[r] . Wd[j] + bd[j]) with the product on the f32 matrix cores and never
+    stored; tolerance 1e-5 relative to the float64 value (f32 products, f32 accumulation over K = 256, N terms)."""
+    from bridges_hip import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(n + N)
+    h = torch.relu(torch.randn((n, 256), generator=g)).to(dev)
+    Wd = (torch.randn((N, 256), generator=g) * 0.05).to(dev)
+    bd = (torch.randn(N, generator=g) * 0.1).to(dev)
+    w = (torch.rand(N, generator=g) * 0.02).to(dev)
+    got = ops.head_sigmoid_dot(h, Wd, bd, w)
+    want = (torch.sigmoid(h.double() @ Wd.double().T + bd.double()) * w.double()).sum(dim=1)
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5), float((got.double() - want).abs().max())
+    padded = torch.zeros((n, 320), device=dev)
+    padded[:, :256] = h                                                         # row stride != K
+    assert torch.equal(ops.head_sigmoid_dot(padded[:, :256], Wd, bd, w), got)
+
+
 @pytest.mark.parametrize("loss_fct", ["mse_q_values", "mse_block_features", "mse_q_values+mse_block_features"])
 def test_train_policy_net_reproduces_the_reference_net_fixture(loss_fct, golden_dir):
     """tests/golden/dqn_fixtures.pt (made by make_dqn_fixtures.py from the REFERENCE's own SuccessorMLP / init_weights
