@@ -165,7 +165,10 @@ class SuccessorMLP(nn.Module):
         px = self.img_size[0] * self.img_size[1]
         h = F.relu(h_pre)
         for layer in lin[1:-1]:
-            h = F.relu(layer(h))
+            if h.is_cuda:
+                h = torch._addmm_activation(layer.bias, h, layer.weight.T)       # bias + ReLU in the library GEMM's epilogue
+            else:
+                h = F.relu(layer(h))
         Wo, bo = lin[-1].weight, lin[-1].bias
         if fused_head is not None and h.shape[1] == 256:
             return fused_head(h, Wo[px:2 * px] - Wo[:px], bo[px:2 * px] - bo[:px], reward_features.reshape(px))

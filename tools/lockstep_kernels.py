@@ -15,6 +15,7 @@ ap.add_argument("dir")
 ap.add_argument("--last", type=int, default=4)
 ap.add_argument("--top", type=int, default=45)
 ap.add_argument("--cut", default="k_step")
+ap.add_argument("--width", type=int, default=100, help="characters of the kernel name kept (torch functor names are long)")
 a = ap.parse_args()
 f = sorted(glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True))
 if not f:
@@ -32,8 +33,8 @@ for r in rows:
     s, e = ks(r)
     if s < lo or s >= hi:
         continue
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])
-    name = re.sub(r"^void ", "", name)
+    name = r["Kernel_Name"] if a.width > 100 else re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = re.sub(r"^void ", "", name)[:a.width]
     agg[name] += (e - s) / 1e3
     cnt[name] += 1
     busy += max(0, e - max(s, last_end))
@@ -42,9 +43,10 @@ n = a.last
 seg_us = (hi - lo) / 1e3 / n
 print(f"# {f[0]}: last {n} lock-steps, {seg_us:.0f} us per lock-step wall, GPU busy {busy / 1e3 / n:.0f} us "
       f"({100 * busy / (hi - lo):.0f} %), {sum(cnt.values()) / n:.0f} launches per lock-step")
-print(f"{'kernel':100s} {'launches':>8s} {'us':>9s} {'%':>6s}")
+W = a.width
+print(f"{'kernel':{W}s} {'launches':>8s} {'us':>9s} {'%':>6s}")
 tot = sum(agg.values())
 for name, us in sorted(agg.items(), key=lambda kv: -kv[1])[:a.top]:
-    print(f"{name[:100]:100s} {cnt[name] / n:8.1f} {us / n:9.1f} {100 * us / tot:6.1f}")
+    print(f"{name:{W}s} {cnt[name] / n:8.1f} {us / n:9.1f} {100 * us / tot:6.1f}")
 small = sum(c for k, c in cnt.items() if agg[k] / c < 8.0) / n
 print(f"# launches shorter than 8 us on average: {small:.0f} per lock-step")
