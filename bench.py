@@ -207,7 +207,9 @@ def side_modes(args):
     sim("bit_packed_rasters_only", task + ["--no-f32-rasters", "--groups", "3"])
     sim("candidate_stability", task + ["--mode", "candidate-stability"])
     # BASELINE.json configs[4]'s simulator workload: hexagon blocks, bridge-span task, max_steps=15
-    sim("config5_hexagon_bridge", ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15", "--groups", str(args.groups)])
+    # (three env groups: its rasteriser launches are twice as long as the tower task's, so the third group's overlap is
+    # worth more than the extra ramp / drain -- tools/hex_groups_sweep.sh: 2.39 / 2.47 / 2.14 M env-steps/s for 2 / 3 / 4)
+    sim("config5_hexagon_bridge", ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15", "--groups", "3"])
     if os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
         tool = os.path.join(ROOT, "tools", "train_throughput.py")
         n_ls = os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")
