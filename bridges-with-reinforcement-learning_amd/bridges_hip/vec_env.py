@@ -331,6 +331,40 @@ class VecAssemblyGym:
         self.buf["n_cand"].copy_(torch.clamp(n_cand, max=self.a_max).to(torch.int32))
         self.refresh()
 
+    def load_records(self, rec):
+        """load_states for the next states s' of sampled transition records ([n <= E, RECORD_WIDTH] float64,
+        robotoddler/training/records.py): ONE launch (bridges_replay_unpack) writes the block lists, the candidate
+        counts and the block ranges instead of the ~60 slice / cast / index launches of unpack_states + load_states;
+        envs beyond n repeat record 0.  Returns (bits of s, lin_reward f32, stable(s) f32, done u8, stable(s') u8), [E] each."""
+        E, K, dev = self.E, self.K, self.device
+        assert rec.dtype == torch.float64 and rec.is_contiguous() and 1 <= rec.shape[0] <= E
+        if getattr(self, "_nv_dev", None) is None:
+            self._nv_dev = torch.tensor([g.num_faces_2d for g in self.table_geoms], dtype=torch.int32, device=dev)
+        ranges = torch.empty((2, E, 2), dtype=torch.int32, device=dev)
+        lin, stable_s = torch.empty(E, dtype=torch.float32, device=dev), torch.empty(E, dtype=torch.float32, device=dev)
+        done, stable_n = torch.empty(E, dtype=torch.uint8, device=dev), torch.empty(E, dtype=torch.uint8, device=dev)
+        b = self.buf
+        abi.check(self.L.bridges_replay_unpack(E, rec.shape[0], K, _ptr(rec), _ptr(self._nv_dev), self._nv_dev.numel(),
+                                               len(self.groups), len(self.x_discr_ground), len(self.offset_values), self.a_max,
+                                               _ptr(b["n_blocks"]), _ptr(b["blk_shape"]), _ptr(b["blk_pose"]), _ptr(b["blk_occ"]),
+                                               _ptr(b["n_cand"]), _ptr(ranges[0]), _ptr(ranges[1]), _ptr(lin), _ptr(stable_s),
+                                               _ptr(done), _ptr(stable_n), _stream()), "bridges_replay_unpack")
+        b["needs_reset"].zero_()
+        b["n_if"].zero_()                             # interfaces are only needed by step(); replay states never step
+        self._contacts_current = False
+        flat_shape = b["blk_shape"].reshape(E * K)
+        abi.check(self.L.bridges_pose_block(self.table.ptr, E * K, _ptr(flat_shape), _ptr(b["blk_pose"]), _ptr(b["blk_verts"]),
+                                            _stream()), "bridges_pose_block")
+        bits = torch.empty((E * K, 64), dtype=torch.int64, device=dev)
+        abi.check(self.L.bridges_raster_sized(self.table.ptr, E * K, _ptr(b["blk_verts"]), _ptr(flat_shape), _ptr(self.grid_x_dev),
+                                              _ptr(self.grid_y_dev), self.img, _ptr(bits), None, _stream()), "bridges_raster")
+        abi.check(self.L.bridges_bits_or(E, _ptr(ranges[0]), _ptr(bits), _ptr(b["state_bits"]), _stream()), "bridges_bits_or")
+        bits_s = torch.empty((E, 64), dtype=torch.int64, device=dev)
+        abi.check(self.L.bridges_bits_or(E, _ptr(ranges[1]), _ptr(bits), _ptr(bits_s), _stream()), "bridges_bits_or")
+        self._keep = (bits, ranges[0], flat_shape)    # alive until the stream has consumed them
+        self.refresh()
+        return bits_s, lin, stable_s, done, stable_n
+
     def prefix_state_bits(self, n_prefix):
         """Bit raster of the first n_prefix[e] blocks of every env as loaded by the last load_states call (int32/int64
         [E]): the state a transition started from, when the env holds the state it led to."""

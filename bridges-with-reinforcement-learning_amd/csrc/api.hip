@@ -519,6 +519,44 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
+int bridges_record_state(int32_t E, int32_t K, const int32_t* n_blocks, const int32_t* blk_shape, const double* blk_pose,
+                         const uint8_t* blk_occ, const uint8_t* step_flags, const int64_t* sel_row, const int32_t* cand_desc,
+                         const double* cand_pose, double* rec, void* stream) {
+    if (E < 0 || K < 1 || K > BRIDGES_REC_K || !n_blocks || !blk_shape || !blk_pose || !blk_occ || !step_flags || !sel_row ||
+        !cand_desc || !cand_pose || !rec)
+        return fail_arg("bridges_record_state");
+    if (E == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_record_state, dim3((unsigned)E), dim3(64), 0, (hipStream_t)stream, E, K, n_blocks, blk_shape, blk_pose, blk_occ,
+                       step_flags, sel_row, cand_desc, cand_pose, rec);
+    LAUNCH_CHECK("k_record_state");
+    return BRIDGES_OK;
+}
+
+int bridges_record_result(int32_t E, const float* reward, const float* lin_reward, const uint8_t* step_flags, double* rec,
+                          uint8_t* valid, void* stream) {
+    if (E < 0 || !reward || !lin_reward || !step_flags || !rec || !valid) return fail_arg("bridges_record_result");
+    if (E == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_record_result, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E, reward, lin_reward,
+                       step_flags, rec, valid);
+    LAUNCH_CHECK("k_record_result");
+    return BRIDGES_OK;
+}
+
+int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec, const int32_t* shape_faces, int32_t n_shapes,
+                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t a_max, int32_t* n_blocks, int32_t* blk_shape,
+                          double* blk_pose, uint8_t* blk_occ, int32_t* n_cand, int32_t* ranges_next, int32_t* ranges_prev,
+                          float* lin, float* stable_s, uint8_t* done, uint8_t* stable_n, void* stream) {
+    if (E < 0 || n_rec < 1 || n_rec > E || K < 1 || K > BRIDGES_REC_K || !rec || !shape_faces || n_shapes < 1 || n_groups < 0 ||
+        n_ground < 0 || n_off < 0 || a_max < 0 || !n_blocks || !blk_shape || !blk_pose || !blk_occ || !n_cand || !ranges_next ||
+        !ranges_prev || !lin || !stable_s || !done || !stable_n)
+        return fail_arg("bridges_replay_unpack");
+    hipLaunchKernelGGL(k_replay_unpack, dim3((unsigned)E), dim3(64), 0, (hipStream_t)stream, E, n_rec, K, rec, shape_faces, n_shapes, n_groups,
+                       n_ground, n_off, a_max, n_blocks, blk_shape, blk_pose, blk_occ, n_cand, ranges_next, ranges_prev, lin, stable_s,
+                       done, stable_n);
+    LAUNCH_CHECK("k_replay_unpack");
+    return BRIDGES_OK;
+}
+
 int bridges_head_sigmoid_dot(int32_t n_rows, int32_t K, int32_t N, const float* h, int64_t h_stride, const float* Wd,
                              const float* bd, const float* w, float* out, float* part, int32_t splits, void* stream) {
     if (n_rows < 0 || N <= 0 || !h || !Wd || !bd || !w || !out || splits < 1 || (splits > 1 && !part))

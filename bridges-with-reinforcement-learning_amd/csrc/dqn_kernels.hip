@@ -286,4 +286,112 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool2(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Transition records of the vectorised loop (robotoddler/training/records.py: one float64 row per transition, the
+// compact form of the reference's Transition, successor_dqn.py:27-44; layout BRIDGES_REC_* of the header).  The torch
+// formulation of these three steps was ~95 slice / cast / index launches of a few microseconds per lock-step.
+//   k_record_state:   before step(): the state s of every env and the chosen candidate -> rec[:, 0 : REC_REWARD], stable(s)
+//   k_record_result:  after step():  reward, lin_reward, done | no_actions, stable(s') -> rec, valid_step -> valid
+//   k_replay_unpack:  sampled records -> the replay env's state arrays holding s' = s + the action block with the
+//                     occupancy update of gym_env.py:228-232, the candidate count of s', the block ranges of s' and s
+// One 64-lane workgroup per env / record, lane k = block slot k.
+__global__ __launch_bounds__(64) void k_record_state(int E, int K, const int32_t* __restrict__ n_blocks,
+                                                     const int32_t* __restrict__ blk_shape, const double* __restrict__ blk_pose,
+                                                     const uint8_t* __restrict__ blk_occ, const uint8_t* __restrict__ step_flags,
+                                                     const int64_t* __restrict__ sel_row, const int32_t* __restrict__ cand_desc,
+                                                     const double* __restrict__ cand_pose, double* __restrict__ rec) {
+    const int e = blockIdx.x, k = threadIdx.x;
+    if (e >= E) return;
+    double* r = rec + (size_t)e * BRIDGES_REC_WIDTH;
+    for (int c = k; c < BRIDGES_REC_WIDTH; c += 64) r[c] = 0.0;        // slots >= K, td_error
+    __syncthreads();
+    if (k < K) {
+        r[BRIDGES_REC_SHAPE + k] = (double)blk_shape[(size_t)e * K + k];
+        const double* p = blk_pose + ((size_t)e * K + k) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[BRIDGES_REC_POSE + 4 * k + j] = p[j];
+        r[BRIDGES_REC_OCC + k] = (double)blk_occ[(size_t)e * K + k];
+    }
+    if (k == 0) {
+        const int nb = n_blocks[e];
+        r[BRIDGES_REC_NB] = (double)nb;
+        const int64_t row = sel_row[e];
+        const int32_t* d = cand_desc + row * 4;                            // (target_block, target_face, shape, face)
+        r[BRIDGES_REC_ASHAPE] = (double)d[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[BRIDGES_REC_APOSE + j] = cand_pose[row * 4 + j];
+        r[BRIDGES_REC_ATB] = (double)d[0];
+        r[BRIDGES_REC_ATF] = (double)d[1];
+        r[BRIDGES_REC_AFACE] = (double)d[3];
+        // 'stable' of s: a freshly reset env is stable (stability.py:53-56), else the frozen verdict of the last step
+        r[BRIDGES_REC_STABLE_S] = (nb == 0 || step_flags[(size_t)e * 8 + 1]) ? 1.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_record_result(int E, const float* __restrict__ reward, const float* __restrict__ lin_reward,
+                                                       const uint8_t* __restrict__ step_flags, double* __restrict__ rec,
+                                                       uint8_t* __restrict__ valid) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const uint8_t* f = step_flags + (size_t)e * 8;
+    double* r = rec + (size_t)e * BRIDGES_REC_WIDTH;
+    r[BRIDGES_REC_REWARD] = (double)reward[e];
+    r[BRIDGES_REC_LIN] = (double)lin_reward[e];
+    r[BRIDGES_REC_DONE] = (f[5] | f[6]) ? 1.0 : 0.0;                     // done | no_actions
+    r[BRIDGES_REC_STABLE_N] = f[1] ? 1.0 : 0.0;
+    valid[e] = f[0] != 0;
+}
+
+__global__ __launch_bounds__(64) void k_replay_unpack(int E, int n_rec, int K, const double* __restrict__ rec,
+                                                      const int32_t* __restrict__ shape_faces, int n_shapes, int n_groups, int n_ground, int n_off,
+                                                      int a_max, int32_t* __restrict__ n_blocks, int32_t* __restrict__ blk_shape,
+                                                      double* __restrict__ blk_pose, uint8_t* __restrict__ blk_occ,
+                                                      int32_t* __restrict__ n_cand, int32_t* __restrict__ ranges_next,
+                                                      int32_t* __restrict__ ranges_prev, float* __restrict__ lin,
+                                                      float* __restrict__ stable_s, uint8_t* __restrict__ done,
+                                                      uint8_t* __restrict__ stable_n) {
+    const int e = blockIdx.x, k = threadIdx.x;
+    if (e >= E) return;
+    const double* r = rec + (size_t)(e < n_rec ? e : 0) * BRIDGES_REC_WIDTH;     // padding envs repeat the first record
+    const int nb = (int)r[BRIDGES_REC_NB];
+    const int slot = nb < K - 1 ? nb : K - 1;
+    const int tb = (int)r[BRIDGES_REC_ATB];
+    int free_faces = 0;
+    if (k < K) {
+        int shape = (int)r[BRIDGES_REC_SHAPE + k];
+        int occ = (int)r[BRIDGES_REC_OCC + k] & 255;
+        double p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = r[BRIDGES_REC_POSE + 4 * k + j];
+        if (k == slot) {                                                   // the action block
+            shape = (int)r[BRIDGES_REC_ASHAPE];
+            occ = (1 << (int)r[BRIDGES_REC_AFACE]) & 255;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = r[BRIDGES_REC_APOSE + j];
+        }
+        if (tb >= 0 && k == tb) occ |= (1 << (int)r[BRIDGES_REC_ATF]) & 255;   // the face it was put on
+        blk_shape[(size_t)e * K + k] = shape;
+        blk_occ[(size_t)e * K + k] = (uint8_t)occ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) blk_pose[((size_t)e * K + k) * 4 + j] = p[j];
+        if (k <= nb && k < K) free_faces = shape_faces[shape < 0 ? 0 : (shape < n_shapes ? shape : n_shapes - 1)] - __builtin_popcount(occ & ((1 << BRIDGES_MAX_VERTS) - 1));
+    }
+    int nfree = free_faces;                                                // lanes >= K hold 0
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) nfree += __shfl_xor(nfree, m);
+    if (k == 0) {
+        n_blocks[e] = nb + 1;
+        const int nc = n_groups * (n_ground + nfree * n_off);
+        n_cand[e] = nc < a_max ? nc : a_max;
+        ranges_next[2 * e] = e * K;
+        ranges_next[2 * e + 1] = e * K + nb + 1;
+        ranges_prev[2 * e] = e * K;
+        ranges_prev[2 * e + 1] = e * K + nb;
+        lin[e] = (float)r[BRIDGES_REC_LIN];
+        stable_s[e] = (float)r[BRIDGES_REC_STABLE_S];
+        done[e] = r[BRIDGES_REC_DONE] > 0.5;
+        stable_n[e] = r[BRIDGES_REC_STABLE_N] > 0.5;
+    }
+}
+
 }  // namespace bridges

@@ -207,10 +207,11 @@ class VecDQN:
         else:
             sel_compact = torch.zeros(E, dtype=torch.long, device=self.device)
         sel_index = (sel_compact - env.cand_offset[:E].long()).clamp(min=0).to(torch.int32)
-        snap = R.snapshot(env)
-        sel_rows = (env.cand_desc[sel_compact].clone(), env.cand_pose[sel_compact].clone())
+        # the record of the lock-step in two launches around the step (bridges_record_state / _result); the torch formulation
+        # R.snapshot + R.make_records (~35 launches) is what tests/test_gpu_vec_dqn.py compares them with
+        rec = R.pack_state(env, sel_compact)
         env.step(sel_index)
-        rec, valid = R.make_records(env, snap, sel_rows)
+        valid = R.pack_result(env, rec)
         return rec, valid
 
     # ------------------------------------------------------------------ gradient steps on sampled batches
@@ -239,23 +240,18 @@ class VecDQN:
         n = rec.shape[0]
         renv = self._replay_env(n)
         K, E = renv.K, renv.E
-        if n < E:                                       # pad with copies of the first record; sliced off below
-            rec_p = torch.cat([rec, rec[:1].expand(E - n, -1)])
-        else:
-            rec_p = rec
-        (nb, shape, pose, occ), (nnb, nshape, npose, nocc) = R.unpack_states(rec_p, K)
         # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout; s is the
-        # prefix of its block list, so its raster comes out of the same per-block bit rasters
-        renv.load_states(nnb, nshape, npose, nocc)
-        bits_s = renv.prefix_state_bits(nb)
+        # prefix of its block list, so its raster comes out of the same per-block bit rasters.  One launch unpacks the
+        # records into the scratch env (envs beyond n repeat record 0 and are sliced off below); R.unpack_states +
+        # load_states + prefix_state_bits is the torch formulation the tests compare it with.
+        bits_s, lin, stable_s, done_rec, stable_n = renv.load_records(rec.contiguous())
         block_f = renv.crop(ops.bits_to_f32(bits_s)).unsqueeze(1)
         action_f = renv.crop(ops.bits_to_f32(renv.state_bits & ~bits_s)).unsqueeze(1)         # s' minus s = the new block
         idx, row_env = renv.valid_rows()
         seg, counts = self._segments(renv)
-        done = (rec_p[:, R.O_DONE] > 0.5) | (counts == 0)
+        done = done_rec.bool() | (counts == 0)
         use_sf = 'mse_block_features' in self.loss_parts
-        stable_n = rec_p[:, R.O_STABLE_N] > 0.5
-        lin = rec_p[:, R.O_LIN].float().contiguous()
+        stable_n = stable_n.bool()
         if idx.numel() and self._factored(self.target_net):
             # q of every next candidate through the factored forward on the bit-packed rasters; the 8204-wide output
             # (successor features) is only needed for the arg-max row of each transition
@@ -279,10 +275,10 @@ class VecDQN:
                 next_sf=nsf[:, 0] if use_sf else None,
                 action_raster=action_f.squeeze(1) if use_sf else None)
         else:
-            q_target = rec_p[:, R.O_LIN].float()
+            q_target = lin
             sf_target = action_f.reshape(E, -1) if use_sf else None
         binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
-        binary[:, 0] = rec_p[:, R.O_STABLE_S].float()
+        binary[:, 0] = stable_s
         return block_f[:n], binary[:n], action_f[:n], q_target[:n], (sf_target[:n] if use_sf else None)
 
     def _loss(self, q, sf, q_target, sf_target):

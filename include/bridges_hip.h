@@ -297,6 +297,45 @@ int bridges_stability_penalty(const bridges_shape* shapes_dev, int32_t n, int32_
 int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, bridges_shape** out_dev);
 int bridges_shapes_free(bridges_shape* dev);
 
+/* --- transition records of the vectorised loop ------------------------------------------------------------------
+ * One float64 row per transition: the compact form of the reference's Transition (successor_dqn.py:27-44) -- the block
+ * list of s, the placed block and the scalars; rasters and candidate sets are re-generated when a record is sampled.
+ * Integers are stored exactly as float64.  The same rows are what the ranks all-gather per lock-step. */
+#define BRIDGES_REC_K 16                                    /* block slots of a record */
+#define BRIDGES_REC_NB 0                                    /* n_blocks of s */
+#define BRIDGES_REC_SHAPE 1                                 /* [K] shape ids */
+#define BRIDGES_REC_POSE (1 + BRIDGES_REC_K)                /* [K][4] (x, z, cos, sin) */
+#define BRIDGES_REC_OCC (1 + 5 * BRIDGES_REC_K)             /* [K] face-occupancy bit masks */
+#define BRIDGES_REC_ASHAPE (1 + 6 * BRIDGES_REC_K)          /* action: shape id, pose[4], target_block, target_face, face */
+#define BRIDGES_REC_APOSE (BRIDGES_REC_ASHAPE + 1)
+#define BRIDGES_REC_ATB (BRIDGES_REC_APOSE + 4)
+#define BRIDGES_REC_ATF (BRIDGES_REC_APOSE + 5)
+#define BRIDGES_REC_AFACE (BRIDGES_REC_APOSE + 6)
+#define BRIDGES_REC_REWARD (BRIDGES_REC_AFACE + 1)
+#define BRIDGES_REC_LIN (BRIDGES_REC_REWARD + 1)
+#define BRIDGES_REC_DONE (BRIDGES_REC_REWARD + 2)           /* terminated | truncated | no next action */
+#define BRIDGES_REC_STABLE_S (BRIDGES_REC_REWARD + 3)
+#define BRIDGES_REC_STABLE_N (BRIDGES_REC_REWARD + 4)       /* stable(s') with the last block frozen */
+#define BRIDGES_REC_TD (BRIDGES_REC_STABLE_N + 1)           /* rollout td_error (successor_dqn.py:413-426), 0 unless prioritised */
+#define BRIDGES_REC_WIDTH (BRIDGES_REC_TD + 1)              /* 111 doubles = 888 B */
+/* Before the lock-step's step: state s of every env (the env's own arrays, K = its block slots <= 16) and the candidate
+ * sel_row[e] (compact row of cand_desc / cand_pose) it is about to place -> rec[e, 0 : REC_REWARD], stable(s); the rest 0. */
+int bridges_record_state(int32_t E, int32_t K, const int32_t* n_blocks, const int32_t* blk_shape, const double* blk_pose,
+                         const uint8_t* blk_occ, const uint8_t* step_flags, const int64_t* sel_row, const int32_t* cand_desc,
+                         const double* cand_pose, double* rec, void* stream);
+/* After it: reward, lin_reward, done | no_actions, stable(s') into the same rows; valid[e] = the lock-step was a real
+ * env-step of env e (reset-only lock-steps are not transitions). */
+int bridges_record_result(int32_t E, const float* reward, const float* lin_reward, const uint8_t* step_flags, double* rec,
+                          uint8_t* valid, void* stream);
+/* Sampled records -> the state arrays of a replay env of E >= n_rec envs (envs >= n_rec repeat record 0): s' = s plus the
+ * action block with the occupancy update of gym_env.py:228-232, its candidate count
+ * min(n_groups * (n_ground + free faces * n_off), a_max) (generate_actions, actions.py:7-52), the block ranges
+ * [e*K, e*K + n) of s' and of s (for bridges_bits_or over the per-block rasters) and the scalars the targets need. */
+int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec, const int32_t* shape_faces, int32_t n_shapes,
+                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t a_max, int32_t* n_blocks, int32_t* blk_shape,
+                          double* blk_pose, uint8_t* blk_occ, int32_t* n_cand, int32_t* ranges_next, int32_t* ranges_prev,
+                          float* lin, float* stable_s, uint8_t* done, uint8_t* stable_n, void* stream);
+
 /* --- K7: DQN ops (robotoddler/training/successor_dqn.py) --------------------- */
 /* update_target_net (successor_dqn.py:280-288): target = policy*tau + target*one_minus_tau, the two products and the
  * sum rounded separately in float32 as torch evaluates it (one_minus_tau = (float)(1.0 - tau) from the host). */

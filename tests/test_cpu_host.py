@@ -46,6 +46,23 @@ def test_struct_sizes_match_the_header():
                                      abi.ENV_LP_WS_DOUBLES, abi.ENV_LP_SNAP_DOUBLES, abi.CAND_WS_SLOTS]
 
 
+def test_record_layout_of_the_header_is_the_one_records_py_uses():
+    """BRIDGES_REC_* (what bridges_record_state / _result / bridges_replay_unpack read and write) vs records.py's offsets."""
+    from robotoddler.training import records as R
+    names = ["K", "NB", "SHAPE", "POSE", "OCC", "ASHAPE", "APOSE", "ATB", "ATF", "AFACE", "REWARD", "LIN", "DONE", "STABLE_S",
+             "STABLE_N", "TD", "WIDTH"]
+    src = ('#include <stdio.h>\n#include "bridges_hip.h"\nint main(){printf("' + " ".join(["%d"] * len(names)) + '\\n", '
+           + ", ".join("BRIDGES_REC_" + n for n in names) + ');return 0;}\n')
+    exe = os.path.join(ROOT, "tests", "_rec_layout")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    try:
+        out = [int(v) for v in subprocess.check_output([exe]).decode().split()]
+    finally:
+        os.remove(exe)
+    assert out == [R.K, R.O_NB, R.O_SHAPE, R.O_POSE, R.O_OCC, R.O_ASHAPE, R.O_APOSE, R.O_ATB, R.O_ATF, R.O_AFACE, R.O_REWARD, R.O_LIN,
+                   R.O_DONE, R.O_STABLE_S, R.O_STABLE_N, R.O_TD, R.RECORD_WIDTH]
+
+
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
 def test_product_path_fails_loudly_without_gpu():
     from bridges_hip import abi

@@ -44,8 +44,48 @@ def test_records_rebuild_the_recorded_states():
             assert torch.equal(renv.cand_pose[a:a + n], env.cand_pose[b:b + n])
 
 
+@pytest.mark.parametrize("shape,E,n_rec", [("trapezoid", 48, 48), ("trapezoid", 48, 17), ("hexagon", 40, 40)])
+def test_record_kernels_equal_the_torch_formulation(shape, E, n_rec):
+    """bridges_record_state / _result write the very rows snapshot + make_records build, and bridges_replay_unpack (load_records)
+    leaves the scratch env in the very state unpack_states + load_states + prefix_state_bits do (all arrays bit-identical)."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    from robotoddler.training import records as R
+    H = 0.8
+    mk = lambda seed: VecAssemblyGym(E, [load_urdf(f"shapes/{shape}.urdf")], [(0.5, 0., i * H + H / 2) for i in range(2)],
+                                     [(0.5, 0, 2 * H + H / 2)], max_steps=12, seed=seed)
+    env, renv_a, renv_b = mk(7), mk(1), mk(2)
+    for it in range(8):
+        env.select_random()
+        sel = env.cand_offset[:E].long() + env.sel_index.long()
+        snap = R.snapshot(env)
+        sel_rows = (env.cand_desc[sel].clone(), env.cand_pose[sel].clone())
+        rec = R.pack_state(env, sel)
+        env.step()
+        valid = R.pack_result(env, rec)
+        want, want_valid = R.make_records(env, snap, sel_rows)
+        assert torch.equal(valid, want_valid)
+        assert torch.equal(rec, want), torch.nonzero(rec != want)[:5]
+        # records of padded / unpadded batches into the scratch envs
+        part = rec[:n_rec].contiguous()
+        padded = torch.cat([part, part[:1].expand(E - n_rec, -1)]) if n_rec < E else part
+        (nb, sh, po, oc), (nnb, nsh, npo, noc) = R.unpack_states(padded, renv_a.K)
+        renv_a.load_states(nnb, nsh, npo, noc)
+        bits_s_a = renv_a.prefix_state_bits(nb)
+        bits_s, lin, stable_s, done, stable_n = renv_b.load_records(part)
+        assert torch.equal(bits_s, bits_s_a)
+        assert torch.equal(lin, padded[:, R.O_LIN].float()) and torch.equal(stable_s, padded[:, R.O_STABLE_S].float())
+        assert torch.equal(done.bool(), padded[:, R.O_DONE] > 0.5) and torch.equal(stable_n.bool(), padded[:, R.O_STABLE_N] > 0.5)
+        for name in ("n_blocks", "blk_shape", "blk_pose", "blk_occ", "n_cand", "n_valid", "state_bits", "blk_verts"):
+            assert torch.equal(renv_a.buf[name], renv_b.buf[name]), name
+        tot = int(renv_a.cand_offset[E])
+        assert tot == int(renv_b.cand_offset[E])
+        for name in ("cand_mask", "cand_bits", "cand_pose", "cand_desc", "cand_lin"):
+            assert torch.equal(renv_a.buf[name][:tot], renv_b.buf[name][:tot]), name
+
+
 TOWER2 = ["--tower_height", "2"]
-HEX_BRIDGE = ["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"]       # BASELINE.json configs[4]
+HEX_BRIDGE =["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"]       # BASELINE.json configs[4]
 
 
 @pytest.mark.parametrize("model,loss,task", [("SuccessorMLP", "mse_q_values+mse_block_features", TOWER2),
