@@ -35,11 +35,29 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def gaussian_kernel_1d(kernel_size, sigma, device):
-    """robotoddler/utils/utils.py:93-100."""
-    coords = torch.arange(kernel_size, device=device) - kernel_size // 2
+def gaussian_reward_map(target_image, kernel_size=101, sigma=16):
+    """convolve_with_gaussian(targets raster, 101, 16) of get_task_features (successor_dqn.py:77-82, utils.py:93-115): the
+    zero-padded 'same' cross-correlation of the 0/1 target image with the float32 kernel k k^T, k as the reference builds it
+    (torch float32 on the host).  Evaluated on the host, in float64, set pixel by set pixel in row-major order, and rounded
+    to float32 once: ONE fixed order on every box.  The library convolution this replaces (conv2d on the GPU) picked its
+    algorithm from MIOpen's find results, which depend on the box and on what an earlier process left in MIOpen's cache --
+    the same training run ended with different weights after an unrelated process had run convolutions on the box.
+    target_image: numpy array [S, S] (the 0/1 targets raster; any weights work); returns float32 [S, S] (within 1e-7 relative
+    of the library's float32 sum)."""
+    coords = torch.arange(kernel_size) - kernel_size // 2
     k = torch.exp(-(coords.float() ** 2) / (2 * sigma ** 2))
-    return k / k.sum()
+    k = k / k.sum()
+    k2 = (k.unsqueeze(0) * k.unsqueeze(1)).numpy().astype(np.float64)       # the float32 products, as the reference's kernel
+    img = np.asarray(target_image, dtype=np.float64)
+    S0, S1 = img.shape
+    half = kernel_size // 2
+    out = np.zeros((S0, S1), dtype=np.float64)
+    ys, xs = np.arange(S0)[:, None], np.arange(S1)[None, :]
+    for py, px in zip(*np.nonzero(img)):                                     # row-major
+        i, j = py - ys + half, px - xs + half                                # out[y, x] += k2[py - y + half, px - x + half]
+        ok = (i >= 0) & (i < kernel_size) & (j >= 0) & (j < kernel_size)
+        out += img[py, px] * np.where(ok, k2[np.clip(i, 0, kernel_size - 1), np.clip(j, 0, kernel_size - 1)], 0.0)
+    return out.astype(np.float32)
 
 
 class ShapeTable:
@@ -192,16 +210,14 @@ class VecAssemblyGym:
         tbits = raster_points(self.targets)
         timg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
         abi.check(self.L.bridges_bits_to_f32(1, _ptr(tbits), _ptr(timg), _stream()), "bridges_bits_to_f32")
-        k1 = gaussian_kernel_1d(101, 16, dev)                              # successor_dqn.py:80-82
-        kernel = (k1.unsqueeze(0) * k1.unsqueeze(1))
         S = self.img                                                       # the map of the S x S image, rest of the canvas 0
-        rm = torch.nn.functional.conv2d(timg[None, :, :S, :S].contiguous(), kernel.unsqueeze(0).unsqueeze(0), padding=50)
-        self.buf["reward_map"].zero_()
-        self.buf["reward_map"][:S, :S].copy_(rm[0, 0])
+        rm = np.zeros((64, 64), dtype=np.float32)
+        rm[:S, :S] = gaussian_reward_map(timg[0, :S, :S].cpu().numpy())    # successor_dqn.py:80-82, once per task, on the host
+        self.buf["reward_map"].copy_(torch.from_numpy(rm))
         # float64 row prefix sums of the map, accumulated left to right on the host (one fixed order on every box): the
         # rasteriser takes sum(raster * reward_map) of a candidate from the runs of its rows (bridges_env_buffers.reward_prefix)
         pre = np.zeros((64, 65), dtype=np.float64)
-        pre[:, 1:] = np.cumsum(self.buf["reward_map"].cpu().numpy().astype(np.float64), axis=1)
+        pre[:, 1:] = np.cumsum(rm.astype(np.float64), axis=1)
         self.buf["reward_prefix"].copy_(torch.from_numpy(pre))
         oimg = torch.empty((1, 64, 64), dtype=torch.float32, device=dev)
         abi.check(self.L.bridges_bits_to_f32(1, _ptr(self.buf["obstacle_bits"]), _ptr(oimg), _stream()),
