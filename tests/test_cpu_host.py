@@ -399,3 +399,23 @@ def test_vectorised_loop_hands_every_lockstep_to_the_same_sinks():
     assert "aim_run=aim_run, wandb_run=wandb_run" in inspect.getsource(successor_dqn.main)
     src = inspect.getsource(vec_dqn.run_vectorised)
     assert "track_run_sinks(lockstep_log_values(info)" in src
+
+
+def test_host_reward_map_equals_the_reference_convolution():
+    """vec_env.gaussian_reward_map (fixed-order float64 evaluation on the host) against the reference's own call --
+    conv2d of the targets raster with gaussian_kernel(101, 16), utils.py:93-115, on the CPU -- and the oracle's separable form."""
+    import numpy as np
+    from bridges_hip.vec_env import gaussian_reward_map
+    from robotoddler.utils.utils import gaussian_kernel
+    sys.path.insert(0, ROOT)
+    from oracle import raster as R
+    for S, boxes in ((64, [(50, 54, 30, 34)]), (64, [(0, 1, 0, 1), (63, 64, 63, 64), (20, 26, 40, 44)]), (32, [(5, 9, 7, 9)])):
+        img = np.zeros((S, S), dtype=np.float32)
+        for y0, y1, x0, x1 in boxes:
+            img[y0:y1, x0:x1] = 1.0
+        got = gaussian_reward_map(img)
+        want = torch.nn.functional.conv2d(torch.from_numpy(img)[None, None], gaussian_kernel(101, 16)[None, None], padding=50)[0, 0].numpy()
+        assert got.dtype == np.float32 and got.shape == (S, S)
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(got, R.convolve_with_gaussian(img.astype(np.float64)), rtol=1e-6, atol=1e-9)
+        assert np.array_equal(got, gaussian_reward_map(img))
