@@ -411,15 +411,34 @@ class VecAssemblyGym:
         return idx, self.buf["cand_stable"][idx] == 1
 
     def valid_rows(self):
-        """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed."""
+        """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed
+        (bridges_valid_rows: two launches and ONE wait for the row count; torch.nonzero + gather were six launches and two
+        waits).  The returned tensors are views of two alternating buffers: they stay intact until the call after next."""
         cached = getattr(self, "_valid_rows", None)
         if cached is not None and cached[0] == self._cand_version:       # same candidate set as when it was last asked for
             return cached[1], cached[2]
-        total = self.total_candidates()
-        idx = torch.nonzero(self.buf["cand_mask"][:total]).squeeze(1)
-        row_env = self.buf["cand_env"][idx].long()
-        self._valid_rows = (self._cand_version, idx, row_env)
+        if getattr(self, "_vr_buf", None) is None:
+            cap = self.buf["cand_mask"].numel()
+            mk = lambda: (torch.empty(cap, dtype=torch.int64, device=self.device), torch.empty(cap, dtype=torch.int64, device=self.device),
+                          torch.empty(self.E + 1, dtype=torch.int32, device=self.device))
+            self._vr_buf, self._vr_flip = (mk(), mk()), 0
+            self._vr_total = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._vr_flip ^= 1
+        idx_b, env_b, seg = self._vr_buf[self._vr_flip]
+        b = self.buf
+        abi.check(self.L.bridges_valid_rows(self.E, _ptr(b["cand_offset"]), _ptr(b["n_cand"]), _ptr(b["n_valid"]), _ptr(b["cand_mask"]),
+                                            _ptr(seg), _ptr(idx_b), _ptr(env_b), C.c_void_p(self._vr_total.data_ptr()), _stream()),
+                  "bridges_valid_rows")
+        torch.cuda.current_stream(self.device).synchronize()             # the one wait: the count is on the host now
+        n = int(self._vr_total[0])
+        idx, row_env = idx_b[:n], env_b[:n]
+        self._valid_rows = (self._cand_version, idx, row_env, seg)
         return idx, row_env
+
+    def valid_segments(self):
+        """Row ranges of the envs in ``valid_rows()``: int32 [E + 1] prefix sums of n_valid (from the same launch)."""
+        self.valid_rows()
+        return self._valid_rows[3]
 
     # ------------------------------------------------------------------ views
     def flags(self):

@@ -557,6 +557,17 @@ int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec
     return BRIDGES_OK;
 }
 
+int bridges_valid_rows(int32_t E, const int32_t* cand_offset, const int32_t* n_cand, const int32_t* n_valid, const uint8_t* cand_mask,
+                       int32_t* seg, int64_t* idx, int64_t* row_env, int32_t* h_total, void* stream) {
+    if (E < 1 || !cand_offset || !n_cand || !n_valid || !cand_mask || !seg || !idx || !row_env || !h_total) return fail_arg("bridges_valid_rows");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, E, n_valid, seg, h_total);
+    LAUNCH_CHECK("k_valid_scan");
+    hipLaunchKernelGGL(k_valid_fill, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, E, cand_offset, n_cand, cand_mask, (const int32_t*)seg, idx, row_env);
+    LAUNCH_CHECK("k_valid_fill");
+    return BRIDGES_OK;
+}
+
 int bridges_head_sigmoid_dot(int32_t n_rows, int32_t K, int32_t N, const float* h, int64_t h_stride, const float* Wd,
                              const float* bd, const float* w, float* out, float* part, int32_t splits, void* stream) {
     if (n_rows < 0 || N <= 0 || !h || !Wd || !bd || !w || !out || splits < 1 || (splits > 1 && !part))

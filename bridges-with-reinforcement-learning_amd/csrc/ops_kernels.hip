@@ -278,4 +278,58 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The rows a Q-network is fed: compact indices of the valid (filtered, actions.py:71-82) candidates of every env, env-major,
+// with their owning env and the per-env row ranges.  torch.nonzero + gather did this in six launches and made the host
+// wait twice (nonzero reads its count back); here the count travels to a host word behind the two launches.
+//   k_valid_scan: seg[e] = sum of n_valid[0 .. e), seg[E] = total -> *h_total (host-visible), one workgroup
+//   k_valid_fill: one wave per env, ballot compaction of its mask bytes in candidate order
+__global__ __launch_bounds__(1024) void k_valid_scan(int E, const int32_t* __restrict__ n_valid, int32_t* __restrict__ seg,
+                                                     int32_t* __restrict__ h_total) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) { carry_s = 0; seg[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < E; base += 1024) {
+        const int i = base + t;
+        int incl = i < E ? n_valid[i] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_tot[wv] = incl;
+        __syncthreads();
+        int wbase = carry_s;
+        for (int k = 0; k < wv; ++k) wbase += wave_tot[k];
+        if (i < E) seg[i + 1] = wbase + incl;
+        __syncthreads();
+        if (t == 1023) carry_s = wbase + incl;
+        __syncthreads();
+    }
+    if (t == 0) *h_total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_valid_fill(int E, const int32_t* __restrict__ cand_offset, const int32_t* __restrict__ n_cand,
+                                                    const uint8_t* __restrict__ cand_mask, const int32_t* __restrict__ seg,
+                                                    int64_t* __restrict__ idx, int64_t* __restrict__ row_env) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const int off = cand_offset[e], n = n_cand[e], end = seg[e + 1];
+    int pos = seg[e];
+    for (int base = 0; base < n; base += 64) {
+        const int a = base + lane;
+        const bool m = a < n && cand_mask[off + a] != 0;
+        const unsigned long long b = __ballot(m);
+        const int p = pos + __popcll(b & ((1ull << lane) - 1ull));
+        if (m && p < end) {                                               // p < end: n_valid and the mask always agree; never write past the env's range
+            idx[p] = off + a;
+            row_env[p] = e;
+        }
+        pos += __popcll(b);
+    }
+}
+
 }  // namespace bridges

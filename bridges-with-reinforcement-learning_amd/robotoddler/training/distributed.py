@@ -24,11 +24,19 @@ def init(backend=None, device=None):
     return dist.get_rank(), dist.get_world_size()
 
 
-def all_gather_records(rec, valid):
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def all_gather_records(rec, valid, n_valid=None):
     """rec [E, W] float64, valid [E] bool -> the valid records of every rank, rank-major ([N, W]).
-    Every rank gets the same rows in the same order, so the replicated replay rings stay identical."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return rec[valid]
+    Every rank gets the same rows in the same order, so the replicated replay rings stay identical.
+    n_valid = valid.sum() when the host already knows it: the single-rank selection then does not wait for the device
+    (a boolean index reads its row count back)."""
+    if world_size() == 1:
+        if n_valid is None:
+            return rec[valid]
+        return rec.index_select(0, torch.nonzero_static(valid, size=int(n_valid)).squeeze(1))
     world = dist.get_world_size()
     E, W = rec.shape
     payload = torch.cat([rec, valid.to(rec.dtype).unsqueeze(1)], dim=1).contiguous()     # validity travels in-band

@@ -63,6 +63,7 @@ class VecDQN:
         self._graph_state, self._eager_calls = None, 0
         self.episodes_done = 0
         self.env_steps = 0
+        self._counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()      # (env-steps, finished episodes) of a lock-step
 
     ROW_CHUNK = 2048       # rows per forward call: ONE input shape for the whole run (MIOpen tunes per shape)
 
@@ -114,9 +115,7 @@ class VecDQN:
         """Row ranges of the envs in ``env.valid_rows()`` (rows are env-major) from the env's own per-env counts --
         torch.bincount would make the host wait for the device (it reads the maximum back)."""
         counts = env.n_valid[:env.E].long()
-        seg = torch.zeros(env.E + 1, dtype=torch.int32, device=env.device)
-        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        return seg, counts
+        return env.valid_segments(), counts                    # the prefix sums bridges_valid_rows left beside the rows
 
     @staticmethod
     def _stable_flags(env):
@@ -499,11 +498,22 @@ class VecDQN:
         rec, valid = self.act()
         if self.prioritized:
             rec[:, R.O_TD] = self.td_errors(rec).to(rec.dtype)
-        self.env.valid_rows()                           # the next act's candidate rows, while the host waits here anyway
-        self.env_steps += int(valid.sum().item())
-        allrec = D.all_gather_records(rec, valid)
+        # ONE wait per lock-step on this side: the two counts ride to pinned memory in front of the next act's candidate rows,
+        # whose row count the host has to wait for anyway (bridges_valid_rows)
+        done_rec = valid & (rec[:, R.O_DONE] > 0.5)
+        self._counts_host.copy_(torch.stack([valid.sum(), done_rec.sum()]), non_blocking=True)
+        arrived = torch.cuda.Event()
+        arrived.record()
+        self.env.valid_rows()
+        arrived.synchronize()                           # passed already unless the rows came out of the env's cache
+        n_valid, n_done = int(self._counts_host[0]), int(self._counts_host[1])
+        self.env_steps += n_valid
+        allrec = D.all_gather_records(rec, valid, n_valid=n_valid)
         self.ring.push(allrec)
-        self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())
+        if D.world_size() == 1:
+            self.episodes_done += n_done
+        else:
+            self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())
         losses = self.train_steps(n_train_steps, defer=defer_losses)
         self.update_target()
         self.epsilon = (self.epsilon - self.eps_end) * self.eps_decay + self.eps_end

@@ -297,6 +297,13 @@ int bridges_stability_penalty(const bridges_shape* shapes_dev, int32_t n, int32_
 int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, bridges_shape** out_dev);
 int bridges_shapes_free(bridges_shape* dev);
 
+/* The rows a Q-network is fed (filter_actions, actions.py:71-82, for every env at once): compact indices of the candidates
+ * with cand_mask != 0, env-major in candidate order, their owning env, and seg[e] .. seg[e + 1] = the rows of env e
+ * (seg [E + 1]; n_valid[e] = the env's count, as bridges_env_step leaves it).  idx / row_env need room for every candidate.
+ * The total goes to *h_total, a HOST-visible word (pinned, device-accessible): valid once the stream has passed the call. */
+int bridges_valid_rows(int32_t E, const int32_t* cand_offset, const int32_t* n_cand, const int32_t* n_valid, const uint8_t* cand_mask,
+                       int32_t* seg, int64_t* idx, int64_t* row_env, int32_t* h_total, void* stream);
+
 /* --- transition records of the vectorised loop ------------------------------------------------------------------
  * One float64 row per transition: the compact form of the reference's Transition (successor_dqn.py:27-44) -- the block
  * list of s, the placed block and the scalars; rasters and candidate sets are re-generated when a record is sampled.

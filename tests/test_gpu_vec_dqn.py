@@ -84,6 +84,33 @@ def test_record_kernels_equal_the_torch_formulation(shape, E, n_rec):
             assert torch.equal(renv_a.buf[name][:tot], renv_b.buf[name][:tot]), name
 
 
+@pytest.mark.parametrize("shape,E", [("trapezoid", 50), ("hexagon", 1100)])
+def test_valid_rows_operator_equals_nonzero(shape, E):
+    """bridges_valid_rows (scan of n_valid + ballot compaction per env) against torch.nonzero over the mask bytes: same rows in
+    the same order, their envs, the per-env ranges; the alternating buffers keep the previous call's rows intact."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    H = 0.8
+    env = VecAssemblyGym(E, [load_urdf(f"shapes/{shape}.urdf")], [(0.5, 0., i * H + H / 2) for i in range(2)],
+                         [(0.5, 0, 2 * H + H / 2)], max_steps=12, seed=3)
+    prev = None
+    for it in range(5):
+        idx, row_env = env.valid_rows()
+        total = env.total_candidates()
+        want = torch.nonzero(env.buf["cand_mask"][:total]).squeeze(1)
+        assert torch.equal(idx, want)
+        assert torch.equal(row_env, env.buf["cand_env"][want].long())
+        seg = env.valid_segments()
+        assert seg.dtype == torch.int32 and int(seg[0]) == 0 and int(seg[E]) == idx.numel()
+        assert torch.equal(seg[1:] - seg[:-1], env.n_valid[:E])
+        assert env.valid_rows()[0] is idx                                  # cached until the candidate set changes
+        if prev is not None:
+            assert torch.equal(prev[0], prev[1])                           # the rows of the call before are untouched
+        prev = (idx, idx.clone())
+        env.select_random()
+        env.step()
+
+
 TOWER2 = ["--tower_height", "2"]
 HEX_BRIDGE =["--shapes", "hexagon", "--bridge_length", "3", "--max_steps", "15"]       # BASELINE.json configs[4]
 
