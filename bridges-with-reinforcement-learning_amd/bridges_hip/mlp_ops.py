@@ -4,6 +4,7 @@ robotoddler/training/successor_dqn.py:157-235).  The parameters stay the module'
 their ``.grad`` -- the optimiser (torch's fused Adam) is untouched.  No CPU fallback: abi.require_gpu() raises without
 the HIP library."""
 import ctypes as C
+import os
 
 import torch
 
@@ -92,10 +93,30 @@ class FusedSuccessorStep:
                 p.grad = torch.zeros_like(p)
             assert p.grad.is_contiguous()
             self._grads.append(p.grad)
+        self._setup_mid_stack()
         self.fused_adam, self.optimizer = False, None
         if (optimizer is not None and self.grad_flat is not None and self._adam_applies(optimizer, net)
                 and {id(p) for p in params} == {id(p) for p in net.parameters()}):
             self._adopt_adam(optimizer, params)
+
+    def _setup_mid_stack(self):
+        """The Linear + ReLU layers between the first and the last as ONE launch each way (bridges_mlp_mid_forward /
+        _backward: a workgroup per tile of the stack's last layer computes what the tile depends on itself, no traffic between
+        workgroups) where the library has that stack (the reference's 256-128-64-128-256); ``BRIDGES_MID_STACK=0`` keeps a
+        launch per layer (bit-identical results)."""
+        self.mid = None
+        mids = self.linears[1:-1]
+        if not mids or os.environ.get("BRIDGES_MID_STACK", "1") == "0":
+            return
+        n = len(mids)
+        dims = (C.c_int32 * (n + 1))(mids[0].in_features, *[l.out_features for l in mids])
+        if not self.L.bridges_mlp_mid_supported(self.rows, n, dims):
+            return
+        VP, VP1 = C.c_void_p * n, C.c_void_p * (n + 1)
+        ptr = lambda t: t.data_ptr()
+        self.mid = dict(n=n, dims=dims, W=VP(*[ptr(l.weight) for l in mids]), bias=VP(*[ptr(l.bias) for l in mids]),
+                        dW=VP(*[ptr(l.weight.grad) for l in mids]), db=VP(*[ptr(l.bias.grad) for l in mids]),
+                        acts=VP1(*[ptr(t) for t in self.acts[1:n + 2]]), dz=VP1(*[ptr(t) for t in self.dz[0:n + 1]]))
 
     def allocate_inputs(self, n_batches):
         """Room for the first layer's input rows of n_batches batches (52 MB for 25 batches of 32 rows of 64x64 images): after
@@ -191,7 +212,13 @@ class FusedSuccessorStep:
             abi.check(L.bridges_mlp_input(B, rows, px, nf, _ptr(counter), _ptr(block_all), _ptr(action_all), _ptr(binary_all),
                                           _ptr(reward), _ptr(obstacle), _ptr(self.acts[0]), st), "bridges_mlp_input")
         last = len(self.linears) - 1
+        mid = self.mid
         for l, lin in enumerate(self.linears):
+            if mid is not None and 0 < l < last:
+                if l == 1:
+                    abi.check(L.bridges_mlp_mid_forward(rows, mid["n"], mid["dims"], mid["W"], mid["bias"], mid["acts"], st),
+                              "bridges_mlp_mid_forward")
+                continue
             abi.check(L.bridges_linear_forward(rows, lin.in_features, lin.out_features, _ptr(x0 if l == 0 else self.acts[l]),
                                                _ptr(lin.weight), _ptr(lin.bias), int(l < last), _ptr(self.acts[l + 1]), _ptr(self.ws),
                                                self.ws.numel(), blk if l == 0 else None, st), "bridges_linear_forward")
@@ -209,6 +236,11 @@ class FusedSuccessorStep:
         fold_first = self.fused_adam and rows == 32 and self._rest is not None
         for l in range(last, -1, -1):
             lin = self.linears[l]
+            if mid is not None and 0 < l < last:
+                if l == last - 1:
+                    abi.check(L.bridges_mlp_mid_backward(rows, mid["n"], mid["dims"], mid["W"], mid["dW"], mid["db"], mid["acts"],
+                                                         mid["dz"], st), "bridges_mlp_mid_backward")
+                continue
             if l == 0 and fold_first:
                 mw, vw, mb, vb = self._moments[0]
                 lo, hi = self._rest

@@ -710,6 +710,53 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
     return BRIDGES_OK;
 }
 
+// the middle stack the k_mid_* kernels are instantiated for: SuccessorMLP's 256-128-64-128-256 (successor_dqn.py:366)
+static bool mid_dims_supported(int32_t n_layers, const int32_t* dims) {
+    static const int32_t want[5] = {256, 128, 64, 128, 256};
+    if (n_layers != 4 || !dims) return false;
+    for (int i = 0; i < 5; ++i) if (dims[i] != want[i]) return false;
+    return true;
+}
+static int mid_ptrs_fill(const char* who, MidPtrs& p, const float* const* W, const float* const* bias, float* const* dW,
+                         float* const* db, float* const* acts, float* const* dz) {
+    if (!W || !acts) return fail_arg(who);
+    for (int l = 0; l < 4; ++l) {
+        if (!W[l] || (((uintptr_t)W[l]) & 15) || (bias && !bias[l]) || (dW && !dW[l]) || (db && !db[l])) return fail_arg(who);
+        p.W[l] = W[l]; p.bias[l] = bias ? bias[l] : nullptr; p.dW[l] = dW ? dW[l] : nullptr; p.db[l] = db ? db[l] : nullptr;
+    }
+    for (int l = 0; l < 5; ++l) {
+        if (!acts[l] || (((uintptr_t)acts[l]) & 15) || (dz && (l == 0 || l == 4) && (!dz[l] || (((uintptr_t)dz[l]) & 15)))) return fail_arg(who);
+        p.act[l] = acts[l]; p.dz[l] = dz ? dz[l] : nullptr;
+    }
+    return BRIDGES_OK;
+}
+
+int bridges_mlp_mid_supported(int32_t rows, int32_t n_layers, const int32_t* dims) {
+    return (rows == 32 && mid_dims_supported(n_layers, dims)) ? 1 : 0;
+}
+
+int bridges_mlp_mid_forward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
+                            float* const* acts, void* stream) {
+    if (rows != 32 || !mid_dims_supported(n_layers, dims) || !bias) return fail_arg("bridges_mlp_mid_forward: 32 rows of 256-128-64-128-256 only");
+    MidPtrs p{};
+    int rc = mid_ptrs_fill("bridges_mlp_mid_forward", p, W, bias, nullptr, nullptr, acts, nullptr);
+    if (rc != BRIDGES_OK) return rc;
+    hipLaunchKernelGGL((k_mid_fwd<256, 128, 64, 128, 256>), dim3(256 / 32), dim3(1024), 0, (hipStream_t)stream, p);
+    LAUNCH_CHECK("k_mid_fwd");
+    return BRIDGES_OK;
+}
+
+int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
+                             float* const* db, float* const* acts, float* const* dz, void* stream) {
+    if (rows != 32 || !mid_dims_supported(n_layers, dims) || !dW || !db || !dz) return fail_arg("bridges_mlp_mid_backward: 32 rows of 256-128-64-128-256 only");
+    MidPtrs p{};
+    int rc = mid_ptrs_fill("bridges_mlp_mid_backward", p, W, nullptr, dW, db, acts, dz);
+    if (rc != BRIDGES_OK) return rc;
+    hipLaunchKernelGGL((k_mid_bwd<256, 128, 64, 128, 256>), dim3(256 / 32), dim3(1024), 0, (hipStream_t)stream, p);
+    LAUNCH_CHECK("k_mid_bwd");
+    return BRIDGES_OK;
+}
+
 int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, float* W, float* bias,
                                  float* exp_avg_w, float* exp_avg_sq_w, float* exp_avg_b, float* exp_avg_sq_b, float* rest_param,
                                  const float* rest_grad, float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step,

@@ -539,6 +539,242 @@ __global__ void k_loss_log(int batch, const float* __restrict__ loss_rows, float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The middle layers of the step (SuccessorMLP, successor_dqn.py:366: 256-128-64-128-256 -- four Linear + ReLU of 8-128 KB of
+// weights on 32 rows) as ONE launch each way, WITHOUT any traffic between workgroups.  A launch per layer runs 6-8 us of
+// which < 2 us is work: launch, first memory round trip, drain.  Here a workgroup per 32-column tile of the stack's LAST layer
+// (8 of 1024 threads) computes everything that tile depends on itself -- the three layers in front of it in full, redundantly
+// in every workgroup (768 of its 832 MFMAs), activations handed from layer to layer through LDS, __syncthreads between
+// layers -- so there is no inter-workgroup protocol to get right and nothing to wait for across the chip.  Every weight
+// fragment a workgroup needs (<= 80 VGPRs of its 1024 threads) and the biases are requested before the first MFMA: one
+// memory latency per launch instead of one per layer.  Backward the same way round: a workgroup per 32-column tile of the
+// gradient the stack hands down, the three input-gradient products above it in full in each; the 80 weight-gradient tiles
+// (which only need the dz every workgroup holds) are dealt one to a wave.
+// Measured alternatives, all bit-identical, none kept: eight workgroups with an in-launch barrier between layers (sc1
+// hand-off): ~9 us per barrier, slower than the launches; ONE 1024-thread workgroup for everything: one CU's four matrix
+// pipes are the floor (1280 MFMAs forward = 8.5 us, 2560 backward): 24 / 37 us kernels, slower too; round 2's 256-thread
+// single workgroup.
+// Tile by tile the arithmetic is that of k_lin_fwd (one split) / k_lin_bwd (one split, rows == 32): a tile's K (or N) range
+// in four contiguous quarters, one wave each, summed ((q0 + q1) + q2) + q3 -- bit-identical results
+// (tests/test_gpu_mlp_step.py::test_middle_layer_stack_equals_the_per_layer_launches).
+#define MID_PAD 4                                            /* LDS row padding (floats): conflict-free 16-B row reads */
+struct MidPtrs {
+    const float* W[4]; const float* bias[4];
+    float* dW[4]; float* db[4];
+    float* act[5];               // act[l] [32][D_l]: input of middle layer l; act[l + 1] its output
+    float* dz[5];                // dz[l + 1] [32][D_{l+1}]: gradient at layer l's pre-activation; dz[0]: handed below the stack
+};
+// forward job = (tile << 2) | quarter of a layer [K -> N]: weight fragments and the tile's bias value
+template <int K>
+__device__ __forceinline__ void mid_fwd_load(const float* __restrict__ W, const float* __restrict__ bias, int job, bool live, int lane,
+                                             f4u (&w)[K / 32], float& bv) {
+    if (live) {
+        const float* wp = W + (size_t)((job >> 2) * 32 + (lane & 31)) * K + (job & 3) * (K / 4) + 4 * (lane >> 5);
+#pragma unroll
+        for (int u = 0; u < K / 32; ++u) w[u] = *reinterpret_cast<const f4u*>(wp + 8 * u);
+        bv = bias[(job >> 2) * 32 + (lane & 31)];
+    }
+}
+// x in LDS [32][K + MID_PAD] -> y = relu(x . W^T + b) of the job's tile into LDS [32][N + MID_PAD] (ys) and / or memory (yg)
+template <int K, int N>
+__device__ __forceinline__ void mid_fwd_job(const f4u (&w)[K / 32], float bv, int job, bool live, const float* xs, float* ys,
+                                            float* __restrict__ yg, float (*red)[3][16][64], int lane) {
+    const int row = lane & 31, half = lane >> 5;
+    const int nt = job >> 2, q = job & 3;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (live) {
+        const float* xp = xs + row * (K + MID_PAD) + q * (K / 4) + 4 * half;
+#pragma unroll
+        for (int u = 0; u < K / 32; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(xp + 8 * u);
+            acc = mfma32(a.x, w[u].x, acc);
+            acc = mfma32(a.y, w[u].y, acc);
+            acc = mfma32(a.z, w[u].z, acc);
+            acc = mfma32(a.w, w[u].w, acc);
+        }
+        if (q > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[nt & 3][q - 1][r][lane] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (live && q == 0) {
+        const int n = nt * 32 + row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = ((acc[r] + red[nt & 3][0][r][lane]) + red[nt & 3][1][r][lane]) + red[nt & 3][2][r][lane];
+            v += bv;
+            v = v > 0.f ? v : 0.f;
+            const int m = mfma_row(r, lane);
+            if (ys) ys[m * (N + MID_PAD) + n] = v;
+            if (yg) yg[(size_t)m * N + n] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// grid = D4 / 32 workgroups of 1024 threads
+template <int D0, int D1, int D2, int D3, int D4>
+__global__ __launch_bounds__(1024) void k_mid_fwd(MidPtrs p) {
+    constexpr int M01 = D0 > D1 ? D0 : D1, M23 = D2 > D3 ? D2 : D3, DM = M01 > M23 ? M01 : M23;
+    __shared__ __attribute__((aligned(16))) float xa[32 * (DM + MID_PAD)], xb[32 * (DM + MID_PAD)];
+    __shared__ float red[4][3][16][64];
+    static_assert((D1 / 32) * 4 <= 16 && (D2 / 32) * 4 <= 16 && (D3 / 32) * 4 <= 16, "a layer in front of the last has at most 4 tiles");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool first = blockIdx.x == 0;                            // one workgroup writes the shared intermediate activations
+    const bool l0 = wave < (D1 / 32) * 4, l1 = wave < (D2 / 32) * 4, l2 = wave < (D3 / 32) * 4, l3 = wave < 4;
+    const int job3 = ((int)blockIdx.x << 2) | (wave & 3);
+    f4u w0[D0 / 32], w1[D1 / 32], w2[D2 / 32], w3[D3 / 32];
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    mid_fwd_load<D0>(p.W[0], p.bias[0], wave, l0, lane, w0, b0);
+    mid_fwd_load<D1>(p.W[1], p.bias[1], wave, l1, lane, w1, b1);
+    mid_fwd_load<D2>(p.W[2], p.bias[2], wave, l2, lane, w2, b2);
+    mid_fwd_load<D3>(p.W[3], p.bias[3], job3, l3, lane, w3, b3);
+    for (int i = threadIdx.x; i < 32 * D0 / 4; i += 1024) {
+        const int m = i / (D0 / 4), c = i % (D0 / 4);
+        *reinterpret_cast<float4*>(&xa[m * (D0 + MID_PAD) + 4 * c]) = reinterpret_cast<const float4*>(p.act[0])[i];
+    }
+    __syncthreads();
+    mid_fwd_job<D0, D1>(w0, b0, wave, l0, xa, xb, first ? p.act[1] : nullptr, red, lane);
+    mid_fwd_job<D1, D2>(w1, b1, wave, l1, xb, xa, first ? p.act[2] : nullptr, red, lane);
+    mid_fwd_job<D2, D3>(w2, b2, wave, l2, xa, xb, first ? p.act[3] : nullptr, red, lane);
+    mid_fwd_job<D3, D4>(w3, b3, job3, l3, xb, nullptr, p.act[4], red, lane);
+}
+
+// backward job = (k tile << 2) | quarter of N: W fragments B[kk = n][j = k]
+template <int K, int N>
+__device__ __forceinline__ void mid_dx_load(const float* __restrict__ W, int job, bool live, int lane, float (&w)[N / 8]) {
+    if (live) {
+        const float* wp = W + (size_t)((job & 3) * (N / 4) + 4 * (lane >> 5)) * K + (job >> 2) * 32 + (lane & 31);
+#pragma unroll
+        for (int u = 0; u < N / 32; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[4 * u + j] = wp[(size_t)(8 * u + j) * K];
+        }
+    }
+}
+// dz_below tile = (dz . W) * mask: dz in LDS [32][N + MID_PAD], mask bytes [32][K]; result to LDS (zs) and / or memory (zg)
+template <int K, int N>
+__device__ __forceinline__ void mid_dx_job(const float (&w)[N / 8], int job, bool live, const float* dzs, const unsigned char* mask,
+                                           float* zs, float* __restrict__ zg, float (*red)[3][16][64], int lane) {
+    const int row = lane & 31, half = lane >> 5;
+    const int kt = job >> 2, q = job & 3;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (live) {
+        const float* dp = dzs + row * (N + MID_PAD) + q * (N / 4) + 4 * half;
+#pragma unroll
+        for (int u = 0; u < N / 32; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(dp + 8 * u);
+            acc = mfma32(a.x, w[4 * u + 0], acc);
+            acc = mfma32(a.y, w[4 * u + 1], acc);
+            acc = mfma32(a.z, w[4 * u + 2], acc);
+            acc = mfma32(a.w, w[4 * u + 3], acc);
+        }
+        if (q > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[kt & 3][q - 1][r][lane] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (live && q == 0) {
+        const int k = kt * 32 + row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = ((acc[r] + red[kt & 3][0][r][lane]) + red[kt & 3][1][r][lane]) + red[kt & 3][2][r][lane];
+            const int m = mfma_row(r, lane);
+            if (!mask[m * K + k]) v = 0.f;
+            if (zs) zs[m * (K + MID_PAD) + k] = v;
+            if (zg) zg[(size_t)m * K + k] = v;
+        }
+    }
+    __syncthreads();
+}
+template <int K>
+__device__ __forceinline__ void mid_mask_load(const float* __restrict__ act, unsigned char* mask) {    // [act > 0] as bytes
+    for (int i = threadIdx.x; i < 32 * K / 4; i += 1024) {
+        const float4 v = reinterpret_cast<const float4*>(act)[i];
+        uchar4 m;
+        m.x = v.x > 0.f; m.y = v.y > 0.f; m.z = v.z > 0.f; m.w = v.w > 0.f;
+        reinterpret_cast<uchar4*>(mask)[i] = m;
+    }
+}
+template <int K>
+__device__ __forceinline__ void mid_dw_load(const float* __restrict__ act, int kt, int lane, float (&bv)[16]) {
+    const float* p = act + (size_t)(lane >> 5) * K + kt * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) bv[t] = p[(size_t)(2 * t) * K];
+}
+template <int K, int N>
+__device__ __forceinline__ void mid_dw_tile(const float* dzs, const float (&bv)[16], float* __restrict__ dW, float* __restrict__ db, int nt,
+                                            int kt, int lane) {
+    const int row = lane & 31, half = lane >> 5;
+    float av[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) av[t] = dzs[(2 * t + half) * (N + MID_PAD) + nt * 32 + row];
+    if (kt == 0) {
+        float sdb = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sdb += av[t];
+        sdb += __shfl_xor(sdb, 32);
+        if (half == 0) db[nt * 32 + row] = sdb;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = mfma32(av[t], bv[t], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW[(size_t)(nt * 32 + mfma_row(r, lane)) * K + kt * 32 + row] = acc[r];
+}
+
+// grid = D0 / 32 workgroups of 1024 threads; needs (D0 / 32) * 16 >= the number of weight-gradient tiles
+template <int D0, int D1, int D2, int D3, int D4>
+__global__ __launch_bounds__(1024) void k_mid_bwd(MidPtrs p) {
+    __shared__ __attribute__((aligned(16))) float z4[32 * (D4 + MID_PAD)], z3[32 * (D3 + MID_PAD)], z2[32 * (D2 + MID_PAD)], z1[32 * (D1 + MID_PAD)];
+    __shared__ float red[4][3][16][64];
+    __shared__ __attribute__((aligned(16))) unsigned char m3[32 * D3], m2[32 * D2], m1[32 * D1], m0[32 * D0];
+    constexpr int J3 = (D4 / 32) * (D3 / 32), J2 = (D3 / 32) * (D2 / 32), J1 = (D2 / 32) * (D1 / 32), J0 = (D1 / 32) * (D0 / 32);
+    static_assert((D3 / 32) * 4 <= 16 && (D2 / 32) * 4 <= 16 && (D1 / 32) * 4 <= 16, "a gradient above the last has at most 4 tiles");
+    static_assert(J3 + J2 + J1 + J0 <= (D0 / 32) * 16, "one weight-gradient tile per wave");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool l3 = wave < (D3 / 32) * 4, l2 = wave < (D2 / 32) * 4, l1 = wave < (D1 / 32) * 4, l0 = wave < 4;
+    const int job0 = ((int)blockIdx.x << 2) | (wave & 3);
+    float w3[D4 / 8], w2[D3 / 8], w1[D2 / 8], w0[D1 / 8];
+    mid_dx_load<D3, D4>(p.W[3], wave, l3, lane, w3);
+    mid_dx_load<D2, D3>(p.W[2], wave, l2, lane, w2);
+    mid_dx_load<D1, D2>(p.W[1], wave, l1, lane, w1);
+    mid_dx_load<D0, D1>(p.W[0], job0, l0, lane, w0);
+    for (int i = threadIdx.x; i < 32 * D4 / 4; i += 1024) {
+        const int m = i / (D4 / 4), c = i % (D4 / 4);
+        *reinterpret_cast<float4*>(&z4[m * (D4 + MID_PAD) + 4 * c]) = reinterpret_cast<const float4*>(p.dz[4])[i];
+    }
+    mid_mask_load<D3>(p.act[3], m3);
+    mid_mask_load<D2>(p.act[2], m2);
+    mid_mask_load<D1>(p.act[1], m1);
+    mid_mask_load<D0>(p.act[0], m0);
+    __syncthreads();
+    mid_dx_job<D3, D4>(w3, wave, l3, z4, m3, z3, nullptr, red, lane);
+    // this wave's weight-gradient tile: layer 3 first, nt fastest inside a layer; its act fragments are requested now that the
+    // largest set of W fragments is dead (128 VGPRs per thread at 1024 threads), and arrive under the rest of the chain
+    const int g = (int)blockIdx.x * 16 + wave;
+    float bv[16];
+    if (g < J3) mid_dw_load<D3>(p.act[3], g / (D4 / 32), lane, bv);
+    else if (g < J3 + J2) mid_dw_load<D2>(p.act[2], (g - J3) / (D3 / 32), lane, bv);
+    else if (g < J3 + J2 + J1) mid_dw_load<D1>(p.act[1], (g - J3 - J2) / (D2 / 32), lane, bv);
+    else if (g < J3 + J2 + J1 + J0) mid_dw_load<D0>(p.act[0], (g - J3 - J2 - J1) / (D1 / 32), lane, bv);
+    mid_dx_job<D2, D3>(w2, wave, l2, z3, m2, z2, nullptr, red, lane);
+    mid_dx_job<D1, D2>(w1, wave, l1, z2, m1, z1, nullptr, red, lane);
+    mid_dx_job<D0, D1>(w0, job0, l0, z1, m0, nullptr, p.dz[0], red, lane);
+    if (g < J3) mid_dw_tile<D3, D4>(z4, bv, p.dW[3], p.db[3], g % (D4 / 32), g / (D4 / 32), lane);
+    else if (g < J3 + J2) mid_dw_tile<D2, D3>(z3, bv, p.dW[2], p.db[2], (g - J3) % (D3 / 32), (g - J3) / (D3 / 32), lane);
+    else if (g < J3 + J2 + J1) mid_dw_tile<D1, D2>(z2, bv, p.dW[1], p.db[1], (g - J3 - J2) % (D2 / 32), (g - J3 - J2) / (D2 / 32), lane);
+    else if (g < J3 + J2 + J1 + J0) mid_dw_tile<D0, D1>(z1, bv, p.dW[0], p.db[0], (g - J3 - J2 - J1) % (D1 / 32), (g - J3 - J2 - J1) / (D1 / 32), lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Head of the factored acting forward, fused: q[r] = sum_j w[j] * sigmoid(h[r,:] . Wd[j,:] + bd[j]) for n rows, K = 256
 // hidden units, N = px outputs (cv.py:101-104 with channel 1 of the softmax over the two successor channels =
 // sigmoid(psi1 - psi0); SuccessorMLP.q_from_first_layer).  The [n, 4096] product is never written: the library GEMM

@@ -378,6 +378,21 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
 int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
                             float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
                             const int64_t* a_block, int32_t a_block_bias, void* stream);
+/* The middle Linear + ReLU layers of the step in ONE launch each way and without traffic between workgroups: a 1024-thread
+ * workgroup per 32-column tile of the stack's last layer (backward: of the gradient handed below the stack) computes the
+ * layers that tile depends on itself, in full, handing activations / gradients from layer to layer through LDS; every weight
+ * fragment is requested before the first MFMA.  Built for the reference's stack (successor_dqn.py:366): n_layers = 4,
+ * dims = {256, 128, 64, 128, 256} (layer l: dims[l] -> dims[l + 1]), one 32-row batch tile; bridges_mlp_mid_supported says
+ * whether a shape is (1 / 0), anything else is refused by the two calls.
+ *   forward:  acts[l + 1] = relu(acts[l] . W[l]^T + bias[l])                      (acts: 5 arrays [32, dims[l]])
+ *   backward: dW[l] = dz[l + 1]^T . acts[l], db[l] = column sums of dz[l + 1], dz[0] = the gradient handed below the stack
+ *             (dz: 5 pointers like acts; dz[4] given, dz[0] written, dz[1..3] live in LDS only and are not touched)
+ * dims and the pointer tables are HOST arrays.  Bit-identical to four calls of bridges_linear_forward / _backward. */
+int bridges_mlp_mid_supported(int32_t rows, int32_t n_layers, const int32_t* dims);
+int bridges_mlp_mid_forward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
+                            float* const* acts, void* stream);
+int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
+                             float* const* db, float* const* acts, float* const* dz, void* stream);
 /* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
  * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
  * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further
