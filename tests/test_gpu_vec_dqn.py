@@ -432,3 +432,70 @@ def test_load_checkpoint_resumes_the_vectorised_loop(tmp_path):
         assert h["avg_loss"] == pytest.approx(ref["avg_loss"], rel=1e-4), h["lockstep"]
         n += 1
     assert n >= 10
+
+
+@pytest.mark.parametrize("E,amax,p_valid", [(1, 7, 0.5), (3, 70, 0.0), (1025, 130, 0.3), (5000, 9, 1.0)])
+def test_valid_rows_operator_on_ragged_and_empty_inputs(E, amax, p_valid):
+    """bridges_valid_rows straight through the C ABI on synthetic candidate sets: envs without candidates, without valid
+    candidates, all valid, more envs than one scan pass (1024) and more candidates than one wave pass (64)."""
+    import ctypes as C
+    from bridges_hip import abi
+    from bridges_hip.ops import _ptr, _stream
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(E + amax)
+    n_cand = torch.randint(0, amax + 1, (E,), generator=g, dtype=torch.int32)
+    n_cand[::7] = 0                                                          # envs with no candidate at all
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(n_cand, 0)
+    total = int(off[E])
+    mask = (torch.rand(max(total, 1), generator=g) < p_valid).to(torch.uint8)
+    mask[total:] = 0
+    env_of = torch.repeat_interleave(torch.arange(E), n_cand.long())
+    n_valid = torch.zeros(E, dtype=torch.int32)
+    n_valid.index_add_(0, env_of, mask[:total].to(torch.int32))
+    d = lambda t: t.to(dev)
+    off_d, nc_d, nv_d, mask_d = d(off), d(n_cand), d(n_valid), d(mask)
+    seg = torch.full((E + 1,), -7, dtype=torch.int32, device=dev)
+    idx = torch.full((max(total, 1),), -7, dtype=torch.int64, device=dev)
+    renv = torch.full((max(total, 1),), -7, dtype=torch.int64, device=dev)
+    host = torch.full((1,), -7, dtype=torch.int32).pin_memory()
+    abi.check(abi.lib().bridges_valid_rows(E, _ptr(off_d), _ptr(nc_d), _ptr(nv_d), _ptr(mask_d), _ptr(seg), _ptr(idx), _ptr(renv),
+                                           C.c_void_p(host.data_ptr()), _stream()), "bridges_valid_rows")
+    torch.cuda.synchronize()
+    want = torch.nonzero(mask[:total]).squeeze(1)
+    n = int(host[0])
+    assert n == want.numel() == int(n_valid.sum())
+    assert torch.equal(idx[:n].cpu(), want) and torch.equal(renv[:n].cpu(), env_of[want])
+    assert torch.equal(seg.cpu()[1:] - seg.cpu()[:-1], n_valid) and int(seg[0]) == 0
+    assert bool((idx[n:] == -7).all()) and bool((renv[n:] == -7).all())      # nothing written past the rows
+
+
+def test_record_kernels_at_the_last_block_slot_and_on_the_floor():
+    """bridges_replay_unpack on hand-made records: a state that already holds K - 1 blocks (the action block takes the last
+    slot), an action on the floor (target_block = -1: no occupancy update), one record for a scratch env of many."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    from robotoddler.training import records as R
+    H = 0.8
+    mk = lambda seed: VecAssemblyGym(6, [load_urdf("shapes/trapezoid.urdf")], [(0.5, 0., H / 2)], [(0.5, 0, H + H / 2)], max_steps=5, seed=seed)
+    a, b = mk(1), mk(2)
+    K = a.K
+    g = torch.Generator().manual_seed(0)
+    rec = torch.zeros((2, R.RECORD_WIDTH), dtype=torch.float64)
+    for r, (nb, tb) in enumerate([(K - 1, 2), (0, -1)]):
+        rec[r, R.O_NB] = nb
+        rec[r, R.O_POSE:R.O_POSE + 4 * K] = torch.rand(4 * K, generator=g, dtype=torch.float64)
+        rec[r, R.O_OCC:R.O_OCC + K] = torch.randint(0, 16, (K,), generator=g).double()
+        rec[r, R.O_APOSE:R.O_APOSE + 4] = torch.tensor([0.3, 1.1, 1.0, 0.0], dtype=torch.float64)
+        rec[r, R.O_ATB], rec[r, R.O_ATF], rec[r, R.O_AFACE] = tb, 1, 3
+        rec[r, R.O_LIN], rec[r, R.O_DONE], rec[r, R.O_STABLE_S], rec[r, R.O_STABLE_N] = 0.25 * (r + 1), r, 1, 1 - r
+    for n_rec in (2, 1):
+        part = rec[:n_rec].cuda().contiguous()
+        padded = torch.cat([part, part[:1].expand(6 - n_rec, -1)])
+        (nb, sh, po, oc), (nnb, nsh, npo, noc) = R.unpack_states(padded, K)
+        a.load_states(nnb, nsh, npo, noc)
+        bits_s, lin, stable_s, done, stable_n = b.load_records(part)
+        assert torch.equal(bits_s, a.prefix_state_bits(nb))
+        for name in ("n_blocks", "blk_shape", "blk_pose", "blk_occ", "n_cand", "n_valid", "state_bits"):
+            assert torch.equal(a.buf[name], b.buf[name]), name
+        assert torch.equal(lin, padded[:, R.O_LIN].float()) and torch.equal(done.bool(), padded[:, R.O_DONE] > 0.5)
