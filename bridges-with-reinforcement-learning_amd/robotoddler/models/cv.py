@@ -163,12 +163,23 @@ class SuccessorMLP(nn.Module):
         256 -- ``fused_head(h, Wd, bd, w) -> sum_j w[j] * sigmoid(h . Wd[j] + bd[j])``, which never stores the [n, px] product."""
         lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
-        h = F.relu(h_pre)
+        n = h_pre.shape[0]
+        if h_pre.is_cuda and len(lin) > 2:
+            # the row count changes with every call, and a row count the GEMM library has not seen costs 77 us of host time per
+            # call against 20 us for one it has (tools/addmm_host_cost.py): the middle layers run on the rows padded to a
+            # multiple of 512 (zero rows, sliced off below), so a run meets a handful of shapes instead of thousands
+            n_pad = -(-n // 512) * 512
+            h = torch.empty((n_pad, h_pre.shape[1]), dtype=h_pre.dtype, device=h_pre.device)
+            torch.clamp(h_pre, min=0, out=h[:n])                                 # relu into the padded buffer
+            h[n:].zero_()
+        else:
+            h = F.relu(h_pre)
         for layer in lin[1:-1]:
             if h.is_cuda:
                 h = torch._addmm_activation(layer.bias, h, layer.weight.T)       # bias + ReLU in the library GEMM's epilogue
             else:
                 h = F.relu(layer(h))
+        h = h[:n]
         Wo, bo = lin[-1].weight, lin[-1].bias
         if fused_head is not None and h.shape[1] == 256:
             return fused_head(h, Wo[px:2 * px] - Wo[:px], bo[px:2 * px] - bo[:px], reward_features.reshape(px))
