@@ -519,6 +519,17 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
+int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg, const float* q, const float* join, const float* u,
+                              float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset, int64_t* sel_compact,
+                              int32_t* sel_index, float* q_sel, float* explore_w, void* stream) {
+    if (E < 1 || n_rows < 1 || !seg || !q || !join || !u || !idx || !cand_offset || !sel_compact || !sel_index || !q_sel || !explore_w)
+        return fail_arg("bridges_eps_greedy_select");
+    hipLaunchKernelGGL(k_eps_greedy_select, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, E, n_rows, seg, q, join, u, eps,
+                       (int)greedy, idx, cand_offset, sel_compact, sel_index, q_sel, explore_w);
+    LAUNCH_CHECK("k_eps_greedy_select");
+    return BRIDGES_OK;
+}
+
 int bridges_record_state(int32_t E, int32_t K, const int32_t* n_blocks, const int32_t* blk_shape, const double* blk_pose,
                          const uint8_t* blk_occ, const uint8_t* step_flags, const int64_t* sel_row, const int32_t* cand_desc,
                          const double* cand_pose, double* rec, void* stream) {

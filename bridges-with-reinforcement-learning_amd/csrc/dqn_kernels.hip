@@ -287,6 +287,51 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool2(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// EpsilonGreedy.select (successor_dqn.py:98-132) for every env of the vectorised loop in one launch: per env, over its rows
+// seg[e] .. seg[e + 1] of the Q pass, the greedy row = first maximum of q, the exploring row = first minimum of the overlap
+// `join` of the candidate with the count image of the env's episode step (count-based exploration); the env explores when
+// its uniform draw u[e] <= eps (and the call is not greedy).  An env without rows gets row 0 with weight 0.  Replaces two
+// segmented arg-max launches and ~20 element-wise / index launches.  One wave per env.
+//   sel_compact[e] = idx[row]  (compact candidate index), sel_index[e] = sel_compact - cand_offset[e] (>= 0),
+//   q_sel[e] = q[row] (0 without rows), explore_w[e] = 1.0 if the env explored and has rows else 0.0
+__global__ __launch_bounds__(256) void k_eps_greedy_select(int E, int n_rows, const int32_t* __restrict__ seg, const float* __restrict__ q,
+                                                           const float* __restrict__ join, const float* __restrict__ u, float eps,
+                                                           int greedy, const int64_t* __restrict__ idx,
+                                                           const int32_t* __restrict__ cand_offset, int64_t* __restrict__ sel_compact,
+                                                           int32_t* __restrict__ sel_index, float* __restrict__ q_sel,
+                                                           float* __restrict__ explore_w) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const int lo = seg[e], hi = seg[e + 1];
+    const bool explore = !greedy && u[e] <= eps;
+    // first maximum of q, or of -join (= first minimum of join), over the env's rows
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lo + lane; j < hi; j += 64) {
+        const float v = explore ? -join[j] : q[j];
+        if (bi == 0x7fffffff || v > best || (v == best && j < bi)) { best = v; bi = j; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float v = __shfl_xor(best, m);
+        const int k = __shfl_xor(bi, m);
+        if (k != 0x7fffffff && (bi == 0x7fffffff || v > best || (v == best && k < bi))) { best = v; bi = k; }
+    }
+    if (lane == 0) {
+        const bool has = hi > lo;
+        int row = has ? bi : 0;
+        if (row > n_rows - 1) row = n_rows - 1;
+        const int64_t c = idx[row];
+        sel_compact[e] = c;
+        const int64_t rel = c - (int64_t)cand_offset[e];
+        sel_index[e] = rel > 0 ? (int32_t)rel : 0;
+        q_sel[e] = has ? q[row] : 0.f;
+        explore_w[e] = (explore && has) ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Transition records of the vectorised loop (robotoddler/training/records.py: one float64 row per transition, the
 // compact form of the reference's Transition, successor_dqn.py:27-44; layout BRIDGES_REC_* of the header).  The torch
 // formulation of these three steps was ~95 slice / cast / index launches of a few microseconds per lock-step.

@@ -173,7 +173,6 @@ class VecDQN:
         idx, row_env = env.valid_rows()
         stable = self._stable_flags(env)
         seg, counts = self._segments(env)
-        sel_row = torch.zeros(E, dtype=torch.long, device=self.device)
         self._q_sel = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
             step_of_row = env.n_blocks[row_env].long()
@@ -184,28 +183,21 @@ class VecDQN:
                 join = ops.bits_dot(env.cand_bits, self.step_images, step_of_row, bits_row=idx)
             else:
                 join = (self.step_images[step_of_row] * env.crop(env.cand_raster[idx])).sum(dim=(1, 2))
-            zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
-            nodone = torch.zeros(E, dtype=torch.uint8, device=self.device)
-            _, _, arg_q = dqn_ops.td_target(seg, q.contiguous().float(), zeros, nodone, 1.0)       # segmented argmax
-            _, _, arg_x = dqn_ops.td_target(seg, (-join).contiguous(), zeros, nodone, 1.0)          # segmented argmin
-            explore = (torch.rand(E, generator=self.explore_gen, device=self.device) <= self.epsilon) & (not greedy)
-            sel_row = torch.where(explore, arg_x.long(), arg_q.long())
-            has = counts > 0
-            sel_row = torch.where(has, sel_row, torch.zeros_like(sel_row))
-            ex = explore & has
+            # greedy row = first maximum of q, exploring row = first minimum of the overlap, per env, in ONE launch
+            # (bridges_eps_greedy_select; an `if explore.any()` here would make the host wait for the Q pass it has just queued)
+            u = torch.rand(E, generator=self.explore_gen, device=self.device)
+            sel_compact, sel_index, self._q_sel, ex_w = ops.eps_greedy_select(seg, q, join, u, self.epsilon, greedy, idx,
+                                                                              env.cand_offset[:E])
             # count images of the explored choices; every env takes part with weight 0 or 1, so no host decision
-            # (an `if ex.any()` here would make the host wait for the Q pass it has just queued)
-            rows = sel_row.clamp(max=idx.numel() - 1)
+            step_of_env = env.n_blocks.long()
             if env.img == 64:                                     # the set pixels of the chosen rasters, by float atomics
-                ops.bits_accumulate_(self.step_images, env.cand_bits, step_of_row[rows], weight=ex.to(torch.float32), bits_row=idx[rows])
+                ops.bits_accumulate_(self.step_images, env.cand_bits, step_of_env, weight=ex_w, bits_row=sel_compact)
             else:
-                picked = env.crop(ops.bits_to_f32(env.cand_bits[idx[rows]])) * ex[:, None, None].to(torch.float32)
-                self.step_images.index_add_(0, step_of_row[rows], picked)
-            sel_compact = idx[sel_row.clamp(max=idx.numel() - 1)]
-            self._q_sel = torch.where(has, q.float()[sel_row.clamp(max=idx.numel() - 1)], self._q_sel)
+                picked = env.crop(ops.bits_to_f32(env.cand_bits[sel_compact])) * ex_w[:, None, None]
+                self.step_images.index_add_(0, step_of_env, picked)
         else:
             sel_compact = torch.zeros(E, dtype=torch.long, device=self.device)
-        sel_index = (sel_compact - env.cand_offset[:E].long()).clamp(min=0).to(torch.int32)
+            sel_index = (sel_compact - env.cand_offset[:E].long()).clamp(min=0).to(torch.int32)
         # the record of the lock-step in two launches around the step (bridges_record_state / _result); the torch formulation
         # R.snapshot + R.make_records (~35 launches) is what tests/test_gpu_vec_dqn.py compares them with
         rec = R.pack_state(env, sel_compact)

@@ -304,6 +304,15 @@ int bridges_shapes_free(bridges_shape* dev);
 int bridges_valid_rows(int32_t E, const int32_t* cand_offset, const int32_t* n_cand, const int32_t* n_valid, const uint8_t* cand_mask,
                        int32_t* seg, int64_t* idx, int64_t* row_env, int32_t* h_total, void* stream);
 
+/* EpsilonGreedy.select (successor_dqn.py:98-132) for every env at once.  Rows seg[e] .. seg[e + 1] of q / join / idx belong to
+ * env e (bridges_valid_rows).  The env explores when u[e] <= eps and greedy == 0: its row is then the FIRST minimum of join (the
+ * overlap of the candidate raster with the count image of the env's episode step), else the FIRST maximum of q.
+ * -> sel_compact[e] = idx[row], sel_index[e] = max(sel_compact - cand_offset[e], 0), q_sel[e] = q[row],
+ *    explore_w[e] = 1 if the env explored (the weight of its count-image update) -- an env without rows: idx[0], 0, 0. */
+int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg, const float* q, const float* join, const float* u,
+                              float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset, int64_t* sel_compact,
+                              int32_t* sel_index, float* q_sel, float* explore_w, void* stream);
+
 /* --- transition records of the vectorised loop ------------------------------------------------------------------
  * One float64 row per transition: the compact form of the reference's Transition (successor_dqn.py:27-44) -- the block
  * list of s, the placed block and the scalars; rasters and candidate sets are re-generated when a record is sampled.

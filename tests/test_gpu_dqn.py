@@ -475,3 +475,41 @@ def test_hand_written_upconv_matches_torch(c_in, c_out, H, W, n):
     ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
     assert out.shape == ref.shape
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("E,amax,eps,greedy", [(1, 5, 0.5, False), (300, 40, 0.3, False), (300, 40, 1.0, False), (257, 150, 0.3, True)])
+def test_eps_greedy_select_matches_the_segmented_torch_formulation(E, amax, eps, greedy):
+    """bridges_eps_greedy_select against the per-env rule written out with torch: first maximum of q, or -- when the env's draw
+    is <= eps -- first minimum of the overlap; ties (quantised values), empty segments and segments longer than a wave."""
+    from bridges_hip import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(E * 7 + amax)
+    counts = torch.randint(0, amax + 1, (E,), generator=g)
+    counts[::5] = 0
+    if int(counts.sum()) == 0:
+        counts[0] = 3
+    seg = torch.zeros(E + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(counts, 0)
+    n = int(seg[E])
+    q = torch.randint(-3, 4, (n,), generator=g).float() * 0.25              # many ties
+    join = torch.randint(0, 5, (n,), generator=g).float()
+    u = torch.rand(E, generator=g)
+    idx = torch.sort(torch.randperm(n * 3, generator=g)[:n]).values          # compact candidate indices, ascending like the env's
+    cand_offset = torch.zeros(E, dtype=torch.int32)
+    for e in range(E):
+        cand_offset[e] = int(idx[seg[e]]) - (e % 3) if counts[e] else int(idx[min(int(seg[e]), n - 1)]) + 5
+    got = ops.eps_greedy_select(seg.to(dev), q.to(dev), join.to(dev), u.to(dev), eps, greedy, idx.to(dev), cand_offset.to(dev))
+    sel_compact, sel_index, q_sel, ex_w = [t.cpu() for t in got]
+    for e in range(E):
+        lo, hi = int(seg[e]), int(seg[e + 1])
+        explore = (not greedy) and bool(u[e] <= torch.tensor(eps, dtype=torch.float32))
+        if hi > lo:
+            row = lo + (int(torch.argmin(join[lo:hi])) if explore else int(torch.argmax(q[lo:hi])))   # torch returns the first extremum
+            v = join[lo:hi] if explore else q[lo:hi]
+            assert row == lo + int((v == (v.min() if explore else v.max())).nonzero()[0])
+        else:
+            row = 0
+        assert int(sel_compact[e]) == int(idx[row]), e
+        assert int(sel_index[e]) == max(int(idx[row]) - int(cand_offset[e]), 0)
+        assert float(q_sel[e]) == (float(q[row]) if hi > lo else 0.0)
+        assert float(ex_w[e]) == (1.0 if (explore and hi > lo) else 0.0)
