@@ -205,7 +205,12 @@ def side_modes(args):
 
     sim("sparse_raster_update", task + ["--sparse-raster-update", "--groups", "3"])
     sim("bit_packed_rasters_only", task + ["--no-f32-rasters", "--groups", "3"])
-    sim("candidate_stability", task + ["--mode", "candidate-stability"])
+    # the LP pass behind the chain of ONE group: its kernels alone on the chip (decisions_per_s = their own rate); then with
+    # three groups, each group's LP pass beside the other groups' rasterisers (tools/cand_groups_sweep.sh: 2.76 / 3.01 / 3.18 M
+    # env-steps/s for 1 / 2 / 3 groups -- the passes stretch beside a rasteriser that holds every wave slot, decisions_per_s_wall
+    # is the figure to read there)
+    sim("candidate_stability", task + ["--mode", "candidate-stability", "--groups", "1"])
+    sim("candidate_stability_3groups", task + ["--mode", "candidate-stability", "--groups", "3"])
     # BASELINE.json configs[4]'s simulator workload: hexagon blocks, bridge-span task, max_steps=15
     # (three env groups: its rasteriser launches are twice as long as the tower task's, so the third group's overlap is
     # worth more than the extra ramp / drain -- tools/hex_groups_sweep.sh: 2.39 / 2.47 / 2.14 M env-steps/s for 2 / 3 / 4)
@@ -409,21 +414,19 @@ def main():
                   candidate_snapshots=cand_mode or args.snapshots, env_id_base=rank * args.envs)
         cand_ev, cand_count = [], []
         if cand_mode:
-            env = VecAssemblyGym(args.envs, geoms, obstacles, targets, **kw)
+            # every group: lock-step, then the LP pass over its valid candidates, on the group's stream -- the latency-bound LPs
+            # of one group run beside the rasteriser of the next (one group, LPs behind the chain: 1.49 ms per lock-step)
+            env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, **kw)
 
             def lockstep():
-                env.select_random()
-                env.step()
-                if len(cand_ev) < 4096:
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    n_dec = env.candidate_stability_mask()
-                    b.record()
-                    cand_ev.append((a, b))
-                    cand_count.append(n_dec)
+                if len(cand_ev) < 4096 * env.G:
+                    timed = []
+                    env.lockstep_random_candidates(timed)
+                    for a, b, n_dec in timed:
+                        cand_ev.append((a, b))
+                        cand_count.append(n_dec)
                 else:
-                    env.candidate_stability_mask()
-            env.sync = lambda: None
+                    env.lockstep_random_candidates()
         else:
             env = VecAssemblyGymGroups(args.envs, geoms, obstacles, targets, groups=args.groups, **kw)
             lockstep = env.lockstep_random
@@ -569,13 +572,18 @@ def main():
             torch.cuda.synchronize()
             ms = sum(a.elapsed_time(b) for a, b in cand_ev)
             n_dec = int(sum(int(c) for c in cand_count))
-            total = env.total_candidates()
-            cst = env.cand_stable[:total][env.cand_mask[:total].bool()]
+            g0 = env.envs[-1]                           # verdict counts of the last lock-step: one group's candidates
+            total = g0.total_candidates()
+            cst = g0.cand_stable[:total][g0.cand_mask[:total].bool()]
+            n_ls = max(len(cand_ev) // env.G, 1)
             out["candidate_stability"] = {
+                # decisions_per_s: over the LP passes' own durations (each group's pass timed on its stream, beside whatever the
+                # other groups run); decisions_per_s_wall: over the wall time of the whole run (simulator included)
                 "decisions": n_dec, "decisions_per_s": n_dec / (ms * 1e-3) if ms > 0 else 0.0, "unit": "LPs/s",
-                "ms_per_lockstep": ms / max(len(cand_ev), 1), "decisions_per_lockstep": n_dec / max(len(cand_ev), 1),
+                "decisions_per_s_wall": n_dec / runs[-1]["dt"] if runs[-1]["dt"] > 0 else 0.0,
+                "ms_per_lockstep": ms / n_ls, "decisions_per_lockstep": n_dec / n_ls, "groups": env.G,
                 "last_lockstep": {"stable": int((cst == 1).sum()), "unstable": int((cst == 0).sum()), "errors": int((cst == 2).sum()),
-                                  "queued_large_tableaux": int(env.cand_counters[0])}}
+                                  "queued_large_tableaux": int(g0.cand_counters[0])}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world > 1:

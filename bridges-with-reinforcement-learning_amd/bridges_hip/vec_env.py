@@ -527,6 +527,27 @@ class VecAssemblyGymGroups:
             if rc != 0:
                 abi.check(rc, "bridges_env_lockstep_random")
 
+    def lockstep_random_candidates(self, timed=None):
+        """lockstep_random, then is_action_stable_rbe for every valid candidate of the new states (candidate_stability_mask),
+        group by group on the groups' own streams: the latency-bound LP pass of one group runs beside the bandwidth-bound
+        rasteriser of the next.  The envs must have been created with candidate_snapshots=True.  ``timed``: a list that
+        receives (start event, end event, decisions as a device scalar) of every group's LP pass."""
+        fn = self.envs[0].L.bridges_env_lockstep_random
+        for env, st, sp in zip(self.envs, self.streams, self._stream_ptrs):
+            with torch.cuda.stream(st):
+                rc = fn(env._env, sp)
+                env._cand_version += 1
+                if rc != 0:
+                    abi.check(rc, "bridges_env_lockstep_random")
+                if timed is not None:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    n = env.candidate_stability_mask()
+                    b.record()
+                    timed.append((a, b, n))
+                else:
+                    env.candidate_stability_mask()
+
     def timing_begin(self, max_launches):
         for env in self.envs:
             env.timing_begin(max_launches)

@@ -36,12 +36,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     vals = sorted(p["value"] for p in j["config"]["per_seed"])
     assert j["value"] == pytest.approx(vals[1]) and j["config"]["seed_of_value"] in (0, 1, 2)      # the median run
     om = j["other_modes"]
-    assert set(om) == {"sparse_raster_update", "bit_packed_rasters_only", "candidate_stability", "config5_hexagon_bridge"}
+    assert set(om) == {"sparse_raster_update", "bit_packed_rasters_only", "candidate_stability", "candidate_stability_3groups",
+                       "config5_hexagon_bridge"}
     for k, v in om.items():
         assert "error" not in v, (k, v)
         assert v["value"] > 1e4
-    cs = om["candidate_stability"]["candidate_stability"]
-    assert cs["decisions_per_s"] > 1e5 and cs["last_lockstep"]["errors"] == 0
+    for leg, groups in (("candidate_stability", 1), ("candidate_stability_3groups", 3)):
+        cs = om[leg]["candidate_stability"]
+        assert cs["decisions_per_s"] > 1e5 and cs["decisions_per_s_wall"] > 1e5 and cs["last_lockstep"]["errors"] == 0 and cs["groups"] == groups
     assert "hexagon" in om["config5_hexagon_bridge"]["workload"]
 
 
