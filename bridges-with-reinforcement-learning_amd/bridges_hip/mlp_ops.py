@@ -40,6 +40,28 @@ def linear_backward(dz, a_in, weight, act_below=None, need_input_grad=True, ws=N
     return dW, db, below
 
 
+def mid_rows(h_pre, linears):
+    """The Linear + ReLU layers ``linears`` (the reference's 256-128-64-128-256 stack) applied to relu(h_pre) for every row, in
+    one launch (bridges_mlp_mid_rows); returns None when the library is not built for the stack (the caller then runs the
+    layers one by one).  h_pre [n, 256] float32 with contiguous rows."""
+    L = abi.require_gpu()
+    n = len(linears)
+    if n == 0 or h_pre.dtype != torch.float32 or h_pre.dim() != 2 or h_pre.stride(1) != 1:
+        return None
+    dims = (C.c_int32 * (n + 1))(linears[0].in_features, *[l.out_features for l in linears])
+    if h_pre.shape[1] != linears[0].in_features or not L.bridges_mlp_mid_supported(32, n, dims):
+        return None
+    if h_pre.stride(0) % 4 or h_pre.data_ptr() % 16 or any(l.weight.data_ptr() % 16 or not l.weight.is_contiguous() for l in linears):
+        return None
+    VP = C.c_void_p * n
+    out = torch.empty((h_pre.shape[0], linears[-1].out_features), dtype=torch.float32, device=h_pre.device)
+    mid = torch.empty((h_pre.shape[0], 64), dtype=torch.float32, device=h_pre.device)
+    abi.check(L.bridges_mlp_mid_rows(h_pre.shape[0], n, dims, VP(*[l.weight.data_ptr() for l in linears]),
+                                     VP(*[l.bias.data_ptr() for l in linears]), _ptr(h_pre), h_pre.stride(0), _ptr(out), out.stride(0),
+                                     _ptr(mid), _stream()), "bridges_mlp_mid_rows")
+    return out
+
+
 class FusedSuccessorStep:
     """Static buffers + launch sequence of one SuccessorMLP training step for a fixed batch size.
 

@@ -757,6 +757,26 @@ int bridges_mlp_mid_forward(int32_t rows, int32_t n_layers, const int32_t* dims,
     return BRIDGES_OK;
 }
 
+int bridges_mlp_mid_rows(int32_t n_rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
+                         const float* x, int64_t x_stride, float* y, int64_t y_stride, float* mid, void* stream) {
+    if (n_rows < 0 || !mid_dims_supported(n_layers, dims) || !W || !bias || !x || !y || !mid || x_stride < dims[0] || y_stride < dims[4] ||
+        (x_stride & 3) || ((uintptr_t)x & 15) || ((uintptr_t)mid & 15))
+        return fail_arg("bridges_mlp_mid_rows: 256-128-64-128-256 only, 16-byte aligned input rows, scratch of n x 64 floats");
+    if (n_rows == 0) return BRIDGES_OK;
+    for (int l = 0; l < 4; ++l)
+        if (!W[l] || !bias[l] || (((uintptr_t)W[l]) & 15)) return fail_arg("bridges_mlp_mid_rows");
+    const int n_tiles = (n_rows + 31) / 32;
+    const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_rows2<256, 128, 64, true>), grid, dim3(1024), 0, st, W[0], bias[0], W[1], bias[1], (int)n_rows, x, x_stride, mid,
+                       (int64_t)64);
+    LAUNCH_CHECK("k_rows2<256,128,64>");
+    hipLaunchKernelGGL((k_rows2<64, 128, 256, false>), grid, dim3(1024), 0, st, W[2], bias[2], W[3], bias[3], (int)n_rows, (const float*)mid,
+                       (int64_t)64, y, y_stride);
+    LAUNCH_CHECK("k_rows2<64,128,256>");
+    return BRIDGES_OK;
+}
+
 int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
                              float* const* db, float* const* acts, float* const* dz, void* stream) {
     if (rows != 32 || !mid_dims_supported(n_layers, dims) || !dW || !db || !dz) return fail_arg("bridges_mlp_mid_backward: 32 rows of 256-128-64-128-256 only");

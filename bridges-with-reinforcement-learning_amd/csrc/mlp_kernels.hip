@@ -577,7 +577,7 @@ __device__ __forceinline__ void mid_fwd_load(const float* __restrict__ W, const 
 // x in LDS [32][K + MID_PAD] -> y = relu(x . W^T + b) of the job's tile into LDS [32][N + MID_PAD] (ys) and / or memory (yg)
 template <int K, int N>
 __device__ __forceinline__ void mid_fwd_job(const f4u (&w)[K / 32], float bv, int job, bool live, const float* xs, float* ys,
-                                            float* __restrict__ yg, float (*red)[3][16][64], int lane) {
+                                            float* __restrict__ yg, float (*red)[3][16][64], int lane, int rows_left = 32) {
     const int row = lane & 31, half = lane >> 5;
     const int nt = job >> 2, q = job & 3;
     f32x16 acc;
@@ -608,7 +608,47 @@ __device__ __forceinline__ void mid_fwd_job(const f4u (&w)[K / 32], float bv, in
             v = v > 0.f ? v : 0.f;
             const int m = mfma_row(r, lane);
             if (ys) ys[m * (N + MID_PAD) + n] = v;
-            if (yg) yg[(size_t)m * N + n] = v;
+            if (yg && m < rows_left) yg[(size_t)m * N + n] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// the same job with the result going to memory only, row stride y_stride, rows < rows_left
+template <int K, int N>
+__device__ __forceinline__ void mid_fwd_job_strided(const f4u (&w)[K / 32], float bv, int job, bool live, const float* xs,
+                                                    float* __restrict__ yg, int64_t y_stride, float (*red)[3][16][64], int lane,
+                                                    int rows_left) {
+    const int row = lane & 31, half = lane >> 5;
+    const int nt = job >> 2, q = job & 3;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (live) {
+        const float* xp = xs + row * (K + MID_PAD) + q * (K / 4) + 4 * half;
+#pragma unroll
+        for (int u = 0; u < K / 32; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(xp + 8 * u);
+            acc = mfma32(a.x, w[u].x, acc);
+            acc = mfma32(a.y, w[u].y, acc);
+            acc = mfma32(a.z, w[u].z, acc);
+            acc = mfma32(a.w, w[u].w, acc);
+        }
+        if (q > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[nt & 3][q - 1][r][lane] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (live && q == 0) {
+        const int n = nt * 32 + row;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = ((acc[r] + red[nt & 3][0][r][lane]) + red[nt & 3][1][r][lane]) + red[nt & 3][2][r][lane];
+            v += bv;
+            v = v > 0.f ? v : 0.f;
+            const int m = mfma_row(r, lane);
+            if (m < rows_left) yg[(size_t)m * y_stride + n] = v;
         }
     }
     __syncthreads();
@@ -640,6 +680,64 @@ __global__ __launch_bounds__(1024) void k_mid_fwd(MidPtrs p) {
     mid_fwd_job<D1, D2>(w1, b1, wave, l1, xb, xa, first ? p.act[2] : nullptr, red, lane);
     mid_fwd_job<D2, D3>(w2, b2, wave, l2, xa, xb, first ? p.act[3] : nullptr, red, lane);
     mid_fwd_job<D3, D4>(w3, b3, job3, l3, xb, nullptr, p.act[4], red, lane);
+}
+
+// The same layers for MANY rows (the acting / target forward between the first layer and the head, cv.py:20-38 inside
+// SuccessorMLP.forward), two layers per launch: y = relu(relu(x' . Wa^T + ba) . Wb^T + bb) with x' = relu(x) if RELU_IN (x the
+// pre-activation of the layer in front) else x.  A workgroup keeps the weight fragments of both layers in registers (all four
+// layers' 160 registers per thread do not fit beside the accumulators at any workgroup size that fills the matrix pipes: 108
+// spills at 16 waves, 39 at 8) and walks over 32-row tiles (grid-stride): tile into LDS, layer a into LDS, layer b to memory; the
+// next tile's rows are requested while the current one computes.  Two launches replace four library GEMM calls (20-77 us of
+// host time each), their ReLU passes and two of the three [n, 64..256] intermediates; tile by tile the arithmetic of k_mid_fwd /
+// k_lin_fwd, so the acting forward and the training forward agree bit for bit on these layers.
+template <int DA, int DB, int DC, bool RELU_IN>
+__global__ __launch_bounds__(1024) void k_rows2(const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ Wb,
+                                                const float* __restrict__ bb, int n_rows, const float* __restrict__ x, int64_t x_stride,
+                                                float* __restrict__ y, int64_t y_stride) {
+    constexpr int JA = (DB / 32) * 4, JB = (DC / 32) * 4, RB = (JB + 15) / 16, PER = 32 * DA / 1024;     // PER floats of a tile per thread
+    static_assert(JA <= 16 && RB <= 2 && (PER == 8 || PER == 2), "layer widths outside what this kernel covers");
+    __shared__ __attribute__((aligned(16))) float xa[32 * (DA + MID_PAD)], xb[32 * (DB + MID_PAD)];
+    __shared__ float red[4][3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool la = wave < JA;
+    f4u wa[DA / 32], wb[RB][DB / 32];
+    float bva = 0.f, bvb[RB];
+    mid_fwd_load<DA>(Wa, ba, wave, la, lane, wa, bva);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { bvb[r] = 0.f; mid_fwd_load<DB>(Wb, bb, r * 16 + wave, r * 16 + wave < JB, lane, wb[r], bvb[r]); }
+    const int n_tiles = (n_rows + 31) / 32;
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    // this thread's PER consecutive floats of a tile: row e / DA, column e % DA with e = PER * threadIdx.x
+    const int trow = (PER * threadIdx.x) / DA, tcol = (PER * threadIdx.x) % DA;
+    float v[PER];
+#define ROWS2_FETCH(t_)                                                                                        \
+    {                                                                                                          \
+        int r_ = (t_) * 32 + trow;                                                                             \
+        r_ = r_ < n_rows ? r_ : n_rows - 1;                      /* rows beyond n read row n - 1, never stored */ \
+        const float* src_ = x + (size_t)r_ * x_stride + tcol;                                                  \
+        if constexpr (PER == 8) {                                                                              \
+            const float4 q0_ = *reinterpret_cast<const float4*>(src_), q1_ = *reinterpret_cast<const float4*>(src_ + 4); \
+            v[0] = q0_.x; v[1] = q0_.y; v[2] = q0_.z; v[3] = q0_.w; v[4] = q1_.x; v[5] = q1_.y; v[6] = q1_.z; v[7] = q1_.w; \
+        } else {                                                                                               \
+            const float2 q0_ = *reinterpret_cast<const float2*>(src_);                                         \
+            v[0] = q0_.x; v[1] = q0_.y;                                                                        \
+        }                                                                                                      \
+    }
+    ROWS2_FETCH(tile)
+    for (; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) xa[trow * (DA + MID_PAD) + tcol + j] = (RELU_IN && !(v[j] > 0.f)) ? 0.f : v[j];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) ROWS2_FETCH(next)                          // in flight under this tile's layers
+        mid_fwd_job<DA, DB>(wa, bva, wave, la, xa, xb, nullptr, red, lane);
+        float* yt = y + (size_t)tile * 32 * y_stride;
+        const int left = n_rows - tile * 32;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) mid_fwd_job_strided<DB, DC>(wb[r], bvb[r], r * 16 + wave, r * 16 + wave < JB, xb, yt, y_stride, red, lane, left);
+    }
+#undef ROWS2_FETCH
 }
 
 // backward job = (k tile << 2) | quarter of N: W fragments B[kk = n][j = k]

@@ -151,10 +151,32 @@ class SuccessorMLP(nn.Module):
         [n, 4*px+f] input, the other 2*px+2f-px outputs or the softmax of the module forward."""
         lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
+        h = self._middle_layers(h_pre, lin)
+        return torch.addmm(lin[-1].bias[:px], h, lin[-1].weight[:px].T)
+
+    @staticmethod
+    def _middle_layers(h_pre, lin):
+        """relu(h_pre) through the Linear + ReLU layers between the first and the last (inference)."""
+        n = h_pre.shape[0]
+        if h_pre.is_cuda and len(lin) > 2:
+            from bridges_hip import mlp_ops
+            h = mlp_ops.mid_rows(h_pre, lin[1:-1])                  # the whole stack in one launch where the library has it
+            if h is not None:
+                return h
+            # the row count changes with every call, and a row count the GEMM library has not seen costs 77 us of host time per
+            # call against 20 us for one it has (tools/addmm_host_cost.py): the layers run on the rows padded to a multiple
+            # of 512 (zero rows, sliced off below), so a run meets a handful of shapes instead of thousands
+            n_pad = -(-n // 512) * 512
+            h = torch.empty((n_pad, h_pre.shape[1]), dtype=h_pre.dtype, device=h_pre.device)
+            torch.clamp(h_pre, min=0, out=h[:n])                                 # relu into the padded buffer
+            h[n:].zero_()
+            for layer in lin[1:-1]:
+                h = torch._addmm_activation(layer.bias, h, layer.weight.T)       # bias + ReLU in the library GEMM's epilogue
+            return h[:n]
         h = F.relu(h_pre)
         for layer in lin[1:-1]:
             h = F.relu(layer(h))
-        return torch.addmm(lin[-1].bias[:px], h, lin[-1].weight[:px].T)
+        return h
 
     @torch.no_grad()
     def q_from_first_layer(self, h_pre, reward_features, head=None, fused_head=None):
@@ -163,23 +185,7 @@ class SuccessorMLP(nn.Module):
         256 -- ``fused_head(h, Wd, bd, w) -> sum_j w[j] * sigmoid(h . Wd[j] + bd[j])``, which never stores the [n, px] product."""
         lin = [m for m in self.mlp.layers if isinstance(m, nn.Linear)]
         px = self.img_size[0] * self.img_size[1]
-        n = h_pre.shape[0]
-        if h_pre.is_cuda and len(lin) > 2:
-            # the row count changes with every call, and a row count the GEMM library has not seen costs 77 us of host time per
-            # call against 20 us for one it has (tools/addmm_host_cost.py): the middle layers run on the rows padded to a
-            # multiple of 512 (zero rows, sliced off below), so a run meets a handful of shapes instead of thousands
-            n_pad = -(-n // 512) * 512
-            h = torch.empty((n_pad, h_pre.shape[1]), dtype=h_pre.dtype, device=h_pre.device)
-            torch.clamp(h_pre, min=0, out=h[:n])                                 # relu into the padded buffer
-            h[n:].zero_()
-        else:
-            h = F.relu(h_pre)
-        for layer in lin[1:-1]:
-            if h.is_cuda:
-                h = torch._addmm_activation(layer.bias, h, layer.weight.T)       # bias + ReLU in the library GEMM's epilogue
-            else:
-                h = F.relu(layer(h))
-        h = h[:n]
+        h = self._middle_layers(h_pre, lin)
         Wo, bo = lin[-1].weight, lin[-1].bias
         if fused_head is not None and h.shape[1] == 256:
             return fused_head(h, Wo[px:2 * px] - Wo[:px], bo[px:2 * px] - bo[:px], reward_features.reshape(px))

@@ -402,6 +402,13 @@ int bridges_mlp_mid_forward(int32_t rows, int32_t n_layers, const int32_t* dims,
                             float* const* acts, void* stream);
 int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
                              float* const* db, float* const* acts, float* const* dz, void* stream);
+/* The same stack for MANY rows -- the acting / target forward between the first layer and the head (cv.py:20-38 inside
+ * SuccessorMLP.forward): y [n, 256] = the four Linear + ReLU layers applied to relu(x), x [n, 256] the pre-activation of the
+ * layer in front (row strides in floats); mid = scratch of n x 64 floats (the narrow activation between the two launches).
+ * Two launches of two layers each instead of four library GEMMs; the arithmetic of the training step's forward, tile by tile.
+ * dims / W / bias as for bridges_mlp_mid_forward. */
+int bridges_mlp_mid_rows(int32_t n_rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
+                         const float* x, int64_t x_stride, float* y, int64_t y_stride, float* mid, void* stream);
 /* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
  * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
  * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further

@@ -265,3 +265,29 @@ def test_middle_layer_stack_equals_the_per_layer_launches(hidden, with_adam, mon
         assert torch.equal(qa, qb)
         for x, y in zip(ga, gb):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n", [1, 32, 45, 1000, 8209])
+def test_middle_stack_for_many_rows_equals_the_layer_by_layer_forward(n):
+    """bridges_mlp_mid_rows (the acting forward's middle layers, two launches) against bridges_linear_forward layer by layer on
+    the same rows: bit for bit (same tiles, same order), and within 1e-5 of the float64 product; rows beyond n untouched."""
+    from bridges_hip import mlp_ops
+    net = make_net(seed=11)
+    lin = [m for m in net.mlp.layers if isinstance(m, torch.nn.Linear)]
+    g = torch.Generator(device="cpu").manual_seed(n)
+    h_pre = torch.randn((n, 256), generator=g).to(DEV)
+    got = mlp_ops.mid_rows(h_pre, lin[1:-1])
+    assert got is not None and tuple(got.shape) == (n, 256)
+    rows = 32 * ((n + 31) // 32)
+    a = torch.zeros((rows, 256), device=DEV)
+    a[:n] = torch.relu(h_pre)
+    ref64 = torch.relu(h_pre).double()
+    for l in lin[1:-1]:
+        a = mlp_ops.linear_forward(a, l.weight, l.bias, relu=True)
+        ref64 = torch.relu(ref64 @ l.weight.double().T + l.bias.double())
+    assert torch.equal(got, a[:n])
+    assert rel_err(got, ref64.float()) < 1e-5
+    # a strided view as input (rows of a wider buffer)
+    wide = torch.zeros((n, 320), device=DEV)
+    wide[:, :256] = h_pre
+    assert torch.equal(mlp_ops.mid_rows(wide[:, :256], lin[1:-1]), got)
