@@ -224,6 +224,7 @@ class VecAssemblyGym:
                   "bridges_bits_to_f32")
         self.obstacle_raster = self.crop(oimg)                            # [1,S,S] f32
         self.reward_features = self.crop(self.buf["reward_map"].unsqueeze(0))   # [1,S,S] f32
+        self._reward_obstacle_flat = None                                        # (cache of the trainer: both maps, flattened)
 
     def crop(self, images):
         """[..., 64, 64] canvas -> the [..., S, S] image (a no-op view for the default S = 64)."""

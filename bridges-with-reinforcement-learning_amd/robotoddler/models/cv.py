@@ -144,6 +144,16 @@ class SuccessorMLP(nn.Module):
         return binary_features @ W1[:, 4 * px:].T + const
 
     @torch.no_grad()
+    def first_layer_stable_table(self, reward_obstacle):
+        """first_layer_env_terms for the binary vectors the simulator produces, [stable, 0, 0, 0, 0, 0] (the five collision
+        flags are 0 without pybullet, assembly_env.py:311-312): a [2, hidden] table, row s = the terms of an env with stable = s.
+        ``reward_obstacle`` = the flattened reward map followed by the flattened obstacle raster ([2 px])."""
+        px = self.img_size[0] * self.img_size[1]
+        lin = self.first_layer()
+        const = torch.addmv(lin.bias, lin.weight[:, 2 * px:4 * px], reward_obstacle)
+        return torch.stack([const, const + lin.weight[:, 4 * px]])
+
+    @torch.no_grad()
     def sf0_from_first_layer(self, h_pre):
         """Channel 0 of the successor block features (``forward(...)[1][:, 0]`` flattened to [n, px]) from the
         pre-activation of the first layer: the remaining hidden layers and the first px rows of the output layer -- what the

@@ -140,12 +140,13 @@ class VecDQN:
         # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice is the
         # sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
         px, E = 64 * 64, env.E
-        binary = torch.zeros((E, 6), dtype=torch.float32, device=self.device)
-        binary[:, 0] = stable.float()
         W1 = net.first_layer().weight
-        base = ops.bits_linear(env.state_bits, W1[:, :px].T,
-                               base=net.first_layer_env_terms(binary, env.reward_features, env.obstacle_raster),
-                               base_row=torch.arange(E, device=self.device))
+        # the part of the first layer that does not depend on the images: a two-row table indexed by the env's stable flag
+        # (the other binary features are 0, as in the reference without pybullet)
+        ro = getattr(env, "_reward_obstacle_flat", None)
+        if ro is None:
+            ro = env._reward_obstacle_flat = torch.cat([env.reward_features.reshape(-1), env.obstacle_raster.reshape(-1)]).contiguous()
+        base = ops.bits_linear(env.state_bits, W1[:, :px].T, base=net.first_layer_stable_table(ro), base_row=stable.long())
         h_pre = ops.bits_linear(env.cand_bits, W1[:, px:2 * px].T, bits_row=idx, base=base, base_row=row_env)
         q = net.q_from_first_layer(h_pre, env.reward_features, head=ops.sigmoid_dot, fused_head=ops.head_sigmoid_dot)
         return (q, h_pre) if return_h else q
