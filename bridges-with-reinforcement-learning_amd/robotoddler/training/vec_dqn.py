@@ -139,7 +139,7 @@ class VecDQN:
             return self._forward_rows(net, env, idx, row_env, stable)[0]
         # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice is the
         # sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
-        px, E = 64 * 64, env.E
+        px = 64 * 64
         W1 = net.first_layer().weight
         # the part of the first layer that does not depend on the images: a two-row table indexed by the env's stable flag
         # (the other binary features are 0, as in the reference without pybullet)
@@ -173,7 +173,7 @@ class VecDQN:
         env, E = self.env, self.env.E
         idx, row_env = env.valid_rows()
         stable = self._stable_flags(env)
-        seg, counts = self._segments(env)
+        seg = env.valid_segments()
         self._q_sel = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
             step_of_row = env.n_blocks[row_env].long()
@@ -231,7 +231,7 @@ class VecDQN:
         one target-net forward and one k_td_target launch for n_steps * batch_size transitions."""
         n = rec.shape[0]
         renv = self._replay_env(n)
-        K, E = renv.K, renv.E
+        E = renv.E
         # state s' (= s + action block): candidates, masks, rasters by the same kernels as the rollout; s is the
         # prefix of its block list, so its raster comes out of the same per-block bit rasters.  One launch unpacks the
         # records into the scratch env (envs beyond n repeat record 0 and are sliced off below); R.unpack_states +
