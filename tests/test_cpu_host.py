@@ -419,3 +419,26 @@ def test_host_reward_map_equals_the_reference_convolution():
         np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
         np.testing.assert_allclose(got, R.convolve_with_gaussian(img.astype(np.float64)), rtol=1e-6, atol=1e-9)
         assert np.array_equal(got, gaussian_reward_map(img))
+
+
+def test_single_rank_record_selection_with_a_known_count_equals_the_boolean_index():
+    """all_gather_records(rec, valid, n_valid): the single-rank selection that does not read a count back from the device."""
+    from robotoddler.training import distributed as D
+    from robotoddler.training import records as R
+    g = torch.Generator().manual_seed(2)
+    rec = torch.randn((37, R.RECORD_WIDTH), generator=g, dtype=torch.float64)
+    for p in (0.0, 0.4, 1.0):
+        valid = torch.rand(37, generator=g) < p
+        got = D.all_gather_records(rec, valid, n_valid=int(valid.sum()))
+        assert torch.equal(got, rec[valid]) and torch.equal(D.all_gather_records(rec, valid), rec[valid])
+    assert D.world_size() == 1
+
+
+def test_head_column_split_heuristic_covers_every_tile():
+    """ops._head_splits: a power of two <= the tile count for every row count (the launch then covers all column tiles)."""
+    from bridges_hip import ops
+    for n in (1, 31, 129, 800, 9000, 45056, 200000):
+        for tiles in (1, 4, 128):
+            s = ops._head_splits(n, tiles)
+            assert s in (1, 2, 4, 8, 16, 32) and s <= max(tiles, 1)
+    assert ops._head_splits(45056, 128) == 8
