@@ -244,13 +244,18 @@ class FusedSuccessorStep:
             abi.check(L.bridges_linear_forward(rows, lin.in_features, lin.out_features, _ptr(x0 if l == 0 else self.acts[l]),
                                                _ptr(lin.weight), _ptr(lin.bias), int(l < last), _ptr(self.acts[l + 1]), _ptr(self.ws),
                                                self.ws.numel(), blk if l == 0 else None, st), "bridges_linear_forward")
-        # the loss kernel's last-arriving row workgroup logs the loss, advances the batch counter and the Adam step count
+        # logging the loss, advancing the batch counter and the Adam step count need every row's loss: that rides in the head
+        # layer's backward launch (bridges_linear_backward_log, one thread beside its jobs) -- the loss kernel itself hands
+        # nothing between workgroups.  (A net whose head is also its first layer keeps the loss kernel's ticket form.)
+        log_in_backward = last >= 1 and os.environ.get("BRIDGES_LOSS_TICKET", "0") != "1"
         abi.check(L.bridges_successor_loss(B, rows, px, nf, _ptr(self.acts[-1]), _ptr(reward), _ptr(counter),
                                            _ptr(q_target_all) if self.use_q else None,
                                            _ptr(sf_target_all) if self.use_sf else None, int(self.use_q), int(self.use_sf),
-                                           _ptr(self.dz[-1]), _ptr(self.loss_rows), _ptr(self.q), _ptr(losses),
-                                           losses.numel(), _ptr(counter), _ptr(self.ticket),
-                                           _ptr(self.adam_step) if self.fused_adam else None, st), "bridges_successor_loss")
+                                           _ptr(self.dz[-1]), _ptr(self.loss_rows), _ptr(self.q),
+                                           None if log_in_backward else _ptr(losses), losses.numel(),
+                                           None if log_in_backward else _ptr(counter), None if log_in_backward else _ptr(self.ticket),
+                                           _ptr(self.adam_step) if (self.fused_adam and not log_in_backward) else None, st),
+                  "bridges_successor_loss")
         # the whole optimiser update rides in the LAST backward launch (the first layer's, which has no input gradient):
         # Adam goes into its weight-gradient tiles and extra workgroups of that launch update the other layers, whose
         # gradients are complete and whose weights nothing reads any more.  (Adam launches on a parallel branch of the
@@ -272,6 +277,14 @@ class FusedSuccessorStep:
                                                          off(self.flat), off(self.grad_flat), off(self.m_flat), off(self.v_flat),
                                                          hi - lo, _ptr(self.adam_step), self.lr, self.beta1, self.beta2, self.eps, blk,
                                                          -1, st), "bridges_linear_backward_adam")      # -1: the loss kernel advanced the counter
+                continue
+            if l == last and log_in_backward:
+                abi.check(L.bridges_linear_backward_log(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]), _ptr(self.acts[l]),
+                                                        _ptr(lin.weight), _ptr(lin.weight.grad), _ptr(lin.bias.grad), _ptr(self.acts[l]),
+                                                        _ptr(self.dz[l - 1]), _ptr(self.ws), self.ws.numel(), _ptr(self.loss_rows), B,
+                                                        _ptr(losses), losses.numel(), _ptr(counter),
+                                                        _ptr(self.adam_step) if self.fused_adam else None, st),
+                          "bridges_linear_backward_log")
                 continue
             abi.check(L.bridges_linear_backward(rows, lin.in_features, lin.out_features, _ptr(self.dz[l]),
                                                 _ptr(x0 if l == 0 else self.acts[l]), _ptr(lin.weight), _ptr(lin.weight.grad),

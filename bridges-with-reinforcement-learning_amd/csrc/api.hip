@@ -685,9 +685,9 @@ int bridges_linear_forward(int32_t rows, int32_t K, int32_t N, const float* x, c
     return BRIDGES_OK;
 }
 
-int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
-                            float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
-                            const int64_t* a_block, int32_t a_block_bias, void* stream) {
+static int linear_backward_impl(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                                float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                                const int64_t* a_block, int32_t a_block_bias, LossLog log, void* stream) {
     if (rows <= 0 || (rows & 31) || K <= 0 || N <= 0 || !dz || !a_in || !W || !dW || !db) return fail_arg("bridges_linear_backward");
     const int n_ntiles = ceil_div(N, 32), n_ktiles = ceil_div(K, 32), m_tiles = rows / 32;
     int per_job = ceil_div(n_ntiles * n_ktiles, 1024);           // k tiles per dW job: ~1024 jobs on the big layers
@@ -710,7 +710,7 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
     // one split: the input gradient goes straight to dz_below (masked), no partial sums
     hipLaunchKernelGGL(k_lin_bwd<false>, dim3(n_dw_jobs + n_dx_jobs), dim3(256), 0, st, rows, K, N, dz, a_in, W, dW, db,
                        !dz_below ? (float*)nullptr : (nsplit == 1 ? dz_below : ws), nsplit == 1 ? act_below : (const float*)nullptr,
-                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{}, a_block, (int)a_block_bias);
+                       n_dw_jobs, per_job, nsplit, nchunk, AdamFold{}, a_block, (int)a_block_bias, log);
     LAUNCH_CHECK("k_lin_bwd");
     if (dz_below && nsplit > 1) {
         int blocks = ceil_div(rows * K, 256);
@@ -719,6 +719,21 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
         LAUNCH_CHECK("k_lin_dx_finish");
     }
     return BRIDGES_OK;
+}
+
+int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                            float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                            const int64_t* a_block, int32_t a_block_bias, void* stream) {
+    return linear_backward_impl(rows, K, N, dz, a_in, W, dW, db, act_below, dz_below, ws, ws_floats, a_block, a_block_bias, LossLog{}, stream);
+}
+
+int bridges_linear_backward_log(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                                float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                                const float* loss_rows, int32_t batch, float* losses, int32_t n_losses, int64_t* counter,
+                                float* adam_step, void* stream) {
+    if (!loss_rows || batch <= 0 || batch > rows || !counter || (losses && n_losses <= 0)) return fail_arg("bridges_linear_backward_log");
+    return linear_backward_impl(rows, K, N, dz, a_in, W, dW, db, act_below, dz_below, ws, ws_floats, nullptr, 0,
+                                LossLog{loss_rows, (int)batch, losses, (int)n_losses, counter, adam_step}, stream);
 }
 
 // the middle stack the k_mid_* kernels are instantiated for: SuccessorMLP's 256-128-64-128-256 (successor_dqn.py:366)
@@ -813,7 +828,7 @@ int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float
                 rest_param, rest_grad, rest_exp_avg, rest_exp_avg_sq, (long long)rest_n};
     hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
                        (const float*)W, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job,
-                       0, 0, ad, a_block, (int)a_block_bias);
+                       0, 0, ad, a_block, (int)a_block_bias, LossLog{});
     LAUNCH_CHECK("k_lin_bwd<adam>");
     return BRIDGES_OK;
 }

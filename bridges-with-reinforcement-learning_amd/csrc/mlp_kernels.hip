@@ -169,14 +169,35 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 //     the first k group also write db[n] = sum_b dz[b][n].
 //   jobs [n_dw_jobs, ...): dxpart[split][b][k] = sum_{n in split} dz[b][n] * W[n][k]  (k_lin_dx_finish adds the splits
 //     and applies the ReLU mask of the layer below; with one split act_mask is given and the masked sum is final).
+// Book-keeping of the step that needs every row's loss: losses[*counter] = sum_b loss_rows[b] (row order: the same float as
+// k_loss_log), ++*counter, ++*adam_step.  It rides in the head layer's backward launch -- the first launch behind the loss
+// kernel, which neither reads the batch counter nor the optimiser's step count -- as one thread's work beside the launch's
+// jobs: the loss rows come from a finished kernel (plain loads), nothing waits for it.  (Until late in round 3 the loss
+// kernel's last-arriving workgroup did this behind an agent-scope ticket: four device-scope round trips at the end of a
+// 10 us kernel on the step's critical chain.)
+struct LossLog {
+    const float* loss_rows; int batch; float* losses; int n_losses; int64_t* counter; float* adam_step;
+};
+__device__ __forceinline__ void loss_log_apply(const LossLog& g) {
+    float l = 0.f;
+    for (int b = 0; b < g.batch; ++b) l += g.loss_rows[b];
+    const int64_t c = *g.counter;
+    if (g.losses && c >= 0 && c < g.n_losses) g.losses[c] = l;
+    *g.counter = c + 1;
+    if (g.adam_step) *g.adam_step = *g.adam_step + 1.f;
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const float* __restrict__ dz,
                                                  const float* __restrict__ a, const float* __restrict__ W,
                                                  float* __restrict__ dW, float* __restrict__ db,
                                                  float* __restrict__ dxpart, const float* __restrict__ act_mask,
                                                  int n_dw_jobs, int ktiles_per_job, int nsplit, int nchunk, AdamFold ad,
-                                                 const int64_t* __restrict__ a_block, int a_block_bias) {
+                                                 const int64_t* __restrict__ a_block, int a_block_bias, LossLog log) {
     __shared__ float red[3][16][64];
+    if constexpr (!ADAM) {
+        if (log.counter && blockIdx.x == 0 && threadIdx.x == 0) loss_log_apply(log);      // (a_block is null in such a launch)
+    }
     // block *a_block + a_block_bias of a [n_blocks * rows, K] array of layer inputs (bias -1: the step's loss kernel has
     // already advanced the batch counter the forward pass read)
     if (a_block) a += (size_t)(*a_block + a_block_bias) * rows * K;

@@ -409,6 +409,14 @@ int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims
  * dims / W / bias as for bridges_mlp_mid_forward. */
 int bridges_mlp_mid_rows(int32_t n_rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
                          const float* x, int64_t x_stride, float* y, int64_t y_stride, float* mid, void* stream);
+/* bridges_linear_backward of the LAST layer with the step's book-keeping riding along (one thread of the launch, beside its
+ * jobs): losses[*counter] = sum of loss_rows[0 .. batch) in row order, ++*counter, ++*adam_step (adam_step may be NULL).  The
+ * loss rows are those bridges_successor_loss (called with ticket = NULL, losses = NULL) has just written; nothing between the
+ * two calls may read *counter.  No x_block / a_block indirection (the head's input is the stack's output). */
+int bridges_linear_backward_log(int32_t rows, int32_t K, int32_t N, const float* dz, const float* a_in, const float* W,
+                                float* dW, float* db, const float* act_below, float* dz_below, float* ws, int64_t ws_floats,
+                                const float* loss_rows, int32_t batch, float* losses, int32_t n_losses, int64_t* counter,
+                                float* adam_step, void* stream);
 /* Backward of a Linear layer that needs no input gradient (the first layer) with the optimiser update inside: W, bias and
  * their moments are updated in place from the weight-gradient tiles in the matrix-core accumulators (that gradient is never
  * written; rows must be 32: one batch tile), and extra workgroups of the same launch apply Adam to `rest_n` further
