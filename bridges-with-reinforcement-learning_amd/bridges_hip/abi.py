@@ -182,7 +182,7 @@ def lib():
         "bridges_mlp_mid_rows": [i32, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp],
         "bridges_mlp_mid_supported": [i32, i32, vp],
         "bridges_mlp_mid_forward": [i32, i32, vp, vp, vp, vp, vp],
-        "bridges_mlp_mid_backward": [i32, i32, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_mlp_mid_backward": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp],
         "bridges_eps_greedy_select": [i32, i32, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp],
         "bridges_valid_rows": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_record_state": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],

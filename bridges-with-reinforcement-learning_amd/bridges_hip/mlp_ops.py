@@ -209,6 +209,15 @@ class FusedSuccessorStep:
         # everything behind the first layer's range: the other layers (and padding, whose gradients and moments stay 0)
         first = self._slices[0]
         self._rest = (first[1], self.flat.numel()) if first == covered[0] and first[0] == 0 and self.flat.numel() % 4 == 0 else None
+        # with the middle-layer stack, the head's range (the last of the buffer: 2.1 M of the 2.2 M parameters behind the first
+        # layer) is updated by extra workgroups of the stack's backward launch -- its gradient is complete and its weights are
+        # not read any more by then --, the last launch keeps the first layer's folded update and the small rest
+        self._rest_head = None
+        head = self._slices[-1]
+        if (self._rest is not None and self.mid is not None and len(self.linears) >= 3 and head == covered[-1]
+                and head[0] >= first[1] and os.environ.get("BRIDGES_HEAD_ADAM_RIDER", "1") != "0"):
+            self._rest_head = (head[0], self.flat.numel())
+            self._rest = (first[1], head[0])
         self.optimizer, self.fused_adam = opt, True
 
     def export_state(self):
@@ -265,8 +274,18 @@ class FusedSuccessorStep:
             lin = self.linears[l]
             if mid is not None and 0 < l < last:
                 if l == last - 1:
-                    abi.check(L.bridges_mlp_mid_backward(rows, mid["n"], mid["dims"], mid["W"], mid["dW"], mid["db"], mid["acts"],
-                                                         mid["dz"], st), "bridges_mlp_mid_backward")
+                    rider = self._rest_head if (self.fused_adam and fold_first) else None
+                    if rider is not None:
+                        lo_h, hi_h = rider
+                        offh = lambda t: C.c_void_p(t.data_ptr() + 4 * lo_h)
+                        abi.check(L.bridges_mlp_mid_backward(rows, mid["n"], mid["dims"], mid["W"], mid["dW"], mid["db"], mid["acts"],
+                                                             mid["dz"], offh(self.flat), offh(self.grad_flat), offh(self.m_flat),
+                                                             offh(self.v_flat), hi_h - lo_h, _ptr(self.adam_step), self.lr, self.beta1,
+                                                             self.beta2, self.eps, st), "bridges_mlp_mid_backward")
+                    else:
+                        abi.check(L.bridges_mlp_mid_backward(rows, mid["n"], mid["dims"], mid["W"], mid["dW"], mid["db"], mid["acts"],
+                                                             mid["dz"], None, None, None, None, 0, None, 0.0, 0.0, 0.0, 0.0, st),
+                                  "bridges_mlp_mid_backward")
                 continue
             if l == 0 and fold_first:
                 mw, vw, mb, vb = self._moments[0]

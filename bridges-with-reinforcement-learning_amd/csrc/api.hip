@@ -793,12 +793,25 @@ int bridges_mlp_mid_rows(int32_t n_rows, int32_t n_layers, const int32_t* dims, 
 }
 
 int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
-                             float* const* db, float* const* acts, float* const* dz, void* stream) {
+                             float* const* db, float* const* acts, float* const* dz, float* rest_param, const float* rest_grad,
+                             float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step, double lr, double beta1,
+                             double beta2, double eps, void* stream) {
     if (rows != 32 || !mid_dims_supported(n_layers, dims) || !dW || !db || !dz) return fail_arg("bridges_mlp_mid_backward: 32 rows of 256-128-64-128-256 only");
+    if (rest_n < 0 || (rest_n & 3) || (rest_n > 0 && (!rest_param || !rest_grad || !rest_exp_avg || !rest_exp_avg_sq || !step)))
+        return fail_arg("bridges_mlp_mid_backward: the Adam range must be a multiple of 4 floats with all four buffers and the step");
+    if (rest_n > 0 && ((((uintptr_t)rest_param) | ((uintptr_t)rest_grad) | ((uintptr_t)rest_exp_avg) | ((uintptr_t)rest_exp_avg_sq)) & 15))
+        return fail_arg("bridges_mlp_mid_backward: Adam buffers must be 16-byte aligned");
+    if (rest_n > 0 && (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)))
+        return fail_arg("bridges_mlp_mid_backward: hyper-parameters");
     MidPtrs p{};
     int rc = mid_ptrs_fill("bridges_mlp_mid_backward", p, W, nullptr, dW, db, acts, dz);
     if (rc != BRIDGES_OK) return rc;
-    hipLaunchKernelGGL((k_mid_bwd<256, 128, 64, 128, 256>), dim3(256 / 32), dim3(1024), 0, (hipStream_t)stream, p);
+    p.rest_p = rest_param; p.rest_g = rest_grad; p.rest_m = rest_exp_avg; p.rest_v = rest_exp_avg_sq; p.rest_n = (long long)rest_n;
+    p.step = step; p.lr = lr; p.beta1 = beta1; p.beta2 = beta2; p.eps = eps;
+    // riders: ~4 float4 groups per thread over the range, at most 248 workgroups (one per CU beside the stack's eight)
+    int64_t riders = rest_n > 0 ? ((rest_n >> 2) + 4095) / 4096 : 0;
+    if (riders > 248) riders = 248;
+    hipLaunchKernelGGL((k_mid_bwd<256, 128, 64, 128, 256>), dim3(256 / 32 + (unsigned)riders), dim3(1024), 0, (hipStream_t)stream, p);
     LAUNCH_CHECK("k_mid_bwd");
     return BRIDGES_OK;
 }

@@ -583,6 +583,12 @@ struct MidPtrs {
     float* dW[4]; float* db[4];
     float* act[5];               // act[l] [32][D_l]: input of middle layer l; act[l + 1] its output
     float* dz[5];                // dz[l + 1] [32][D_{l+1}]: gradient at layer l's pre-activation; dz[0]: handed below the stack
+    // optional (backward): an Adam update of another layer's flat parameter range by the workgroups behind the stack's own --
+    // the head's, whose gradient is complete and whose weights nothing reads any more when this launch runs.  59 MB of
+    // streaming traffic that would otherwise sit in the step's last launch (where the first layer's folded update already
+    // fills the memory system) runs beside the eight workgroups of the chain, which leave the memory system idle.
+    float* rest_p; const float* rest_g; float* rest_m; float* rest_v; long long rest_n;
+    const float* step; double lr, beta1, beta2, eps;
 };
 // forward job = (tile << 2) | quarter of a layer [K -> N]: weight fragments and the tile's bias value
 template <int K>
@@ -858,6 +864,29 @@ __global__ __launch_bounds__(1024) void k_mid_bwd(MidPtrs p) {
     constexpr int J3 = (D4 / 32) * (D3 / 32), J2 = (D3 / 32) * (D2 / 32), J1 = (D2 / 32) * (D1 / 32), J0 = (D1 / 32) * (D0 / 32);
     static_assert((D3 / 32) * 4 <= 16 && (D2 / 32) * 4 <= 16 && (D1 / 32) * 4 <= 16, "a gradient above the last has at most 4 tiles");
     static_assert(J3 + J2 + J1 + J0 <= (D0 / 32) * 16, "one weight-gradient tile per wave");
+    if ((int)blockIdx.x >= D0 / 32) {                                 // the riders: flat Adam over the given range
+        if (p.rest_n > 0) {
+            const double t = (double)*p.step;
+            const float step_size = (float)(p.lr / (1.0 - pow(p.beta1, t)));
+            const float bc2_sqrt = (float)sqrt(1.0 - pow(p.beta2, t));
+            const float w1 = (float)(1.0 - p.beta1), w2 = (float)(1.0 - p.beta2), b2 = (float)p.beta2, eps = (float)p.eps;
+            const long long n4 = p.rest_n >> 2;
+            const long long stride = (long long)(gridDim.x - D0 / 32) * blockDim.x;
+            float4* p4 = reinterpret_cast<float4*>(p.rest_p);
+            const float4* g4 = reinterpret_cast<const float4*>(p.rest_g);
+            float4* m4 = reinterpret_cast<float4*>(p.rest_m);
+            float4* v4 = reinterpret_cast<float4*>(p.rest_v);
+            for (long long i = (long long)(blockIdx.x - D0 / 32) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+                float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+                adam_one(pp.x, gg.x, mm.x, vv.x, step_size, bc2_sqrt, b2, w1, w2, eps);
+                adam_one(pp.y, gg.y, mm.y, vv.y, step_size, bc2_sqrt, b2, w1, w2, eps);
+                adam_one(pp.z, gg.z, mm.z, vv.z, step_size, bc2_sqrt, b2, w1, w2, eps);
+                adam_one(pp.w, gg.w, mm.w, vv.w, step_size, bc2_sqrt, b2, w1, w2, eps);
+                p4[i] = pp; m4[i] = mm; v4[i] = vv;
+            }
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool l3 = wave < (D3 / 32) * 4, l2 = wave < (D2 / 32) * 4, l1 = wave < (D1 / 32) * 4, l0 = wave < 4;
     const int job0 = ((int)blockIdx.x << 2) | (wave & 3);

@@ -396,12 +396,17 @@ int bridges_linear_backward(int32_t rows, int32_t K, int32_t N, const float* dz,
  *   forward:  acts[l + 1] = relu(acts[l] . W[l]^T + bias[l])                      (acts: 5 arrays [32, dims[l]])
  *   backward: dW[l] = dz[l + 1]^T . acts[l], db[l] = column sums of dz[l + 1], dz[0] = the gradient handed below the stack
  *             (dz: 5 pointers like acts; dz[4] given, dz[0] written, dz[1..3] live in LDS only and are not touched)
- * dims and the pointer tables are HOST arrays.  Bit-identical to four calls of bridges_linear_forward / _backward. */
+ * dims and the pointer tables are HOST arrays.  Bit-identical to four calls of bridges_linear_forward / _backward.
+ * The backward launch can carry an Adam update of ANOTHER layer's flat range (rest_*, as bridges_linear_backward_adam's; rest_n
+ * = 0: none): the head's, whose gradient is complete and whose weights nothing reads any more -- extra workgroups beside the
+ * stack's eight, so that traffic is out of the step's last launch. */
 int bridges_mlp_mid_supported(int32_t rows, int32_t n_layers, const int32_t* dims);
 int bridges_mlp_mid_forward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, const float* const* bias,
                             float* const* acts, void* stream);
 int bridges_mlp_mid_backward(int32_t rows, int32_t n_layers, const int32_t* dims, const float* const* W, float* const* dW,
-                             float* const* db, float* const* acts, float* const* dz, void* stream);
+                             float* const* db, float* const* acts, float* const* dz, float* rest_param, const float* rest_grad,
+                             float* rest_exp_avg, float* rest_exp_avg_sq, int64_t rest_n, const float* step, double lr, double beta1,
+                             double beta2, double eps, void* stream);
 /* The same stack for MANY rows -- the acting / target forward between the first layer and the head (cv.py:20-38 inside
  * SuccessorMLP.forward): y [n, 256] = the four Linear + ReLU layers applied to relu(x), x [n, 256] the pre-activation of the
  * layer in front (row strides in floats); mid = scratch of n x 64 floats (the narrow activation between the two launches).
