@@ -832,14 +832,16 @@ int bridges_linear_backward_adam(int32_t rows, int32_t K, int32_t N, const float
     // ~256 weight-gradient jobs (a workgroup then walks ~2 KB of every row of W / m / v) and <= 256 workgroups for the other
     // layers' range: measured 142 us per optimiser step against 156 us with 1024 + 1024 (the update is bound by DRAM locality
     // of six strided streams, not by parallelism; 128 jobs: 146 us, 64: 170 us)
-    int per_job = ceil_div(n_ntiles * n_ktiles, 256);
+    int per_job = ceil_div(n_ntiles * n_ktiles, 256);             // (128 / 192 / 384 / 512 jobs with 512 threads: 119 / 114 / 115 / 117 us per step, 256: 112-114)
     if (per_job < 4) per_job = 4;
     const int n_dw_jobs = n_ntiles * ceil_div(n_ktiles, per_job);
     int64_t rest_jobs = ((rest_n >> 2) + 255) / 256;
     if (rest_jobs > 256) rest_jobs = 256;
     AdamFold ad{W, bias, exp_avg_w, exp_avg_sq_w, exp_avg_b, exp_avg_sq_b, step, lr, beta1, beta2, eps,
                 rest_param, rest_grad, rest_exp_avg, rest_exp_avg_sq, (long long)rest_n};
-    hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(256), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
+    // 512-thread workgroups: the eight waves of a weight-gradient job walk eight ADJACENT k tiles, 1 KB of every row of W / m / v
+    // at a time (two workgroups per CU at the kernel's 247 registers would do the same with 512 B)
+    hipLaunchKernelGGL(k_lin_bwd<true>, dim3(n_dw_jobs + (int)rest_jobs), dim3(512), 0, (hipStream_t)stream, rows, K, N, dz, a_in,
                        (const float*)W, (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, n_dw_jobs, per_job,
                        0, 0, ad, a_block, (int)a_block_bias, LossLog{});
     LAUNCH_CHECK("k_lin_bwd<adam>");

@@ -187,8 +187,10 @@ __device__ __forceinline__ void loss_log_apply(const LossLog& g) {
     if (g.adam_step) *g.adam_step = *g.adam_step + 1.f;
 }
 
+// (the ADAM form is bound by memory: two waves per SIMD -- <= 256 registers -- let one workgroup's loads run under the other's
+// update arithmetic and stores; at the 276 registers the compiler takes unasked, every CU held a single workgroup)
 template <bool ADAM>
-__global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const float* __restrict__ dz,
+__global__ __launch_bounds__(ADAM ? 512 : 256) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 1, ADAM ? 2 : 8))) void k_lin_bwd(int rows, int K, int N, const float* __restrict__ dz,
                                                  const float* __restrict__ a, const float* __restrict__ W,
                                                  float* __restrict__ dW, float* __restrict__ db,
                                                  float* __restrict__ dxpart, const float* __restrict__ act_mask,
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
         const int n0 = nt * 32;
         const int ncol = (n0 + row < N) ? n0 + row : N - 1;
         const int kt_end = ((kg + 1) * ktiles_per_job < n_ktiles) ? (kg + 1) * ktiles_per_job : n_ktiles;
+        const int nw = blockDim.x >> 6;                               // the waves of a workgroup take adjacent k tiles
         int kt = kg * ktiles_per_job + wave;
         const bool want_db = (kg == 0 && wave == 0);
         if (rows == 32) {
@@ -246,15 +249,15 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
 #pragma unroll
                 for (int t = 0; t < 16; ++t) bv[t] = a[(size_t)(2 * t + half) * K + kcol];
             }
-            for (; kt < kt_end; kt += 4) {
+            for (; kt < kt_end; kt += nw) {
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc = mfma32(av[t], bv[t], acc);
                 const int k = kt * 32 + row;
-                if (kt + 4 < kt_end) {
-                    const int kcol = ((kt + 4) * 32 + row < K) ? (kt + 4) * 32 + row : K - 1;
+                if (kt + nw < kt_end) {
+                    const int kcol = ((kt + nw) * 32 + row < K) ? (kt + nw) * 32 + row : K - 1;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) bv[t] = a[(size_t)(2 * t + half) * K + kcol];
                 }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void k_lin_bwd(int rows, int K, int N, const f
             for (int b = 0; b < rows; ++b) sdb += dz[(size_t)b * N + n0 + row];
             db[n0 + row] = sdb;
         }
-        for (; kt < kt_end; kt += 4) {
+        for (; kt < kt_end; kt += nw) {
             const int k0 = kt * 32;
             const int kcol = (k0 + row < K) ? k0 + row : K - 1;
             f32x16 acc;
