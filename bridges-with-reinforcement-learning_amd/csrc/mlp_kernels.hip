@@ -869,6 +869,10 @@ __global__ __launch_bounds__(1024) void k_mid_bwd(MidPtrs p) {
     static_assert(J3 + J2 + J1 + J0 <= (D0 / 32) * 16, "one weight-gradient tile per wave");
     if ((int)blockIdx.x >= D0 / 32) {                                 // the riders: flat Adam over the given range
         if (p.rest_n > 0) {
+            // let the chain's eight workgroups put their weight / activation requests into the memory system first (their
+            // latency is the launch's critical path; the riders have ~18 us for ~12 us of streaming)
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
             const double t = (double)*p.step;
             const float step_size = (float)(p.lr / (1.0 - pow(p.beta1, t)));
             const float bc2_sqrt = (float)sqrt(1.0 - pow(p.beta2, t));
