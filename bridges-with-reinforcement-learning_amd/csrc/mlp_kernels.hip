@@ -22,22 +22,27 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// Sum of p[s * stride], s < n, eight loads in flight (a dependent chain of n loads costs n memory latencies); the order of
-// the additions is fixed, so the result is reproducible.
+// Sum of p[s * stride], s < n, 32 loads in flight (a dependent chain of n loads costs n memory latencies; with eight in
+// flight the 57 first-layer splits were eight round trips of a 4.9 us finishing launch, now two); the order of the additions
+// is fixed, so the result is reproducible.
+#define SPLIT_SUM_WIDTH 32
 __device__ __forceinline__ float split_sum(const float* __restrict__ p, size_t stride, int n) {
-    float acc[8];
+    float acc[SPLIT_SUM_WIDTH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-    int s = 0;
-    for (; s + 8 <= n; s += 8) {
-        float v[8];
+    for (int u = 0; u < SPLIT_SUM_WIDTH; ++u) acc[u] = 0.f;
+    for (int s = 0; s < n; s += SPLIT_SUM_WIDTH) {
+        float v[SPLIT_SUM_WIDTH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * stride];
+        for (int u = 0; u < SPLIT_SUM_WIDTH; ++u) v[u] = (s + u < n) ? p[(size_t)(s + u) * stride] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += v[u];
+        for (int u = 0; u < SPLIT_SUM_WIDTH; ++u) acc[u] += v[u];
     }
-    for (int u = 0; s + u < n; ++u) acc[u] += p[(size_t)(s + u) * stride];
-    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+    for (int w = SPLIT_SUM_WIDTH / 2; w >= 1; w >>= 1) {                 // pairwise tree, fixed
+#pragma unroll
+        for (int u = 0; u < w; ++u) acc[u] = acc[2 * u] + acc[2 * u + 1];
+    }
+    return acc[0];
 }
 
 // Waves 1..3 of a workgroup hand their 32x32 accumulators to wave 0 (fixed summation order: deterministic).
