@@ -244,7 +244,7 @@ def side_modes(args):
 def train_config4_leg(args, dev, rank, world, backend):
     """configs[3] ("8 x MI355X over xGMI, 4096 envs/GPU, tower_height=4, mse_q_values+mse_block_features, shared replay via
     RCCL all-gather") on the ranks of this run: every rank steps its own env shard, ONE all_gather_into_tensor of the
-    880-B transition records per lock-step fills every rank's replica of the replay ring, every rank takes the same 25
+    888-B transition records per lock-step fills every rank's replica of the replay ring, every rank takes the same 25
     optimiser steps (robotoddler/training/vec_dqn.py, distributed.py).  Reported beside the headline, never part of
     `value`.  Collective: the process group bench.py was started with (nccl = RCCL on a node; gloo in the rehearsal)."""
     import hashlib
@@ -313,7 +313,8 @@ def train_config4_leg(args, dev, rank, world, backend):
     steps_all = int(allv[:, 2].sum())
     return {"value": steps_all / float(tt[0]), "unit": "env-steps/s (all ranks: acting + record all-gather + replay + 25 optimiser steps per lock-step)",
             "config": "BASELINE.json configs[3] on %d rank(s): %d envs/rank, tower_height=4, SuccessorMLP, %s, replicated "
-                      "replay ring filled by one all_gather_into_tensor of 888-B records per lock-step" % (world, E, loss),
+                      "replay ring filled by one all_gather_into_tensor of %d-B records per lock-step"
+                      % (world, E, loss, 8 * agent.ring.data.shape[1]),
             "ms_per_lockstep": float(tt[0]) / n_ls * 1e3, "locksteps": n_ls, "ranks_seen": dist.get_world_size(),
             "dist_backend": backend, "allgather_ms_per_lockstep": ag_ms,
             "allgather_bytes_per_rank": int(E * (agent.ring.data.shape[1] + 1) * 8),
@@ -381,8 +382,17 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     ranks_seen = 1
-    if world > 1:
+    # BRIDGES_FORCE_COLLECTIVE=1: a one-rank job keeps its process group, so that every collective of the N > 1 path (RCCL
+    # all-gather of the records, the timing all-reduces, barriers) executes on a one-GPU box too
+    use_pg = world > 1 or os.environ.get("BRIDGES_FORCE_COLLECTIVE", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:          # started without torchrun
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
         else:
@@ -394,7 +404,7 @@ def main():
         leg = train_config4_leg(args, dev, rank, world, backend)
         if rank == 0:
             print(json.dumps(leg), flush=True)
-        if world > 1:
+        if use_pg:
             dist.destroy_process_group()
         return
 
@@ -437,7 +447,7 @@ def main():
         def sync():
             env.sync()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_pg:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -456,7 +466,7 @@ def main():
         s1 = env.read_stats()
         d = {k: s1[k] - s0[k] for k in s1}
         env_steps = float(d["env_steps"])
-        if world > 1:
+        if use_pg:
             t = torch.tensor([dt, env_steps], dtype=torch.float64, device=red_dev)
             tmax = t.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -530,7 +540,7 @@ def main():
             "config": {
                 "workload": "%d envs/GPU lock-step, %s, %s, max_steps=%d, uniform-random policy, %s"
                             % (args.envs, task_label, args.shapes, args.max_steps, raster_mode),
-                "envs_per_gpu": args.envs, "groups": 1 if cand_mode else args.groups,
+                "envs_per_gpu": args.envs, "groups": env.G,
                 "seeds": seeds, "seed_of_value": med["seed"],
                 "per_seed": [{"seed": r["seed"], "value": r["steps_all"] / r["dt_all"], "ms_per_step": r["dt_all"] / args.steps * 1e3}
                              for r in runs],
@@ -544,7 +554,7 @@ def main():
                 "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
                 "debug": args.debug, "tableau_snapshots": bool(cand_mode or args.snapshots),
-                "dist_backend": backend if world > 1 else None,
+                "dist_backend": backend if use_pg else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_raster",
@@ -586,7 +596,7 @@ def main():
                                   "queued_large_tableaux": int(g0.cand_counters[0])}}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        if world > 1:
+        if use_pg:
             release()
         plain = not (args.no_f32_rasters or args.sparse_raster_update or args.debug or cand_mode or args.bridge_length
                      or args.shapes != "trapezoid")
@@ -599,8 +609,8 @@ def main():
     # BASELINE.json configs[3] on the same N ranks, as a CHILD job with its own process group and a timeout: the
     # collectives of the training loop have never run on more than one physical GPU from inside this build, and a hang or
     # a crash in there must not cost the headline line.  Every rank of this job leaves its GPU first.
-    want_leg = world > 1 and args.mode == "sim" and os.environ.get("BENCH_TRAIN_MODES", "1") != "0"
-    if world > 1:
+    want_leg = use_pg and args.mode == "sim" and os.environ.get("BENCH_TRAIN_MODES", "1") != "0"
+    if use_pg:
         release()
         dist.barrier()
         dist.destroy_process_group()

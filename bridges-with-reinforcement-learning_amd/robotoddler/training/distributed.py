@@ -11,13 +11,36 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """BRIDGES_FORCE_COLLECTIVE=1: a one-rank job still creates its process group and sends its records, module broadcasts
+    and counters through the collectives (on a GPU: RCCL).  NCCL / RCCL refuse two ranks on one device, so a one-rank group
+    is the only way to execute the multi-GPU branches on a one-GPU box (tests/test_gpu_one_rank_rccl.py)."""
+    return os.environ.get("BRIDGES_FORCE_COLLECTIVE", "0") == "1"
+
+
+def active():
+    """True when records / parameters travel through a process group: several ranks, or one rank with forced()."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def init(backend=None, device=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not forced():
         return 0, 1
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                   # forced one-rank group started without torchrun
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = dict(device_id=device) if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
@@ -33,7 +56,7 @@ def all_gather_records(rec, valid, n_valid=None):
     Every rank gets the same rows in the same order, so the replicated replay rings stay identical.
     n_valid = valid.sum() when the host already knows it: the single-rank selection then does not wait for the device
     (a boolean index reads its row count back)."""
-    if world_size() == 1:
+    if not active():
         if n_valid is None:
             return rec[valid]
         return rec.index_select(0, torch.nonzero_static(valid, size=int(n_valid)).squeeze(1))
@@ -52,7 +75,7 @@ def all_gather_records(rec, valid, n_valid=None):
 
 def broadcast_module(module, src=0):
     """Re-synchronise replicated parameters (float atomics in backward can let replicas drift by ulps)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         flat = getattr(module, "_flat_params", None)
         tensors = [flat.flat] if flat is not None else list(module.state_dict().values())
         for t in tensors:

@@ -516,7 +516,7 @@ class VecDQN:
         self.env_steps += n_valid
         allrec = D.all_gather_records(rec, valid, n_valid=n_valid)
         self.ring.push(allrec)
-        if D.world_size() == 1:
+        if not D.active():
             self.episodes_done += n_done
         else:
             self.episodes_done += int((allrec[:, R.O_DONE] > 0.5).sum().item())

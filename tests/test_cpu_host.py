@@ -209,12 +209,40 @@ open(os.path.join(%r, "ok_%%d" %% rank), "w").write("ok")
 '''
 
 
+def D_free_port():
+    from robotoddler.training.distributed import free_port
+    return free_port()
+
+
+def test_forced_one_rank_group_sends_records_through_the_collective(tmp_path):
+    """BRIDGES_FORCE_COLLECTIVE=1: a one-rank job creates its process group (gloo here, nccl on a GPU box --
+    tests/test_gpu_one_rank_rccl.py) and all_gather_records / broadcast_module take the process-group branch."""
+    script = tmp_path / "one.py"
+    script.write_text(
+        "import os, sys\nsys.path[:0] = [%r, %r]\nimport torch, torch.distributed as dist\n"
+        "from robotoddler.training import distributed as D\n"
+        "assert not D.active()\nrank, world = D.init(backend='gloo')\n"
+        "assert (rank, world) == (0, 1) and dist.is_initialized() and D.active()\n"
+        "rec = torch.arange(40, dtype=torch.float64).reshape(8, 5)\nvalid = torch.tensor([1,0,1,1,0,0,1,0], dtype=torch.bool)\n"
+        "got = D.all_gather_records(rec, valid, n_valid=4)\nassert torch.equal(got, rec[valid])\n"
+        "lin = torch.nn.Linear(3, 2); w = lin.weight.detach().clone(); D.broadcast_module(lin); assert torch.equal(w, lin.weight)\n"
+        "dist.destroy_process_group()\nprint('ok')\n" % (ROOT, PKG))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script)], env=dict(env, BRIDGES_FORCE_COLLECTIVE="1"), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path[:0] = [%r, %r]\n"
+                          "from robotoddler.training import distributed as D\nassert D.init() == (0, 1) and not D.active()" % (ROOT, PKG)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def test_all_gather_of_records_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, PKG, str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(D_free_port()), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), out.stdout + out.stderr

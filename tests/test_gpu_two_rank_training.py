@@ -5,6 +5,7 @@ vectorised loop (successor_dqn.main -> run_vectorised), both losses of the confi
 import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -50,8 +51,11 @@ def test_config4_two_ranks_gather_identical_rings_and_train_identical_replicas(t
     script.write_text(WORKER % dict(root=ROOT, pkg=PKG, tmp=str(tmp_path)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MASTER_ADDR="127.0.0.1", BRIDGES_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:          # a free port, as bench.py's self-launch does
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29561", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
     r = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(2)]
