@@ -16,6 +16,20 @@ from bridges_hip.shapes import ShapeGeometry, load_urdf
 Frame2D = namedtuple("Frame2D", "point xaxis yaxis normal")     # 3-D tuples, y-axis = (0,1,0)
 
 
+class FaceFrame2D(Frame2D):
+    """Frame of a shape / block face as ``get_face_frame_2d`` returns it.  It remembers (shape, face): the placement
+    kernel behind ``align_frames_2d`` takes the new block's face from the uploaded shape table, not from a frame."""
+
+    def __new__(cls, shape, face, point, xaxis, yaxis, normal):
+        self = super().__new__(cls, point, xaxis, yaxis, normal)
+        self.shape, self.face = shape, face
+        return self
+
+    def to_world_coordinates(self, p):
+        """compas Frame.to_world_coordinates for a local point (x along the face, y along +y, z along the normal)."""
+        return [self.point[k] + p[0] * self.xaxis[k] + p[1] * self.yaxis[k] + p[2] * self.normal[k] for k in range(3)]
+
+
 class Quaternion:
     """Minimal stand-in for compas.geometry.Quaternion (w, x, y, z); only rotations about y occur on the path."""
 
@@ -25,11 +39,14 @@ class Quaternion:
     @classmethod
     def from_cos_sin(cls, c, s):
         phi = math.atan2(s, c)
-        return cls(math.cos(phi / 2.0), 0.0, math.sin(phi / 2.0), 0.0)
+        q = cls(math.cos(phi / 2.0), 0.0, math.sin(phi / 2.0), 0.0)
+        q._cos_sin = (float(c), float(s))      # the (cos, sin) it was made from: a Block posed with it is bit for bit that pose
+        return q
 
     def cos_sin(self):
         # rotation about +y by phi: x' = x cos + z sin  <=>  c = 1 - 2y^2, s = 2wy
-        return 1.0 - 2.0 * self.y * self.y, 2.0 * self.w * self.y
+        exact = getattr(self, "_cos_sin", None)
+        return exact if exact is not None else (1.0 - 2.0 * self.y * self.y, 2.0 * self.w * self.y)
 
     @property
     def wxyz(self):
@@ -113,7 +130,8 @@ class Shape:
 
     def get_face_frame_2d(self, face):
         c, t, n = self._frames()[face]
-        return Frame2D(point=(c[0], 0.0, c[1]), xaxis=(t[0], 0.0, t[1]), yaxis=(0.0, 1.0, 0.0), normal=(n[0], 0.0, n[1]))
+        return FaceFrame2D(self, face, point=(c[0], 0.0, c[1]), xaxis=(t[0], 0.0, t[1]), yaxis=(0.0, 1.0, 0.0),
+                           normal=(n[0], 0.0, n[1]))
 
     def contains_2d(self, points):
         """assembly_env.py:126-137 on the HIP point-in-outline kernel."""

@@ -9,6 +9,11 @@ JSON text and their stored cell outputs are parsed.
   assembly_gym/assembly_gym/utils/test_suite.py.
 * assembly_env_notebook.json <- notebooks/AssemblyEnv.ipynb cells 5, 9, 21, 24, 25
   (printed state_info / step tuples).
+* cra_assembly_notebook.json <- notebooks/CRA_Assembly.ipynb cells 2, 3, 4, 6, 7, 8 (stream outputs): the only
+  outputs of the reference that observe INTERFACE DETECTION directly -- "Number of interfaces: N"
+  (= assembly.graph.number_of_edges(), i.e. touching body pairs), the matrix shapes compas_cra prints
+  (Aeq rows = 6 per free block, columns = 3 per contact vertex; Afr rows = 8 per contact vertex), the four
+  compression forces of the tutorial box and the two `'stable'` verdicts of the three-trapezoid assembly.
 """
 import ast
 import json
@@ -72,8 +77,39 @@ def assembly_env_notebook():
     return out
 
 
+def cra_assembly_notebook():
+    nb = json.load(open(os.path.join(REF, "notebooks", "CRA_Assembly.ipynb")))
+
+    def stream(i):
+        return "".join("".join(o["text"]) for o in nb["cells"][i]["outputs"] if o["output_type"] == "stream")
+
+    def shapes(i, name):
+        return [[int(a), int(b)] for a, b in re.findall(name + r":\s+\((\d+), (\d+)\)", stream(i))]
+
+    def edges(i):
+        return int(re.search(r"Number of interfaces: (\d+)", stream(i)).group(1))
+
+    out = {}
+    # cell 2: the compas_cra tutorial -- a 1 x 3 x 1 box on a fixed 4 x 2 x 1 support
+    out["cell2_number_of_edges"] = edges(2)
+    out["cell3_Aeq"], out["cell3_Afr"] = shapes(3, "Aeq")[-1], shapes(3, "Afr")[-1]
+    out["cell3_density_echo"] = [float(v) for v in re.findall(r"^(\d+\.\d+)$", stream(3), flags=re.M)[:2]]
+    out["cell4_normal_forces"] = [float(v) for v in re.findall(r"(?:Compression|Tension): (-?[0-9.eE+-]+)", stream(4))]
+    # cell 6: AssemblyEnv(render=False) (rbe, mu 0.8, density 1): three trapezoids, state_info printed after blocks 2 and 3
+    out["cell6_stable"] = [m == "True" for m in re.findall(r"'stable': (True|False)", stream(6))]
+    out["cell6_frozen_block"] = re.findall(r"'frozen_block': (\w+)", stream(6))
+    # cells 7-8: the same three blocks in a hand-built CRA assembly with a fixed support slab
+    out["cell7_number_of_edges"] = edges(7)
+    out["cell8_Aeq"], out["cell8_Afr"] = shapes(8, "Aeq")[-1], shapes(8, "Afr")[-1]
+    out["cell8_free_blocks"] = out["cell8_Aeq"][0] // 6
+    out["cell8_contact_vertices"] = out["cell8_Afr"][0] // 8
+    return out
+
+
 if __name__ == "__main__":
     json.dump(stability_table(), open(os.path.join(HERE, "stability_table.json"), "w"), indent=0)
     json.dump(assembly_env_notebook(), open(os.path.join(HERE, "assembly_env_notebook.json"), "w"), indent=1)
+    json.dump(cra_assembly_notebook(), open(os.path.join(HERE, "cra_assembly_notebook.json"), "w"), indent=1)
+    print(json.dumps(cra_assembly_notebook()))
     print("rows:", len(stability_table()))
     print(json.dumps(assembly_env_notebook())[:600])

@@ -320,3 +320,68 @@ def test_raster_with_edges_through_pixel_centres():
         assert on_edge > 50                                  # the degenerate cases are really in there
         canvas = ops.bits_to_f32(bits).cpu().numpy()
         assert not canvas[:, S:, :].any() and not canvas[:, :, S:].any()
+
+
+def test_cra_notebook_cell6_through_the_drop_in_surface(golden_dir):
+    """notebooks/CRA_Assembly.ipynb cell 6 as the notebook writes it (Shape / AssemblyEnv / align_frames_2d / Block /
+    add_block), on the HIP operators: the two recorded `'stable'` prints, and bridges_stability's interface count against
+    cell 7's "Number of interfaces: 4" (one face pair per touching body pair in this assembly) and cell 8's three free blocks."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv, Block, Shape
+    from assembly_gym.utils.geometry import align_frames_2d
+    from bridges_hip import ops
+    g = _load(golden_dir, "cra_assembly_notebook.json")
+    trapezoid = Shape(urdf_file='shapes/trapezoid.urdf')
+    env = AssemblyEnv(render=False)
+    env.reset()
+    shape = trapezoid
+    position, rotation = align_frames_2d(env.get_floor_frame(), shape.get_face_frame_2d(face=3), frame1_coordinates=[0.35, 0, 0])
+    block1 = Block(shape=shape, position=position, orientation=rotation.quaternion)
+    info1 = env.add_block(block1)
+    position, rotation = align_frames_2d(block1.get_face_frame_2d(face=1), trapezoid.get_face_frame_2d(face=2), frame1_coordinates=[0.8, 0.0, 0])
+    block2 = Block(shape=trapezoid, position=position, orientation=rotation.quaternion)
+    info2 = env.add_block(block2)
+    p2 = block2.get_face_frame_2d(1).to_world_coordinates([-0.0, 0, 0])
+    position, rotation = align_frames_2d(block2.get_face_frame_2d(face=1), trapezoid.get_face_frame_2d(face=2), frame1_coordinates=[-0.0, 0.0, 0])
+    block3 = Block(shape=trapezoid, position=position, orientation=rotation.quaternion)
+    info3 = env.add_block(block3)
+    assert info1["stable"] is True
+    assert [info2["stable"], info3["stable"]] == g["cell6_stable"] == [False, True]
+    assert info3["frozen_block"] is None and info3["collision"] is False
+    assert len(p2) == 3 and p2[1] == 0.0
+    counts = []
+    for n in (1, 2, 3):
+        stable, info = ops.stability(env.blocks[:n], set(), env.mu, env.density, env.floor_half_width, env.floor_depth)
+        counts.append(info["n_interfaces"])
+    assert counts == [1, 2, 4] and counts[-1] == g["cell7_number_of_edges"]
+    assert g["cell8_free_blocks"] == len(env.blocks)
+    # the block the kernel posed from (position, rotation.quaternion) is the block the oracle places
+    from oracle.geometry import create_block
+    from oracle.shapes import get_shape
+    st = _load(golden_dir, "structures.json")["notebook_cra_cell6"]
+    shapes, oblocks = [get_shape("trapezoid")], []
+    for p in st["placements"]:
+        oblocks.append(create_block(shapes, oblocks, p))
+    for ob, b in zip(oblocks, env.blocks):
+        assert np.array_equal(np.asarray(ob.verts), b.verts_2d)
+
+
+def test_cra_notebook_tutorial_box_through_the_c_abi(golden_dir):
+    """notebooks/CRA_Assembly.ipynb cells 2-4 (the compas_cra tutorial: a 1 x 3 x 1 box on a fixed 4 x 2 x 1 support)
+    through bridges_stability / bridges_stability_penalty: one interface, stable, and the contact compressions of the
+    equilibrium found sum to the recorded 4 x 0.75 (= density x volume of the free box)."""
+    from assembly_gym.envs.assembly_env import Block, Shape
+    from bridges_hip import ops
+    from bridges_hip.shapes import ShapeGeometry, _box_outline
+    g = _load(golden_dir, "cra_assembly_notebook.json")
+    st = _load(golden_dir, "structures.json")["notebook_cra_cell2"]
+    blocks, fixed = [], set()
+    for i, (sx, sy, sz, pos, fx) in enumerate(st["boxes"]):
+        blocks.append(Block(Shape(mesh=ShapeGeometry(*_box_outline(sx, sy, sz), name=f"box{i}")), position=pos))
+        if fx:
+            fixed.add(i)
+    stable, info = ops.stability(blocks, fixed, st["mu"], st["density"], 5.0, 10.0)
+    assert stable is True and info["n_interfaces"] == g["cell2_number_of_edges"] == 1
+    stable, info = ops.stability(blocks, fixed, st["mu"], st["density"], 5.0, 10.0, tension_tol=1e-3)
+    assert stable is True and info["forces"].shape == (1, 2, 3)
+    assert info["forces"][:, :, 0].sum() == pytest.approx(sum(g["cell4_normal_forces"]), abs=1e-9)     # 3.0
+    assert info["forces"][:, :, 1].sum() == pytest.approx(0.0, abs=1e-9)                                   # nothing pulls

@@ -1,6 +1,7 @@
-"""GPU: size-independent properties at BASELINE.json's full size (4096 envs, tower_height=4, max_steps=15) -- the
-oracle cannot follow 4096 envs in seconds, so the checks are invariants of the domain:
-determinism, grouping independence, mask/raster consistency, conservation of counts."""
+"""GPU: BASELINE.json's full sizes.  (1) Oracle parity: the plain-C oracle, sharded over the box's host cores, follows every
+env of configs[2] (4096 envs, tower_height=4, max_steps=15), configs[1]'s simulator side (1024 envs, tower_height=2) and one
+GPU's share of configs[4] (hexagon bridge) for >= 25 lock-steps.  (2) Size-independent properties: determinism, grouping
+independence, mask/raster consistency, conservation of counts."""
 import numpy as np
 import pytest
 import torch
@@ -127,3 +128,22 @@ def test_config5_workload_full_size():
     st = env.read_stats()
     assert st["lp_errors"] == 0 and st["if_overflow"] == 0 and st["env_steps"] > 25 * E
     assert max_blocks >= 6
+
+
+@pytest.mark.parametrize("config,locksteps", [(3, 25), (2, 25), (5, 12)])
+def test_full_size_oracle_parity(config, locksteps):
+    """Every env and lock-step at the BASELINE size against the C oracle: selected action, both stability booleans,
+    termination / truncation / done, reward, linear reward (1e-5), targets reached, block / candidate / valid counts and the
+    state bit raster (tests/stress/full_size_parity.py; the oracle runs in a fork pool of a fresh child process before that
+    process initialises the GPU)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress", "full_size_parity.py"), "--config", str(config),
+                          "--locksteps", str(locksteps)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    m = re.search(r"RESULT .*: (\d+) env-steps .* (\d+) mismatches, lp_errors=(\d+) contact_overflows=(\d+) cand_overflow=(\d+) "
+                  r"f32_equals_bits=(\w+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    steps, mism, lp_err, c_ovf, cand_ovf, f32 = int(m[1]), int(m[2]), int(m[3]), int(m[4]), int(m[5]), m[6]
+    envs = {2: 1024, 3: 4096, 5: 4096}[config]
+    assert steps > 0.6 * envs * locksteps and mism == 0 and lp_err == 0 and c_ovf == 0 and cand_ovf == 0 and f32 == "True"

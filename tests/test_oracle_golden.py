@@ -162,3 +162,58 @@ def test_row_run_rasteriser_algorithm_equals_the_per_pixel_test():
                     d = ((X - c[0]) * n[0])[None, :] + ((Y - c[1]) * n[1])[:, None]
                     on_edge += int((d == 0).sum())
     assert checked == 120 and on_edge > 20
+
+
+def _edges(interfaces):
+    """assembly.graph.number_of_edges(): touching BODY PAIRS (an edge may hold several face-pair interfaces)."""
+    return len({(a, b) for a, b, *_ in interfaces})
+
+
+def test_cra_notebook_tutorial_box_interface_count_and_weight(golden_dir):
+    """CRA_Assembly.ipynb cells 2-4: one edge; Aeq (6, 12) / Afr (32, 12) = 1 free block, 4 contact vertices = ONE
+    rectangular interface (2 contact points in the 2-D restatement, mirrored in y); the four recorded compressions sum to
+    the free block's weight density * (1 x 3 x 1)."""
+    from oracle.geometry import Block
+    from oracle.rbe import equilibrium_system, find_interfaces
+    from oracle.shapes import ShapeDef, _box
+    g = _load(golden_dir, "cra_assembly_notebook.json")
+    st = _load(golden_dir, "structures.json")["notebook_cra_cell2"]
+    blocks, fixed = [], set()
+    for i, (sx, sy, sz, pos, fx) in enumerate(st["boxes"]):
+        blocks.append(Block(ShapeDef(f"box{i}", **_box(sx, sz, sy)), (pos[0], pos[2])))
+        if fx:
+            fixed.add(i)
+    ifs = find_interfaces(blocks)
+    assert _edges(ifs) == g["cell2_number_of_edges"] == 1 and len(ifs) == 1
+    assert (ifs[0][0], ifs[0][1]) == (0, 1)                         # support -> free box; the env's floor (z = 0) touches nothing
+    n_free = len(blocks) - len(fixed)
+    M, w = equilibrium_system(blocks, ifs, fixed, st["mu"], st["density"])
+    assert g["cell3_Aeq"][0] == 6 * n_free and M.shape[0] == 3 * n_free
+    assert g["cell3_Aeq"][1] == 3 * 4 * len(ifs) and g["cell3_Afr"][0] == 8 * 4 * len(ifs) and M.shape[1] == 4 * len(ifs)
+    assert w[1] == pytest.approx(sum(g["cell4_normal_forces"]))     # 4 x 0.75 = 3 = density * volume of the free box
+    assert is_stable_rbe(blocks, fixed, mu=st["mu"], density=st["density"]) is True     # cra_solve found the equilibrium
+    p_lo, p_hi = ifs[0][2], ifs[0][3]
+    assert (p_lo, p_hi) == ((-0.5, 0.5), (0.5, 0.5)) or (p_hi, p_lo) == ((-0.5, 0.5), (0.5, 0.5))
+
+
+def test_cra_notebook_three_trapezoids_interfaces_and_verdicts(golden_dir):
+    """CRA_Assembly.ipynb cells 6-8: the two recorded `'stable'` prints (False after block 2, True after block 3, nothing
+    frozen), "Number of interfaces: 4" for the three-block assembly and Aeq's 18 rows = 3 free blocks.  The 2-D restatement
+    counts face pairs; compas_cra counts graph edges (body pairs): both are compared.  The recorded 18 contact VERTICES
+    (Afr 144 = 8 x 18) are polygon vertices of the 3-D face intersections (not 4 per interface: 4 x 4 = 16) and have no 2-D
+    counterpart; they are not compared."""
+    from oracle.rbe import find_interfaces
+    g = _load(golden_dir, "cra_assembly_notebook.json")
+    st = _load(golden_dir, "structures.json")["notebook_cra_cell6"]
+    shapes, blocks, verdicts, edges = [get_shape(s) for s in st["shapes"]], [], [], []
+    for p in st["placements"]:
+        blocks.append(create_block(shapes, blocks, p))
+        verdicts.append(is_stable_rbe(blocks, set(), mu=st["mu"], density=st["density"]))
+        edges.append(_edges(find_interfaces(blocks)))
+    assert verdicts[0] is True                                      # (not printed by the cell; a single block on the floor)
+    assert verdicts[1:] == g["cell6_stable"] == [False, True]
+    assert g["cell6_frozen_block"] == ["None", "None"]
+    assert edges == [1, 2, 4] and edges[-1] == g["cell7_number_of_edges"]
+    ifs = find_interfaces(blocks)
+    assert sorted((a, b) for a, b, *_ in ifs) == [(-1, 0), (-1, 2), (0, 1), (1, 2)]      # one face pair per edge here
+    assert g["cell8_free_blocks"] == len(blocks) == 3 and g["cell8_Aeq"][0] == 6 * len(blocks)
