@@ -551,7 +551,7 @@ def main():
                 "mean_valid_candidates": d["sum_valid"] / max(units, 1),
                 "mean_blocks": d["sum_blocks"] / max(units, 1),
                 "env_step_fraction": env_steps / max(units, 1),
-                "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"],
+                "lp_errors": d["lp_errors"], "interface_overflows": d["if_overflow"], "cand_overflow": d["cand_overflow"],
                 "bytes_per_env_step": alg / max(units, 1),
                 "debug": args.debug, "tableau_snapshots": bool(cand_mode or args.snapshots),
                 "dist_backend": backend if use_pg else None,

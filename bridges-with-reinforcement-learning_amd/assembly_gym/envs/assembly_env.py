@@ -6,8 +6,6 @@ successor_dqn.py:695 builds AssemblyEnv(render=False)); asking for it raises Not
 import math
 from collections import namedtuple
 
-import os
-
 import numpy as np
 
 from bridges_hip import ops
@@ -280,8 +278,6 @@ class AssemblyEnv:
             "collision_info": {"obstacles": [], "blocks": [], "floor": False, "bounding_box": False},
             "frozen_block": self.frozen_block_index,
         })
-        if os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":     # A/B switch: solve at once, every time
-            self._state_info._solve(memo=False)
 
     def _solve_state(self, snapshot, memo=True):
         """(is_stable, info) of the assembly as it was when ``snapshot`` = [(block, is_static), ...] was taken."""

@@ -2,7 +2,6 @@
 (assembly_gym/assembly_gym/envs/gym_env.py:11-333 of the reference).  gymnasium itself is not required: the class
 keeps the gymnasium calling convention (reset -> (obs, info); step -> (obs, reward, terminated, truncated, info)).
 Placement runs in bridges_create_block, stability in bridges_stability."""
-import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -86,7 +85,7 @@ class AssemblyGym:
         self.reward_fct, self.render_mode, self.restrict_2d, self.max_steps = reward_fct, render_mode, restrict_2d, max_steps
         self.observation_space = self.action_space = None       # gymnasium attributes, unused like in the reference
         self.action_history = self.block_graph = None
-        self._block_cache, self._block_cache_state = {}, None
+        self._block_cache, self._block_cache_state, self._generation = {}, None, 0
         self.assembly_env = assembly_env if assembly_env is not None else AssemblyEnv(render=render_mode == 'human')
         self.reset(shapes, obstacles, targets)
 
@@ -156,17 +155,9 @@ class AssemblyGym:
         blocks of the current state's candidates are kept until the assembly changes: the reference creates every
         candidate twice per env-step (get_action_features, successor_dqn.py:69, then collision_on_action through
         filter_actions, actions.py:71-82) -- the second round is served from here."""
-        state = (len(self.assembly_env.blocks), id(self.assembly_env.blocks[-1]) if self.assembly_env.blocks else None)
-        if os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":      # A/B switch of tools/single_env_throughput.py:
-            self._block_cache, self._block_cache_state = {}, None       # one operator call per candidate, nothing kept
-            out = []
-            for a in actions:
-                target = None if a.target_block == -1 else self.assembly_env.blocks[a.target_block]
-                sh = self.shapes[a.shape]
-                pose, verts, frames = ops.create_block(target, a.target_face, sh.geometry, a.face, a.offset_x, a.offset_y)
-                out.append(Block(sh, position=[pose[0], 0.0, pose[1]], orientation=Quaternion.from_cos_sin(pose[2], pose[3]),
-                                 _posed=(pose, verts, frames)))
-            return out
+        # the cache belongs to ONE state: the block list (by identity, in order), the shape list and the episode (reset()
+        # starts a new generation, so a reset to other shapes or a recycled id() can never serve an old episode's blocks)
+        state = (self._generation, tuple(id(b) for b in self.assembly_env.blocks), tuple(id(s) for s in self.shapes))
         if self._block_cache_state != state:
             self._block_cache, self._block_cache_state = {}, state
         keys = [(a.target_block, a.target_face, a.shape, a.face, float(a.offset_x), float(a.offset_y)) for a in actions]
@@ -204,6 +195,8 @@ class AssemblyGym:
 
     def reset(self, shapes=None, obstacles=None, targets=None, blocks=None):
         self.assembly_env.reset()
+        self._block_cache, self._block_cache_state = {}, None          # candidate blocks of the previous episode are void
+        self._generation += 1
         self.action_history, self.targets_reached = [], []
         self.block_graph = {(-1, 0): []}                        # (block, face) -> what is attached there; floor = (-1, 0)
         self.blocks = blocks if blocks is not None else []

@@ -8,6 +8,36 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRIDGES_LIB", os.path.join(HERE, "libbridges_hip.so"))      # override: diagnostic builds
+CSRC_DIR = os.path.join(os.path.dirname(HERE), "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
+STAMP_PREFIX = "BRIDGES_SRC_HASH="
+
+
+def source_hash():
+    """sha256 over the library's sources: every file of csrc/ and include/ (relative name + contents, sorted by name).
+    __graft_entry__.build() compiles it into the library (bridges_source_hash()); lib() compares."""
+    import hashlib
+    h = hashlib.sha256()
+    for tag, d in (("csrc", CSRC_DIR), ("include", INCLUDE_DIR)):
+        for name in sorted(os.listdir(d)):
+            path = os.path.join(d, name)
+            if os.path.isfile(path) and not name.startswith("."):
+                h.update(f"{tag}/{name}\0".encode())
+                with open(path, "rb") as fh:
+                    h.update(fh.read())
+                h.update(b"\0")
+    return h.hexdigest()
+
+
+def library_stamp(path=None):
+    """The stamp inside a built library file, read from its bytes without loading it (None: no such file / no stamp)."""
+    import re
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as fh:
+        m = re.search(rb"BRIDGES_SRC_HASH=([0-9a-f]{64}|unstamped)", fh.read())
+    return m.group(1).decode() if m else None
 
 MAX_VERTS = 6
 MAX_BLOCKS = 16
@@ -33,7 +63,7 @@ IMG = 64
 FLAG_NAMES = ("valid_step", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",
               "no_actions", "lp_error")
 STAT_NAMES = ("sum_cand", "sum_blocks", "env_steps", "reset_only", "lp_errors", "if_overflow", "locksteps",
-              "sum_valid", "warm_resolved")
+              "sum_valid", "warm_resolved", "cand_overflow")
 
 
 class BridgesHipError(RuntimeError):
@@ -146,6 +176,15 @@ def lib():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
+    try:
+        L.bridges_source_hash.restype = C.c_char_p
+        stamp = L.bridges_source_hash().decode()[len(STAMP_PREFIX):]
+    except AttributeError:
+        stamp = "missing"
+    want = source_hash()
+    if stamp != want:
+        raise BridgesHipError(f"{LIB_PATH} is stale: it was built from other sources (stamp {stamp[:16]}, sources {want[:16]}); "
+                              "rebuild it with `python __graft_entry__.py build`")
     L.bridges_last_error.restype = C.c_char_p
     L.bridges_device_count.restype = C.c_int
     sigs = {
@@ -187,7 +226,7 @@ def lib():
         "bridges_valid_rows": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_record_state": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_record_result": [i32, vp, vp, vp, vp, vp, vp],
-        "bridges_replay_unpack": [i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_replay_unpack": [i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_bits_accumulate": [i32, vp, vp, vp, vp, vp, vp],
         "bridges_stability": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, vp, vp, vp, i64, vp],
         "bridges_stability_penalty": [vp, i32, i32, vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, vp, vp, vp, vp, i64, vp],
@@ -215,7 +254,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = (
-    "bridges_last_error", "bridges_device_count", "bridges_env_create", "bridges_env_destroy",
+    "bridges_last_error", "bridges_device_count", "bridges_source_hash", "bridges_env_create", "bridges_env_destroy",
     "bridges_env_reset", "bridges_env_step", "bridges_env_select_random", "bridges_env_lockstep_random", "bridges_env_refresh",
     "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",

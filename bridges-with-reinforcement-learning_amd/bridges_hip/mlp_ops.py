@@ -4,7 +4,6 @@ robotoddler/training/successor_dqn.py:157-235).  The parameters stay the module'
 their ``.grad`` -- the optimiser (torch's fused Adam) is untouched.  No CPU fallback: abi.require_gpu() raises without
 the HIP library."""
 import ctypes as C
-import os
 
 import torch
 
@@ -77,7 +76,7 @@ class FusedSuccessorStep:
 
     WS_FLOATS = 4 << 20
 
-    def __init__(self, net, batch, use_q, use_sf, optimizer=None):
+    def __init__(self, net, batch, use_q, use_sf, optimizer=None, mid_stack=True):
         self.L = abi.require_gpu()
         self.linears = [m for m in net.mlp.layers if isinstance(m, torch.nn.Linear)]
         self.px = int(net.img_size[0]) * int(net.img_size[1])
@@ -115,20 +114,20 @@ class FusedSuccessorStep:
                 p.grad = torch.zeros_like(p)
             assert p.grad.is_contiguous()
             self._grads.append(p.grad)
-        self._setup_mid_stack()
+        self._setup_mid_stack(mid_stack)
         self.fused_adam, self.optimizer = False, None
         if (optimizer is not None and self.grad_flat is not None and self._adam_applies(optimizer, net)
                 and {id(p) for p in params} == {id(p) for p in net.parameters()}):
             self._adopt_adam(optimizer, params)
 
-    def _setup_mid_stack(self):
+    def _setup_mid_stack(self, enabled=True):
         """The Linear + ReLU layers between the first and the last as ONE launch each way (bridges_mlp_mid_forward /
         _backward: a workgroup per tile of the stack's last layer computes what the tile depends on itself, no traffic between
-        workgroups) where the library has that stack (the reference's 256-128-64-128-256); ``BRIDGES_MID_STACK=0`` keeps a
-        launch per layer (bit-identical results)."""
+        workgroups) where the library has that stack (the reference's 256-128-64-128-256); any other stack keeps a launch
+        per layer (bit-identical results: ``mid_stack=False`` lets the tests compare the two)."""
         self.mid = None
         mids = self.linears[1:-1]
-        if not mids or os.environ.get("BRIDGES_MID_STACK", "1") == "0":
+        if not mids or not enabled:
             return
         n = len(mids)
         dims = (C.c_int32 * (n + 1))(mids[0].in_features, *[l.out_features for l in mids])
@@ -215,7 +214,7 @@ class FusedSuccessorStep:
         self._rest_head = None
         head = self._slices[-1]
         if (self._rest is not None and self.mid is not None and len(self.linears) >= 3 and head == covered[-1]
-                and head[0] >= first[1] and os.environ.get("BRIDGES_HEAD_ADAM_RIDER", "1") != "0"):
+                and head[0] >= first[1]):
             self._rest_head = (head[0], self.flat.numel())
             self._rest = (first[1], head[0])
         self.optimizer, self.fused_adam = opt, True
@@ -256,7 +255,7 @@ class FusedSuccessorStep:
         # logging the loss, advancing the batch counter and the Adam step count need every row's loss: that rides in the head
         # layer's backward launch (bridges_linear_backward_log, one thread beside its jobs) -- the loss kernel itself hands
         # nothing between workgroups.  (A net whose head is also its first layer keeps the loss kernel's ticket form.)
-        log_in_backward = last >= 1 and os.environ.get("BRIDGES_LOSS_TICKET", "0") != "1"
+        log_in_backward = last >= 1
         abi.check(L.bridges_successor_loss(B, rows, px, nf, _ptr(self.acts[-1]), _ptr(reward), _ptr(counter),
                                            _ptr(q_target_all) if self.use_q else None,
                                            _ptr(sf_target_all) if self.use_sf else None, int(self.use_q), int(self.use_sf),

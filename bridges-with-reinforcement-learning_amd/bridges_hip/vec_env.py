@@ -345,7 +345,7 @@ class VecAssemblyGym:
         popc = sum(((occ >> f) & 1) for f in range(abi.MAX_VERTS))
         nfree = ((faces - popc) * live).sum(dim=1).to(torch.int32)
         n_cand = len(self.groups) * (len(self.x_discr_ground) + nfree * len(self.offset_values))
-        self.buf["n_cand"].copy_(torch.clamp(n_cand, max=self.a_max).to(torch.int32))
+        self.buf["n_cand"].copy_(n_cand.to(torch.int32))       # raw count: refresh clamps to a_max and flags / counts a truncation
         self.refresh()
 
     def load_records(self, rec):
@@ -362,7 +362,7 @@ class VecAssemblyGym:
         done, stable_n = torch.empty(E, dtype=torch.uint8, device=dev), torch.empty(E, dtype=torch.uint8, device=dev)
         b = self.buf
         abi.check(self.L.bridges_replay_unpack(E, rec.shape[0], K, _ptr(rec), _ptr(self._nv_dev), self._nv_dev.numel(),
-                                               len(self.groups), len(self.x_discr_ground), len(self.offset_values), self.a_max,
+                                               len(self.groups), len(self.x_discr_ground), len(self.offset_values),
                                                _ptr(b["n_blocks"]), _ptr(b["blk_shape"]), _ptr(b["blk_pose"]), _ptr(b["blk_occ"]),
                                                _ptr(b["n_cand"]), _ptr(ranges[0]), _ptr(ranges[1]), _ptr(lin), _ptr(stable_s),
                                                _ptr(done), _ptr(stable_n), _stream()), "bridges_replay_unpack")
@@ -446,6 +446,7 @@ class VecAssemblyGym:
         f = self.buf["step_flags"]
         out = {n: f[:, i].bool() for i, n in enumerate(abi.FLAG_NAMES)}
         out["lp_error"] = (f[:, 7] & 3) != 0                    # bit 0 solver error, bit 1 contact-list overflow
+        out["cand_overflow"] = (f[:, 7] & 8) != 0               # the state has more raw candidates than a_max: the set was cut
         out["warm_resolved"] = (f[:, 7] & 4) != 0               # a continued tableau's marginal 'unstable' was re-solved cold
         return out
 
@@ -495,7 +496,7 @@ class VecAssemblyGymGroups:
         abi.check(L.bridges_gate_create(C.byref(self._gate)), "bridges_gate_create")
         if raster_gate is None:                     # the gate pays when the rasterisers are HBM-bound (full rewrite);
             # measured 3 groups, sparse row-group update: 6.89 M env-steps/s without it, 6.18 M with it
-            raster_gate = os.environ.get("BRIDGES_RASTER_GATE", "0" if kw.get("sparse_raster_update") else "1") != "0"
+            raster_gate = not kw.get("sparse_raster_update")
         if self.G > 1 and raster_gate:
             for env in self.envs:
                 abi.check(L.bridges_env_set_gate(env._env, self._gate), "bridges_env_set_gate")

@@ -57,6 +57,11 @@ extern "C" {
 
 const char* bridges_last_error(void) { return g_err; }
 
+#ifndef BRIDGES_SRC_HASH
+#define BRIDGES_SRC_HASH "unstamped"
+#endif
+const char* bridges_source_hash(void) { return "BRIDGES_SRC_HASH=" BRIDGES_SRC_HASH; }
+
 int bridges_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -554,15 +559,15 @@ int bridges_record_result(int32_t E, const float* reward, const float* lin_rewar
 }
 
 int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec, const int32_t* shape_faces, int32_t n_shapes,
-                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t a_max, int32_t* n_blocks, int32_t* blk_shape,
+                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t* n_blocks, int32_t* blk_shape,
                           double* blk_pose, uint8_t* blk_occ, int32_t* n_cand, int32_t* ranges_next, int32_t* ranges_prev,
                           float* lin, float* stable_s, uint8_t* done, uint8_t* stable_n, void* stream) {
     if (E < 0 || n_rec < 1 || n_rec > E || K < 1 || K > BRIDGES_REC_K || !rec || !shape_faces || n_shapes < 1 || n_groups < 0 ||
-        n_ground < 0 || n_off < 0 || a_max < 0 || !n_blocks || !blk_shape || !blk_pose || !blk_occ || !n_cand || !ranges_next ||
+        n_ground < 0 || n_off < 0 || !n_blocks || !blk_shape || !blk_pose || !blk_occ || !n_cand || !ranges_next ||
         !ranges_prev || !lin || !stable_s || !done || !stable_n)
         return fail_arg("bridges_replay_unpack");
     hipLaunchKernelGGL(k_replay_unpack, dim3((unsigned)E), dim3(64), 0, (hipStream_t)stream, E, n_rec, K, rec, shape_faces, n_shapes, n_groups,
-                       n_ground, n_off, a_max, n_blocks, blk_shape, blk_pose, blk_occ, n_cand, ranges_next, ranges_prev, lin, stable_s,
+                       n_ground, n_off, n_blocks, blk_shape, blk_pose, blk_occ, n_cand, ranges_next, ranges_prev, lin, stable_s,
                        done, stable_n);
     LAUNCH_CHECK("k_replay_unpack");
     return BRIDGES_OK;

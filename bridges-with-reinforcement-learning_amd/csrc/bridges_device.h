@@ -163,6 +163,6 @@ struct DevCtx {
 };
 
 enum { F_VALID = 0, F_STABLE_FROZEN, F_STABLE_UNFROZEN, F_TERMINATED, F_TRUNCATED, F_DONE, F_NO_ACTIONS, F_LP_ERROR };
-enum { ST_SUM_CAND = 0, ST_SUM_BLOCKS, ST_ENV_STEPS, ST_RESET_ONLY, ST_LP_ERRORS, ST_IF_OVERFLOW, ST_LOCKSTEPS, ST_SUM_VALID, ST_WARM_RESOLVED };
+enum { ST_SUM_CAND = 0, ST_SUM_BLOCKS, ST_ENV_STEPS, ST_RESET_ONLY, ST_LP_ERRORS, ST_IF_OVERFLOW, ST_LOCKSTEPS, ST_SUM_VALID, ST_WARM_RESOLVED, ST_CAND_OVERFLOW };
 
 }  // namespace bridges

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_record_result(int E, const float* __res
 
 __global__ __launch_bounds__(64) void k_replay_unpack(int E, int n_rec, int K, const double* __restrict__ rec,
                                                       const int32_t* __restrict__ shape_faces, int n_shapes, int n_groups, int n_ground, int n_off,
-                                                      int a_max, int32_t* __restrict__ n_blocks, int32_t* __restrict__ blk_shape,
+                                                      int32_t* __restrict__ n_blocks, int32_t* __restrict__ blk_shape,
                                                       double* __restrict__ blk_pose, uint8_t* __restrict__ blk_occ,
                                                       int32_t* __restrict__ n_cand, int32_t* __restrict__ ranges_next,
                                                       int32_t* __restrict__ ranges_prev, float* __restrict__ lin,
@@ -426,8 +426,7 @@ __global__ __launch_bounds__(64) void k_replay_unpack(int E, int n_rec, int K, c
     for (int m = 1; m < 64; m <<= 1) nfree += __shfl_xor(nfree, m);
     if (k == 0) {
         n_blocks[e] = nb + 1;
-        const int nc = n_groups * (n_ground + nfree * n_off);
-        n_cand[e] = nc < a_max ? nc : a_max;
+        n_cand[e] = n_groups * (n_ground + nfree * n_off);     // raw count: bridges_env_refresh clamps to the env's a_max and flags it
         ranges_next[2 * e] = e * K;
         ranges_next[2 * e + 1] = e * K + nb + 1;
         ranges_prev[2 * e] = e * K;

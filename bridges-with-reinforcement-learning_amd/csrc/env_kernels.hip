@@ -27,7 +27,10 @@ __device__ inline void reset_env(const DevCtx& c, int e, int lane) {
     }
 }
 
-// number of raw candidates of a state: n_groups * (n_ground + n_free_faces * n_offsets)
+// number of raw candidates of a state: n_groups * (n_ground + n_free_faces * n_offsets).  NOT clamped to the env's capacity
+// a_max: k_scan does that for every producer of n_cand (k_reset, k_step, bridges_replay_unpack, a host that loads states),
+// raises bit 3 of the env's F_LP_ERROR flag and counts the truncation (stats: cand_overflow) -- a candidate set cut short
+// is data loss the reference cannot have (actions.py:7-52 enumerates everything) and must not pass silently.
 __device__ inline int count_candidates(const DevCtx& c, int e, int nb, int lane) {
     int nfree = 0;
     for (int i0 = 0; i0 < nb * MAXV; i0 += WAVE) {
@@ -40,8 +43,7 @@ __device__ inline int count_candidates(const DevCtx& c, int e, int nb, int lane)
         }
         nfree += __popcll(__ballot(fr));
     }
-    int n = c.n_groups * (c.n_ground + nfree * c.n_offsets);
-    return n > c.a_max ? c.a_max : n;
+    return c.n_groups * (c.n_ground + nfree * c.n_offsets);
 }
 
 __global__ __launch_bounds__(WAVE) void k_reset(DevCtx c) {
@@ -137,8 +139,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
             c.b.lin_reward[e] = 0.f;
             c.b.n_reached[e] = 0;
         }
-        const int nc0 = c.n_groups * c.n_ground;
-        if (lane == 0) c.b.n_cand[e] = nc0 > c.a_max ? c.a_max : nc0;
+        if (lane == 0) c.b.n_cand[e] = c.n_groups * c.n_ground;     // raw count: k_scan clamps to a_max and flags a truncation
         return;
     }
 
@@ -311,8 +312,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
     }
     int nfree = 0;
     for (int b = 0; b < nb_after; ++b) nfree += __builtin_amdgcn_readlane(nf, b);
-    int nc = c.n_groups * (c.n_ground + nfree * c.n_offsets);
-    nc = nc > c.a_max ? c.a_max : nc;
+    const int nc = c.n_groups * (c.n_ground + nfree * c.n_offsets);     // raw count: k_scan clamps to a_max and flags a truncation
     if (lane == 0) c.b.n_cand[e] = nc;
     if (DIAG(c, 8) && lane == 0) {               // 100 MHz wall clock: start, after append, after interfaces, after LPs, end
         const long long ts4 = wall_clock64();
@@ -323,7 +323,8 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// exclusive prefix sum of n_cand -> cand_offset[E+1], plus the per-lock-step statistics (no atomics anywhere:
+// exclusive prefix sum of n_cand -> cand_offset[E+1], the clamp of every env's raw candidate count to the capacity a_max
+// (a truncated env gets bit 3 of its F_LP_ERROR flag and is counted), plus the per-lock-step statistics (no atomics anywhere:
 // 4096 adds on one word cost ~50 us per kernel on this chip).  Single workgroup of only 4 waves: beside another env
 // group's rasteriser (28 of a CU's 32 wave slots taken) a 16-wave workgroup waited ~100 us for a CU to place it.
 #define SCAN_THREADS 256
@@ -332,12 +333,12 @@ __global__ __launch_bounds__(WAVE) void k_step(DevCtx c) {
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step) {
     __shared__ int wave_tot[SCAN_WAVES];
     __shared__ int carry_s;
-    __shared__ unsigned long long red[SCAN_WAVES][7];
+    __shared__ unsigned long long red[SCAN_WAVES][8];
     __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (t == 0) carry_s = 0;
     __syncthreads();
-    unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};   // blocks, env-steps, reset-only, lp errors, if overflow, valid, warm re-solves
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // blocks, env-steps, reset-only, lp errors, if overflow, valid, warm re-solves, truncated candidate sets
     for (int base0 = 0; base0 < c.E; base0 += SCAN_THREADS * SCAN_BATCH) {
         // all loads of the batch first: beside a rasteriser every dependent round trip costs microseconds
         int v[SCAN_BATCH], nbk[SCAN_BATCH], nval[SCAN_BATCH];
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
         for (int u = 0; u < SCAN_BATCH; ++u) {
             const int i = base0 + u * SCAN_THREADS + t;
             const bool in = i < c.E;
-            v[u] = in ? c.b.n_cand[i] : 0;
+            v[u] = in ? c.b.n_cand[i] : 0;              // raw count of the producer
             nbk[u] = in ? c.b.n_blocks[i] : 0;
             nval[u] = (in && after_step) ? c.b.n_valid[i] : 0;
             fl8[u] = (in && after_step) ? *reinterpret_cast<const uint64_t*>(c.b.step_flags + (size_t)i * 8) : 0ull;
@@ -357,6 +358,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
             if (base >= c.E) break;
             const int i = base + t;
             if (i < c.E) {
+                if (v[u] > c.a_max) {                        // more candidates than the env has room for: cut, flag, count
+                    v[u] = c.a_max;
+                    c.b.n_cand[i] = c.a_max;
+                    c.b.step_flags[(size_t)i * 8 + F_LP_ERROR] |= 8;
+                    acc[7] += 1;
+                }
                 acc[0] += (unsigned long long)nbk[u];
                 if (after_step) {
                     const unsigned valid = (unsigned)(fl8[u] >> (8 * F_VALID)) & 0xffu;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
         }
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         unsigned long long x = acc[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
@@ -395,9 +402,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
     }
     __syncthreads();
     if (t == 0) {
-        unsigned long long tot[7] = {0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int w = 0; w < SCAN_WAVES; ++w)
-            for (int k = 0; k < 7; ++k) tot[k] += red[w][k];
+            for (int k = 0; k < 8; ++k) tot[k] += red[w][k];
         c.b.cand_offset[c.E] = carry_s;
         if (c.h_total) *c.h_total = carry_s;
         c.b.stats[ST_SUM_CAND] += (uint64_t)carry_s;
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(DevCtx c, int after_step)
         c.b.stats[ST_IF_OVERFLOW] += tot[4];
         c.b.stats[ST_SUM_VALID] += tot[5];
         c.b.stats[ST_WARM_RESOLVED] += tot[6];
+        c.b.stats[ST_CAND_OVERFLOW] += tot[7];
         c.b.stats[ST_LOCKSTEPS] += 1;
     }
 }

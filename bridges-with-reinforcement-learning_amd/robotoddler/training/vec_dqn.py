@@ -96,13 +96,14 @@ class VecDQN:
         obstacle = env.obstacle_raster.unsqueeze(0).expand(n, -1, -1, -1)
         return block, binary, action, reward, obstacle
 
-    @staticmethod
-    def _factored(net):
-        """Acting through the factored SuccessorMLP forward on bit-packed rasters (BRIDGES_FACTORED_ACT=0: the plain
-        module forward on f32 rasters).  The bit-packed first layer is built for 64x64 images; other --image_size
-        values act through the module forward."""
-        return (hasattr(net, "q_from_first_layer") and tuple(getattr(net, "img_size", (64, 64))) == (64, 64)
-                and os.environ.get("BRIDGES_FACTORED_ACT", "1") != "0")
+    FACTORED_ACTING = True      # tests set it to False to run the same lock-steps through the plain module forward
+
+    @classmethod
+    def _factored(cls, net):
+        """Acting through the factored SuccessorMLP forward on bit-packed rasters.  The bit-packed first layer is built for
+        64x64 images; other --image_size values (and every other net) act through the module forward on f32 rasters."""
+        return (cls.FACTORED_ACTING and hasattr(net, "q_from_first_layer")
+                and tuple(getattr(net, "img_size", (64, 64))) == (64, 64))
 
     @classmethod
     def acting_needs_f32_rasters(cls, net):
@@ -331,7 +332,7 @@ class VecDQN:
         if st["fused"]:
             from bridges_hip.mlp_ops import FusedSuccessorStep
             st["step"] = FusedSuccessorStep(self.policy_net, B, 'mse_q_values' in self.loss_parts, use_sf,
-                                            optimizer=self.opt if os.environ.get("BRIDGES_FUSED_ADAM", "1") != "0" else None)
+                                            optimizer=self.opt)
             st["reward"] = self.env.reward_features.reshape(-1).contiguous()
             st["obstacle"] = self.env.obstacle_raster.reshape(-1).contiguous()
             # the first layer's input rows of all batches of a call are built by ONE launch before the replays
@@ -346,7 +347,7 @@ class VecDQN:
         # the device, so n_max copies of the sequence are the n_max steps): between two graph launches the GPU idles 8.7 us
         # (rocprofv3 trace of the loop), inside a graph consecutive kernels follow each other without a gap
         st["graph_all"] = None
-        if st["fused"] and n_max > 1 and os.environ.get("BRIDGES_TRAIN_GRAPH_ALL", "1") != "0":
+        if st["fused"] and n_max > 1:
             graph_all = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_all):
                 for _ in range(n_max):

@@ -1,7 +1,5 @@
 """generate_actions / filter_actions (robotoddler/utils/actions.py:7-82 of the reference) for the single-environment
 API.  (The vectorised path does both on the device: k_enumerate, k_raster.)"""
-import os
-
 import numpy as np
 import torch
 
@@ -37,15 +35,6 @@ def filter_actions(gym_env, available_actions, action_features, block_features, 
     n = len(available_actions)
     if n == 0:
         return [], action_features[:0]
-    if os.environ.get("BRIDGES_SINGLE_ENV_BATCH", "1") == "0":          # A/B switch: the reference's loop, two scalars read back per action
-        mask = torch.zeros(n, dtype=bool)
-        kept = []
-        for i, action in enumerate(available_actions):
-            if (not gym_env.collision_on_action(action, xlim, ylim) and torch.sum(action_features[i] * block_features) == 0
-                    and torch.sum(action_features[i] * obstacle_features) == 0):
-                mask[i] = True
-                kept.append(action)
-        return kept, action_features[mask.to(action_features.device)]
     in_bounds = torch.tensor([not gym_env.collision_on_action(a, xlim, ylim) for a in available_actions], dtype=torch.bool)
     feats = action_features.reshape(n, -1)
     free = ((feats * block_features.reshape(1, -1)).sum(dim=1) == 0) & ((feats * obstacle_features.reshape(1, -1)).sum(dim=1) == 0)

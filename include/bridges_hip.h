@@ -111,12 +111,15 @@ typedef struct {
     int32_t* sel_index;        /* [E] in: candidate to place */
     uint8_t* step_flags;       /* [E,8] valid_step, stable_frozen, stable_unfrozen, terminated, truncated, done, no_actions,
                                   lp_error (bit 0 solver error, bit 1 contact-list overflow; bit 2 is not an error: the step's
-                                  continued tableau said 'unstable' by a small margin and was solved again from scratch) */
+                                  continued tableau said 'unstable' by a small margin and was solved again from scratch;
+                                  bit 3: the state has more raw candidates than a_max -- its candidate set was cut to a_max,
+                                  something the reference's generate_actions (actions.py:7-52) never does: treat as an error) */
     float* reward;             /* [E] sparse_reward (gym_env.py:11-22) */
     float* lin_reward;         /* [E] successor_dqn.py:397-401 */
     int32_t* n_reached;        /* [E] */
     /* --- candidates of the current state --- */
-    int32_t* n_cand;           /* [E] */
+    int32_t* n_cand;           /* [E] raw candidates of the state, clamped to a_max by reset / step / refresh (a producer that fills
+                                  the state arrays itself writes the unclamped count: the clamp is flagged and counted) */
     int32_t* n_valid;          /* [E] */
     int32_t* cand_offset;      /* [E+1] exclusive prefix sum of n_cand */
     int32_t* cand_env;         /* [C] owning env */
@@ -146,7 +149,8 @@ typedef struct {
                                   header + basis + two tableau halves; owned by the library between reset and step calls */
     int64_t lp_ws_stride;      /* >= BRIDGES_LP_WS_DOUBLES */
     uint64_t* stats;           /* [16] sum n_cand, sum n_blocks, env-steps, reset-only steps, lp errors, if overflow, lock-steps,
-                                  sum n_valid, continued (warm) 'unstable' verdicts solved again from scratch; rest reserved */
+                                  sum n_valid, continued (warm) 'unstable' verdicts solved again from scratch, candidate sets cut to
+                                  a_max (must stay 0: size a_max from the task's bound); rest reserved */
     /* --- candidate stability (bridges_env_candidate_stability; all three may be NULL if it is never called) --- */
     uint8_t* cand_stable;      /* [C] 1 = stable, 0 = unstable or masked-out candidate, 2 = solver error / contact overflow */
     int32_t* cand_queue;       /* [C] scratch: candidates whose tableau needs the large workspace */
@@ -163,6 +167,10 @@ typedef struct bridges_env bridges_env;
 
 const char* bridges_last_error(void);
 int bridges_device_count(void);
+/* The stamp the library was compiled with: sha256 over csrc/<every file> and include/<every file> (file names and contents,
+ * sorted by name; -DBRIDGES_SRC_HASH=... by __graft_entry__.build()), "unstamped" for a build without it.  The Python
+ * binding refuses a library whose stamp is not the hash of the sources lying beside it: a stale .so cannot pass for a build. */
+const char* bridges_source_hash(void);
 
 /* --- vectorised environment ------------------------------------------------ */
 int bridges_env_create(const bridges_task* task, const bridges_env_buffers* buf, bridges_env** out);
@@ -344,11 +352,12 @@ int bridges_record_state(int32_t E, int32_t K, const int32_t* n_blocks, const in
 int bridges_record_result(int32_t E, const float* reward, const float* lin_reward, const uint8_t* step_flags, double* rec,
                           uint8_t* valid, void* stream);
 /* Sampled records -> the state arrays of a replay env of E >= n_rec envs (envs >= n_rec repeat record 0): s' = s plus the
- * action block with the occupancy update of gym_env.py:228-232, its candidate count
- * min(n_groups * (n_ground + free faces * n_off), a_max) (generate_actions, actions.py:7-52), the block ranges
- * [e*K, e*K + n) of s' and of s (for bridges_bits_or over the per-block rasters) and the scalars the targets need. */
+ * action block with the occupancy update of gym_env.py:228-232, its RAW candidate count
+ * n_groups * (n_ground + free faces * n_off) (generate_actions, actions.py:7-52; bridges_env_refresh clamps it to the env's
+ * a_max and flags / counts the truncation), the block ranges [e*K, e*K + n) of s' and of s (for bridges_bits_or over the
+ * per-block rasters) and the scalars the targets need. */
 int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec, const int32_t* shape_faces, int32_t n_shapes,
-                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t a_max, int32_t* n_blocks, int32_t* blk_shape,
+                          int32_t n_groups, int32_t n_ground, int32_t n_off, int32_t* n_blocks, int32_t* blk_shape,
                           double* blk_pose, uint8_t* blk_occ, int32_t* n_cand, int32_t* ranges_next, int32_t* ranges_prev,
                           float* lin, float* stable_s, uint8_t* done, uint8_t* stable_n, void* stream);
 

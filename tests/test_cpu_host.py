@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol():
     assert set(abi.EXPORTED_SYMBOLS) == set(syms)
 
 
+def test_library_carries_the_hash_of_its_sources_and_a_stale_one_is_refused(tmp_path, monkeypatch):
+    """__graft_entry__.build() compiles sha256(csrc/*, include/*) into the library; abi.lib() refuses a library whose stamp
+    differs from the sources beside it (a .so built from other sources cannot pass for a build), and build() decides by the
+    stamp, not by file times."""
+    import shutil
+    from bridges_hip import abi
+    want = abi.source_hash()
+    assert abi.library_stamp() == want                      # the tree's library is the tree's sources
+    L = ctypes.CDLL(abi.LIB_PATH)
+    L.bridges_source_hash.restype = ctypes.c_char_p
+    assert L.bridges_source_hash().decode() == abi.STAMP_PREFIX + want
+    # touching a header changes the hash: the same library is stale against that source tree
+    inc = tmp_path / "include"
+    shutil.copytree(abi.INCLUDE_DIR, inc)
+    with open(inc / "bridges_hip.h", "a") as fh:
+        fh.write("\n/* touched */\n")
+    monkeypatch.setattr(abi, "INCLUDE_DIR", str(inc))
+    monkeypatch.setattr(abi, "_lib", None)
+    assert abi.source_hash() != want
+    with pytest.raises(abi.BridgesHipError, match="stale"):
+        abi.lib()
+    # ... and a library file with another stamp is recognised without loading it
+    fake = tmp_path / "lib.so"
+    fake.write_bytes(b"\x7fELF...." + (abi.STAMP_PREFIX + "0" * 64).encode() + b"\0")
+    assert abi.library_stamp(str(fake)) == "0" * 64 and abi.library_stamp(str(tmp_path / "none.so")) is None
+
+
 def test_struct_sizes_match_the_header():
     """ctypes mirrors vs the C compiler's view of the header."""
     from bridges_hip import abi

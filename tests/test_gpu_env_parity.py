@@ -367,3 +367,51 @@ def test_stress_parity_against_the_c_oracle(task):
                           "--task", task, "--seed", "29"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout
+
+
+def test_candidate_capacity_overflow_is_flagged_and_counted():
+    """a_max is a public constructor argument.  A state with more raw candidates than a_max has its candidate set cut to
+    a_max -- data loss the reference cannot have (generate_actions enumerates everything, actions.py:7-52) -- so the cut
+    must be visible: bit 3 of the env's lp_error flag, flags()['cand_overflow'], and the cand_overflow statistic.  The
+    default capacity (the task's bound) never overflows."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    setup = bridge_setup(num_stories=2)
+    E = 32
+    small = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], setup["obstacles"], setup["targets"], max_steps=10, seed=3,
+                           a_max=44, f32_rasters=False)
+    full = VecAssemblyGym(E, [load_urdf("shapes/trapezoid.urdf")], setup["obstacles"], setup["targets"], max_steps=10, seed=3,
+                          f32_rasters=False)
+    assert small.read_stats()["cand_overflow"] == 0 and not small.flags()["cand_overflow"].any()     # 40 ground candidates fit
+    seen = 0
+    for _ in range(6):
+        for env in (small, full):
+            env.select_random()
+            env.step()
+        nb, nc = small.n_blocks.cpu().numpy(), small.n_cand.cpu().numpy()
+        ovf = small.flags()["cand_overflow"].cpu().numpy()
+        raw = full.n_cand.cpu().numpy()
+        # the first lock-step is the same on both (the 40 ground candidates); afterwards the cut sets lead elsewhere
+        if seen == 0:
+            assert np.array_equal(nb, full.n_blocks.cpu().numpy())
+            assert np.array_equal(ovf, raw > 44) and np.array_equal(nc, np.minimum(raw, 44))
+        assert np.array_equal(ovf, nb >= 1) and (nc[ovf] == 44).all() and (nc[~ovf] == 40).all()     # one block: 4 * (10 + 3) = 52 > 44
+        assert not (small.flags()["lp_error"].cpu().numpy()).any()                                      # not mixed into the solver's error bits
+        seen += int(ovf.sum())
+        assert small.read_stats()["cand_overflow"] == seen
+    assert seen > 0
+    assert full.read_stats()["cand_overflow"] == 0 and not full.flags()["cand_overflow"].any()
+    # the replay path (records -> states) goes through the same clamp
+    from robotoddler.training import records as R
+    rec = torch.zeros((E, R.RECORD_WIDTH), dtype=torch.float64, device=small.device)
+    rec[:, R.O_NB] = 1                                              # s holds one block, the action adds a second: 4 * (10 + 6) = 64
+    rec[:, R.O_POSE + 2] = 1.0
+    rec[:, R.O_POSE] = -1.0
+    rec[:, R.O_OCC] = 8
+    rec[:, R.O_APOSE:R.O_APOSE + 4] = torch.tensor([1.5, 0.3595713675022125, 1.0, 0.0], dtype=torch.float64)
+    rec[:, R.O_ATB], rec[:, R.O_AFACE] = -1, 3
+    before = small.read_stats()["cand_overflow"]
+    small.load_records(rec)
+    assert small.read_stats()["cand_overflow"] == before + E and (small.n_cand.cpu().numpy() == 44).all()
+    full.load_records(rec)
+    assert full.read_stats()["cand_overflow"] == 0 and (full.n_cand.cpu().numpy() == 64).all()

@@ -233,7 +233,7 @@ def test_prebuilt_input_rows_give_the_same_steps():
                                               ((128, 64, 32, 256), False)])
 def test_middle_layer_stack_equals_the_per_layer_launches(hidden, with_adam, monkeypatch):
     """bridges_mlp_mid_forward / _backward (the middle Linear + ReLU layers as one launch each way, a workgroup per tile of the
-    stack's last layer) against a launch per layer (BRIDGES_MID_STACK=0): losses, q values, every gradient and -- with the Adam
+    stack's last layer) against a launch per layer (mid_stack=False): losses, q values, every gradient and -- with the Adam
     update in the step -- every weight bit for bit over three steps.  A stack the library is not built for keeps the per-layer
     launches."""
     from bridges_hip.mlp_ops import FusedSuccessorStep
@@ -244,14 +244,13 @@ def test_middle_layer_stack_equals_the_per_layer_launches(hidden, with_adam, mon
     rw, ob = reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous()
     out = {}
     for mode in ("per_layer", "stack"):
-        monkeypatch.setenv("BRIDGES_MID_STACK", "0" if mode == "per_layer" else "1")
         net = make_net(hidden=hidden, seed=6)
         opt = None
         if with_adam:                                           # the update inside the last launch: weights change every step
             from bridges_hip.dqn_ops import FlatParameters
             net._flat_params = FlatParameters(net)
             opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
-        fused = FusedSuccessorStep(net, B, True, True, optimizer=opt)
+        fused = FusedSuccessorStep(net, B, True, True, optimizer=opt, mid_stack=(mode == "stack"))
         assert (fused.mid is not None) == (mode == "stack" and hidden == (256, 128, 64, 128, 256)) and fused.fused_adam == with_adam
         counter = torch.zeros((), dtype=torch.int64, device=DEV)
         losses = torch.zeros(n_batches, device=DEV)

@@ -369,8 +369,7 @@ def test_vectorised_exploration_follows_the_batched_reading_of_the_reference_rul
     for f32 in (False, True):                               # bit-packed acting path and the f32-raster path
         env = make_env(64, seed=21, tower=2, max_steps=10)
         if f32:
-            import os
-            os.environ["BRIDGES_FACTORED_ACT"] = "0"
+            VecDQN.FACTORED_ACTING = False
         try:
             torch.manual_seed(6)
             pol, tgt = make_nets(args, dev)
@@ -402,9 +401,7 @@ def test_vectorised_exploration_follows_the_batched_reading_of_the_reference_rul
                 assert torch.equal(agent.step_images.cpu(), images_after), (f32, it)
             assert n_checked > 250
         finally:
-            if f32:
-                import os
-                os.environ.pop("BRIDGES_FACTORED_ACT", None)
+            VecDQN.FACTORED_ACTING = True
 
 
 def test_load_checkpoint_resumes_the_vectorised_loop(tmp_path):

@@ -6,6 +6,7 @@
 # cycle counters of the simplex (tools/lp_microbench.py --profile).
 set -e
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DBRIDGES_DIAG "$@" \
+HASH=$(PYTHONPATH=bridges-with-reinforcement-learning_amd python3 -c "from bridges_hip import abi; print(abi.source_hash())")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DBRIDGES_DIAG "-DBRIDGES_SRC_HASH=\"$HASH\"" "$@" \
     bridges-with-reinforcement-learning_amd/csrc/api.hip -o tools/libbridges_hip_diag.so
 echo tools/libbridges_hip_diag.so

@@ -16,15 +16,28 @@ ap.add_argument("--model", default="SuccessorMLP")
 ap.add_argument("--tower_height", type=int, default=2)
 ap.add_argument("--loss", default="mse_q_values")
 ap.add_argument("--count_syncs", action="store_true")
+ap.add_argument("--profile", default="", help="write a cProfile listing (top 60 by cumulative time) of the timed run to this file")
 a = ap.parse_args()
 base = ["--model", a.model, "--tower_height", str(a.tower_height), "--loss_function", a.loss, "--seed", "0",
         "--evaluate_every", "1000000", "--learning_rate", "1e-4"]
 S.main(base + ["--num_episodes", str(a.warmup_episodes)])          # warm-up: library load, first-use allocations
 torch.cuda.synchronize()
+prof = None
+if a.profile:
+    import cProfile
+    prof = cProfile.Profile()
+    prof.enable()
 t0 = time.perf_counter()
 hist = S.main(base + ["--num_episodes", str(a.episodes)])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if prof is not None:
+    import io, pstats
+    prof.disable()
+    buf = io.StringIO()
+    pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(60)
+    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+    open(a.profile, "w").write(buf.getvalue())
 steps = sum(h["num_steps"] for h in hist)
 out = dict(env_steps_per_s=steps / dt, s_per_episode=dt / len(hist), episodes=len(hist), env_steps=steps,
            config=f"successor_dqn.py --model={a.model} --tower_height={a.tower_height} --num_episodes={a.episodes} "
