@@ -66,10 +66,57 @@ class VecDQN:
         self._counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()      # (env-steps, finished episodes) of a lock-step
 
     ROW_CHUNK = 2048       # rows per forward call: ONE input shape for the whole run (MIOpen tunes per shape)
+    DEDUP_ROWS = True      # feed every distinct (state, candidate, stable flag) input once (tests compare with False)
+
+    def _distinct_rows(self, env, idx, row_env, stable_flag):
+        """Candidate rows whose network input is the same tensor, bit for bit: the input of a row is (state raster of its env,
+        its candidate raster, the env's stable flag, the task's reward map and obstacle raster), and thousands of environments
+        of one task pass through the same early states -- every freshly reset env holds the same state and the same
+        candidates.  Rows are keyed by a 64-bit hash of their bit rasters, grouped with torch.unique, and every row is then
+        compared WORD FOR WORD with the representative of its group (a hash collision -- probability ~ n^2 / 2^64 -- sends the
+        call down the plain path), so feeding only the representatives and copying their outputs is exact.
+        -> (rep [m]: positions into idx of one row per distinct input, inverse [n]: group of every row) or None."""
+        n = idx.numel()
+        if not self.DEDUP_ROWS or n < 2:
+            return None
+        m = getattr(self, "_hash_mult", None)
+        if m is None:
+            g = torch.Generator().manual_seed(0x5eed5)
+            m = self._hash_mult = (torch.randint(-2 ** 62, 2 ** 62, (2, 64), generator=g, dtype=torch.int64) | 1).to(self.device)
+        cb = env.cand_bits.index_select(0, idx)                                    # [n, 64] int64
+        flag = stable_flag.to(torch.int64)
+        hs = (env.state_bits * m[0]).sum(dim=1) + flag * 0x51ED270B27B4F3D           # [E]  (int64 arithmetic wraps)
+        key = hs.index_select(0, row_env) * 0x2545F4914F6CDD1D + (cb * m[1]).sum(dim=1)
+        key = key ^ (key >> 29)
+        uniq, inverse = torch.unique(key, return_inverse=True)                      # (one wait: the number of groups)
+        n_groups = uniq.numel()
+        if n_groups == n:
+            return None
+        pos = torch.arange(n, device=self.device)
+        rep = torch.full((n_groups,), n, dtype=torch.int64, device=self.device).scatter_reduce_(0, inverse, pos, reduce="amin")
+        r = rep.index_select(0, inverse)                                             # representative of every row
+        renv = row_env.index_select(0, r)
+        same = ((cb == cb.index_select(0, r)).all(dim=1)
+                & (env.state_bits.index_select(0, row_env) == env.state_bits.index_select(0, renv)).all(dim=1)
+                & (flag.index_select(0, row_env) == flag.index_select(0, renv)))
+        if not bool(same.all()):
+            return None
+        self.rows_seen, self.rows_fed = getattr(self, "rows_seen", 0) + n, getattr(self, "rows_fed", 0) + n_groups
+        return rep, inverse
 
     def _forward_rows(self, net, env, idx, row_env, stable_flag):
         """net(...) over the candidate rows in chunks of ROW_CHUNK rows; the last chunk is padded with copies of row 0
-        (sliced off again), so the convolution / GEMM shapes never change from lock-step to lock-step."""
+        (sliced off again), so the convolution / GEMM shapes never change from lock-step to lock-step.  Rows with identical
+        inputs are fed once (_distinct_rows).  -> (q [n], successor block features of the DISTINCT rows or None, successor
+        binary features of the distinct rows or None, inverse [n] = the distinct row of every row (None: every row is fed))."""
+        n_all = idx.numel()
+        groups = self._distinct_rows(env, idx, row_env, stable_flag)
+        inverse = None
+        if groups is not None:
+            rep, inverse = groups
+            idx, row_env = idx.index_select(0, rep), row_env.index_select(0, rep)
+        else:
+            self.rows_seen, self.rows_fed = getattr(self, "rows_seen", 0) + n_all, getattr(self, "rows_fed", 0) + n_all
         n, C = idx.numel(), self.ROW_CHUNK
         pad = (-n) % C
         if pad:
@@ -79,7 +126,9 @@ class VecDQN:
         q = torch.cat([o[0] for o in outs])[:n]
         sf = torch.cat([o[1] for o in outs])[:n] if outs[0][1] is not None else None
         sb = torch.cat([o[2] for o in outs])[:n] if outs[0][2] is not None else None
-        return q, sf, sb
+        if inverse is not None:
+            q = q.index_select(0, inverse)
+        return q, sf, sb, inverse
 
     # ------------------------------------------------------------------ features of the rows a net is fed
     def _row_features(self, env, idx, row_env, stable_flag):
@@ -260,13 +309,19 @@ class VecDQN:
                 _, sf_target, _ = dqn_ops.td_target(one_each, nq[best].contiguous(), lin, done, self.gamma,
                                                     next_sf=nsf0, action_raster=action_f.squeeze(1))
         elif idx.numel():
-            nq, nsf, _ = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
+            nq, nsf, _, inverse = self._forward_rows(self.target_net, renv, idx, row_env, stable_n)
             if use_sf and nsf is None:
                 raise ValueError("No successor block features available from the chosen policy net.")
-            q_target, sf_target, _ = dqn_ops.td_target(
-                seg, nq.contiguous().float(), lin, done, self.gamma,
-                next_sf=nsf[:, 0] if use_sf else None,
-                action_raster=action_f.squeeze(1) if use_sf else None)
+            nq = nq.contiguous().float()
+            q_target, _, arg = dqn_ops.td_target(seg, nq, lin, done, self.gamma)
+            sf_target = None
+            if use_sf:
+                # successor features of the arg-max row of every transition only (nsf holds the DISTINCT rows' outputs)
+                best = arg.long().clamp_(0, idx.numel() - 1)                       # empty segments are 'done': row unused
+                nsf0 = nsf[:, 0].index_select(0, best if inverse is None else inverse.index_select(0, best)).reshape(E, -1).contiguous()
+                one_each = torch.arange(E + 1, dtype=torch.int32, device=self.device)
+                _, sf_target, _ = dqn_ops.td_target(one_each, nq[best].contiguous(), lin, done, self.gamma,
+                                                    next_sf=nsf0, action_raster=action_f.squeeze(1))
         else:
             q_target = lin
             sf_target = action_f.reshape(E, -1) if use_sf else None

@@ -496,3 +496,63 @@ def test_record_kernels_at_the_last_block_slot_and_on_the_floor():
         for name in ("n_blocks", "blk_shape", "blk_pose", "blk_occ", "n_cand", "n_valid", "state_bits"):
             assert torch.equal(a.buf[name], b.buf[name]), name
         assert torch.equal(lin, padded[:, R.O_LIN].float()) and torch.equal(done.bool(), padded[:, R.O_DONE] > 0.5)
+
+
+@pytest.mark.parametrize("model,loss", [("ConvNet", "mse_q_values"), ("UNet", "mse_q_values+mse_block_features")])
+def test_distinct_row_forward_equals_the_forward_of_every_row(model, loss):
+    """The conv Q-networks are fed every DISTINCT (state, candidate, stable flag) input once (VecDQN._distinct_rows: hash of the
+    bit rasters, torch.unique, word-for-word verification against the group's representative) and the outputs are copied to
+    the duplicates.  Against feeding every row: same q (1e-5: the batch composition of the convolutions differs), same TD /
+    successor-feature targets, on the candidate sets of a running env set -- where many envs share early states."""
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", model, "--loss_function", loss]))
+    dev = torch.device("cuda")
+    env = make_env(256, seed=31, tower=2, max_steps=10)
+    torch.manual_seed(8)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 8192, 16, 0.95, 0.01, loss, seed=5)
+    try:
+        fed = []
+        for it in range(5):
+            idx, row_env = env.valid_rows()
+            stable = agent._stable_flags(env)
+            with torch.no_grad():
+                pol.eval()
+                VecDQN.DEDUP_ROWS = True
+                agent.rows_seen = agent.rows_fed = 0
+                q_d, sf_d, sb_d, inv = agent._forward_rows(pol, env, idx, row_env, stable)
+                fed.append((agent.rows_fed, agent.rows_seen))
+                VecDQN.DEDUP_ROWS = False
+                q_a, sf_a, sb_a, none = agent._forward_rows(pol, env, idx, row_env, stable)
+            assert none is None and q_a.shape == q_d.shape == (idx.numel(),)
+            assert torch.allclose(q_d, q_a, rtol=1e-5, atol=1e-5), float((q_d - q_a).abs().max())
+            if inv is not None:
+                assert inv.shape == (idx.numel(),) and int(inv.max()) + 1 == agent.rows_fed < idx.numel()
+                if sf_a is not None:
+                    assert torch.allclose(sf_d.index_select(0, inv), sf_a, rtol=1e-5, atol=1e-5)
+                if sb_a is not None:
+                    assert torch.allclose(sb_d.index_select(0, inv), sb_a, rtol=1e-5, atol=1e-5)
+            VecDQN.DEDUP_ROWS = True
+            rec, valid = agent.act()
+            agent.ring.push(rec[valid])
+        assert fed[0][0] * 20 < fed[0][1]              # lock-step 1: every env holds the reset state -- one env's rows are fed
+        assert all(f < s for f, s in fed[:3])
+        rec = agent.ring.sample(64, agent.sample_gen)
+        VecDQN.DEDUP_ROWS = True
+        with_d = agent._targets(rec)
+        VecDQN.DEDUP_ROWS = False
+        without = agent._targets(rec)
+        for a, b in zip(with_d, without):
+            if a is None:
+                assert b is None
+            else:
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), float((a - b).abs().max())
+        # a hash that collides (all multipliers zero) must be caught by the word-for-word check: plain path, same result
+        VecDQN.DEDUP_ROWS = True
+        agent._hash_mult = torch.zeros((2, 64), dtype=torch.int64, device=dev)
+        idx, row_env = env.valid_rows()
+        stable = agent._stable_flags(env)
+        assert agent._distinct_rows(env, idx, row_env, stable) is None
+    finally:
+        VecDQN.DEDUP_ROWS = True

@@ -21,6 +21,7 @@ ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--train_steps", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--no_fused_adam", action="store_true")
+ap.add_argument("--no_dedup", action="store_true", help="feed every candidate row, also those with identical inputs (A/B)")
 ap.add_argument("--miopen_search", action="store_true", help="let MIOpen benchmark its algorithms (one shape per run)")
 ap.add_argument("--channels_last", action="store_true")
 ap.add_argument("--shapes", default="trapezoid", choices=["trapezoid", "hexagon", "both"])
@@ -45,10 +46,13 @@ env = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], obs
                      device=dev, f32_rasters=VecDQN.acting_needs_f32_rasters(pol), candidate_snapshots=False)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
+if a.no_dedup:
+    VecDQN.DEDUP_ROWS = False
 for i in range(a.warmup):
     agent.lockstep(a.train_steps)
     print("warm-up lock-step", i, "done", flush=True)
 # 1) the loop as run_vectorised runs it: nothing between lock-steps waits for the optimiser steps (deferred loss readback)
+agent.rows_seen = agent.rows_fed = 0
 torch.cuda.synchronize(); s0 = agent.env_steps; t0 = time.perf_counter()
 pending, per_step, tp = None, [], t0
 for _ in range(a.locksteps):
@@ -61,6 +65,7 @@ losses = pending.get()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 steps_done = agent.env_steps - s0
+rows_seen, rows_fed = getattr(agent, "rows_seen", 0), getattr(agent, "rows_fed", 0)
 per_step.sort()
 median = per_step[len(per_step) // 2]
 # 2) the same lock-steps with a device synchronisation between the phases, for the per-phase times only
@@ -87,6 +92,7 @@ for _ in range(n_phase):
 print(json.dumps(dict(config=vars(a), env_steps_per_s=steps_done / dt,
                       env_steps_per_s_at_median_lockstep=steps_done / a.locksteps / median, ms_median_lockstep=median * 1e3,
                       ms_per_lockstep=dt / a.locksteps * 1e3,
+                      rows_per_lockstep=rows_seen / a.locksteps, rows_fed_fraction=(rows_fed / rows_seen) if rows_seen else None,
                       ms_act=t_act / n_phase * 1e3, ms_targets=t_targets[0] / n_phase * 1e3, ms_train=t_train / n_phase * 1e3,
                       ms_per_train_step=(t_train - t_targets[0]) / n_phase / a.train_steps * 1e3, last_loss=losses[-1] if losses else None,
                       note="env_steps_per_s: pipelined loop (VecDQN.lockstep, deferred loss readback); ms_act / ms_targets / "
