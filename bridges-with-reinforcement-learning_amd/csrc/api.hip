@@ -284,8 +284,12 @@ int bridges_env_refresh(bridges_env* env, void* stream) {
     return refresh(env, (hipStream_t)stream, 0);
 }
 
+#ifndef CS_TAB_SMALL
 #define CS_TAB_SMALL 768     // 6 KiB: with carriers, candidates on up to ~4 placed blocks; 9.5 KB of LDS and <= 128 VGPRs per wave: 16 waves per CU
+#endif
+#ifndef CS_COLS_SMALL
 #define CS_COLS_SMALL 92
+#endif
 #define CS_TAB_LARGE 4096
 int bridges_env_candidate_stability(bridges_env* env, void* stream) {
     if (!env) return fail_arg("null env");

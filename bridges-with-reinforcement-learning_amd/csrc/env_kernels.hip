@@ -788,9 +788,14 @@ __global__ __launch_bounds__(WAVE) void k_select(DevCtx c, int draw) {
 // a candidate whose tableau does not fit is appended to cand_queue (one atomic per such candidate, they are rare).
 // QUEUE == true: a small persistent grid drains that queue with the full-size LDS tableau and the env workspace
 // lp_ws (one slot per workgroup) behind it; every wave leaves when the queue head passes the count.
+#ifndef CS_NEW_IF
 #define CS_NEW_IF 16
+#endif
+#ifndef CS_WAVES            // waves per SIMD the first pass is compiled for (register cap 512 / CS_WAVES); tools/cs_variants.sh
+#define CS_WAVES 4
+#endif
 template <int TAB, int MAXCOLS, bool QUEUE>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(QUEUE ? 1 : 4, QUEUE ? 2 : 4))) void k_candidate_stability(DevCtx c) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(QUEUE ? 1 : CS_WAVES, QUEUE ? 2 : CS_WAVES))) void k_candidate_stability(DevCtx c) {
     __shared__ __attribute__((aligned(16))) double tab[TAB];
     __shared__ LpScratchT<MAXCOLS> S;
     __shared__ double new_geom[CS_NEW_IF * 8];

@@ -528,7 +528,7 @@ def test_distinct_row_forward_equals_the_forward_of_every_row(model, loss):
             assert none is None and q_a.shape == q_d.shape == (idx.numel(),)
             assert torch.allclose(q_d, q_a, rtol=1e-5, atol=1e-5), float((q_d - q_a).abs().max())
             if inv is not None:
-                assert inv.shape == (idx.numel(),) and int(inv.max()) + 1 == agent.rows_fed < idx.numel()
+                assert inv.shape == (idx.numel(),) and int(inv.max()) + 1 == fed[-1][0] < idx.numel()
                 if sf_a is not None:
                     assert torch.allclose(sf_d.index_select(0, inv), sf_a, rtol=1e-5, atol=1e-5)
                 if sb_a is not None:
