@@ -222,8 +222,9 @@ def lib():
         "bridges_mlp_mid_supported": [i32, i32, vp],
         "bridges_mlp_mid_forward": [i32, i32, vp, vp, vp, vp, vp],
         "bridges_mlp_mid_backward": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp],
-        "bridges_eps_greedy_select": [i32, i32, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp],
-        "bridges_valid_rows": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_eps_greedy_select": [i32, i32, vp, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_valid_rows": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "bridges_env_groups": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_record_state": [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_record_result": [i32, vp, vp, vp, vp, vp, vp],
         "bridges_replay_unpack": [i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -243,7 +244,7 @@ def lib():
         "bridges_successor_loss": [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp],
         "bridges_adam_step": [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp],
         "bridges_linear_backward_adam": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp, i32, vp],
-        "bridges_td_target": [i32, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
+        "bridges_td_target": [i32, vp, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -259,7 +260,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_action_features", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_bits_dot", "bridges_bits_accumulate", "bridges_head_sigmoid_dot", "bridges_linear_backward_log", "bridges_mlp_mid_rows", "bridges_mlp_mid_supported", "bridges_mlp_mid_forward", "bridges_mlp_mid_backward", "bridges_eps_greedy_select", "bridges_valid_rows", "bridges_record_state", "bridges_record_result", "bridges_replay_unpack", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_action_features", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_bits_dot", "bridges_bits_accumulate", "bridges_head_sigmoid_dot", "bridges_linear_backward_log", "bridges_mlp_mid_rows", "bridges_mlp_mid_supported", "bridges_mlp_mid_forward", "bridges_mlp_mid_backward", "bridges_eps_greedy_select", "bridges_valid_rows", "bridges_env_groups", "bridges_record_state", "bridges_record_result", "bridges_replay_unpack", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
     "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_mlp_input_batches", "bridges_successor_loss", "bridges_adam_step", "bridges_linear_backward_adam",
 )

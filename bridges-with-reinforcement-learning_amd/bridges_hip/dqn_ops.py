@@ -17,15 +17,22 @@ def _stream():
 def td_target(seg_offset, next_q, lin_reward, done, gamma, next_sf=None, action_raster=None):
     """Target construction of train_policy_net (successor_dqn.py:197-213, 222, 230) in one kernel.
 
-    seg_offset int32 [B+1]: rows [seg_offset[i], seg_offset[i+1]) of next_q / next_sf belong to transition i.
+    seg_offset int32 [B+1]: rows [seg_offset[i], seg_offset[i+1]) of next_q / next_sf belong to transition i; or a pair
+    (lo, hi) of int32 [B] tensors with the rows [lo[i], hi[i]) (transitions whose next states are the same state share rows).
     next_q f32 [R]; next_sf f32 [R, D] view (row stride may exceed D, e.g. psi[:, 0] of a [R,2,64,64] tensor);
     action_raster f32 [B, D]; lin_reward f32 [B]; done uint8/bool [B].
     Returns (q_target [B], sf_target [B, D] or None, argmax_row int32 [B])."""
     L = abi.require_gpu()
-    B = seg_offset.numel() - 1
     dev = next_q.device
     assert next_q.is_contiguous() and next_q.dtype == torch.float32
-    seg_offset = seg_offset.to(device=dev, dtype=torch.int32).contiguous()
+    if isinstance(seg_offset, (tuple, list)):
+        seg_lo, seg_hi = (t.to(device=dev, dtype=torch.int32).contiguous() for t in seg_offset)
+        B = seg_lo.numel()
+        assert seg_hi.numel() == B
+    else:
+        seg_offset = seg_offset.to(device=dev, dtype=torch.int32).contiguous()
+        B = seg_offset.numel() - 1
+        seg_lo, seg_hi = seg_offset[:B], seg_offset[1:]                # views of one buffer: (seg, seg + 1)
     lin_reward = lin_reward.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
     done_u8 = done.to(device=dev).to(torch.uint8).contiguous()
     q_target = torch.empty(B, dtype=torch.float32, device=dev)
@@ -38,7 +45,7 @@ def td_target(seg_offset, next_q, lin_reward, done, gamma, next_sf=None, action_
         action_raster = action_raster.to(torch.float32).reshape(B, D).contiguous()
         sf_target = torch.empty((B, D), dtype=torch.float32, device=dev)
         sf_dim = D
-    abi.check(L.bridges_td_target(B, _ptr(seg_offset), _ptr(next_q), _ptr(next_sf), stride, _ptr(action_raster),
+    abi.check(L.bridges_td_target(B, _ptr(seg_lo), _ptr(seg_hi), _ptr(next_q), _ptr(next_sf), stride, _ptr(action_raster),
                                   _ptr(lin_reward), _ptr(done_u8), float(gamma), sf_dim, _ptr(q_target), _ptr(sf_target),
                                   _ptr(argmax_row), _stream()), "bridges_td_target")
     return q_target, sf_target, argmax_row

@@ -231,13 +231,23 @@ def head_sigmoid_dot(h, Wd, bd, w, splits=None):
     return out
 
 
-def eps_greedy_select(seg, q, join, u, eps, greedy, idx, cand_offset):
-    """EpsilonGreedy.select for every env in one launch (bridges_eps_greedy_select): seg int32 [E + 1] row ranges, q / join
-    float32 [n] (n >= 1), u float32 [E] uniform draws, idx int64 [n] compact candidate index of every row, cand_offset int32 [E].
+def eps_greedy_select(seg, q, join, u, eps, greedy, idx, cand_offset, rep=None):
+    """EpsilonGreedy.select for every env in one launch (bridges_eps_greedy_select): seg int32 [E + 1] row ranges -- or a pair
+    (lo, hi) of int32 [E] tensors, with rep int32 [E] = the env whose candidates the rows of env e index (envs in the same
+    state share rows, bridges_env_groups) --, q / join float32 [n] (n >= 1), u float32 [E] uniform draws, idx int64 [n] compact
+    candidate index of every row, cand_offset int32 [E].
     -> (sel_compact int64 [E], sel_index int32 [E], q_sel float32 [E], explore_w float32 [E])."""
     L = abi.require_gpu()
-    E, n = seg.numel() - 1, q.numel()
-    assert seg.dtype == torch.int32 and idx.dtype == torch.int64 and cand_offset.dtype == torch.int32 and n >= 1
+    if isinstance(seg, (tuple, list)):
+        seg_lo, seg_hi = seg
+        E = seg_lo.numel()
+    else:
+        E = seg.numel() - 1
+        seg_lo, seg_hi = seg[:E], seg[1:]
+    n = q.numel()
+    assert seg_lo.dtype == torch.int32 and seg_hi.dtype == torch.int32 and seg_lo.is_contiguous() and seg_hi.is_contiguous()
+    assert idx.dtype == torch.int64 and cand_offset.dtype == torch.int32 and n >= 1
+    assert rep is None or (rep.dtype == torch.int32 and rep.numel() == E and rep.is_contiguous())
     q, join, u = q.to(torch.float32).contiguous(), join.to(torch.float32).contiguous(), u.to(torch.float32).contiguous()
     idx, cand_offset = idx.contiguous(), cand_offset.contiguous()
     assert join.numel() == n and idx.numel() == n and u.numel() == E and cand_offset.numel() >= E
@@ -245,8 +255,8 @@ def eps_greedy_select(seg, q, join, u, eps, greedy, idx, cand_offset):
     sel_compact = torch.empty(E, dtype=torch.int64, device=dev)
     sel_index = torch.empty(E, dtype=torch.int32, device=dev)
     q_sel, explore_w = torch.empty(E, dtype=torch.float32, device=dev), torch.empty(E, dtype=torch.float32, device=dev)
-    abi.check(L.bridges_eps_greedy_select(E, n, _ptr(seg), _ptr(q), _ptr(join), _ptr(u), float(eps), int(bool(greedy)), _ptr(idx),
-                                          _ptr(cand_offset), _ptr(sel_compact), _ptr(sel_index), _ptr(q_sel), _ptr(explore_w), _stream()),
+    abi.check(L.bridges_eps_greedy_select(E, n, _ptr(seg_lo), _ptr(seg_hi), _ptr(q), _ptr(join), _ptr(u), float(eps), int(bool(greedy)),
+                                          _ptr(idx), _ptr(cand_offset), _ptr(rep), _ptr(sel_compact), _ptr(sel_index), _ptr(q_sel), _ptr(explore_w), _stream()),
               "bridges_eps_greedy_select")
     return sel_compact, sel_index, q_sel, explore_w
 

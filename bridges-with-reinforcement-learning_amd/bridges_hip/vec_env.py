@@ -411,35 +411,58 @@ class VecAssemblyGym:
         idx, _ = self.valid_rows()
         return idx, self.buf["cand_stable"][idx] == 1
 
-    def valid_rows(self):
+    def state_groups(self, flag=None):
+        """rep int32 [E]: the smallest env index that holds exactly this env's state -- block count and the shape, pose bits
+        and face occupancy of its blocks, plus the caller's per-env ``flag`` byte (e.g. the 'stable' feature) -- found by a
+        64-bit hash and verified word for word (bridges_env_groups; two launches, no wait).  Envs in the same state hold the
+        same candidates in the same order, so valid_rows(rep) lets them share one set of rows."""
+        hkey = getattr(self, "_hkey", None)
+        if hkey is None:
+            hkey = self._hkey = torch.empty(self.E, dtype=torch.int64, device=self.device)
+        rep = torch.empty(self.E, dtype=torch.int32, device=self.device)
+        if flag is not None:
+            flag = flag.to(torch.uint8).contiguous()
+        b = self.buf
+        abi.check(self.L.bridges_env_groups(self.E, self.K, _ptr(b["n_blocks"]), _ptr(b["blk_shape"]), _ptr(b["blk_pose"]),
+                                            _ptr(b["blk_occ"]), _ptr(flag), _ptr(hkey), _ptr(rep), _stream()), "bridges_env_groups")
+        return rep
+
+    def valid_rows(self, rep=None):
         """Compact indices of the valid (filtered) candidates and their owning env: the rows a Q-network is fed
         (bridges_valid_rows: two launches and ONE wait for the row count; torch.nonzero + gather were six launches and two
-        waits).  The returned tensors are views of two alternating buffers: they stay intact until the call after next."""
+        waits).  With ``rep`` (state_groups) only the envs that represent their state get rows, and valid_segments() gives
+        every env the range of its representative.  The returned tensors are views of two alternating buffers: they stay
+        intact until the call after next."""
         cached = getattr(self, "_valid_rows", None)
-        if cached is not None and cached[0] == self._cand_version:       # same candidate set as when it was last asked for
+        if cached is not None and cached[0] == self._cand_version and cached[5] is rep:     # same candidate set, same grouping
             return cached[1], cached[2]
         if getattr(self, "_vr_buf", None) is None:
             cap = self.buf["cand_mask"].numel()
             mk = lambda: (torch.empty(cap, dtype=torch.int64, device=self.device), torch.empty(cap, dtype=torch.int64, device=self.device),
-                          torch.empty(self.E + 1, dtype=torch.int32, device=self.device))
+                          torch.empty(self.E + 1, dtype=torch.int32, device=self.device),
+                          torch.empty((2, self.E), dtype=torch.int32, device=self.device))
             self._vr_buf, self._vr_flip = (mk(), mk()), 0
             self._vr_total = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._vr_flip ^= 1
-        idx_b, env_b, seg = self._vr_buf[self._vr_flip]
+        idx_b, env_b, seg, lohi = self._vr_buf[self._vr_flip]
         b = self.buf
         abi.check(self.L.bridges_valid_rows(self.E, _ptr(b["cand_offset"]), _ptr(b["n_cand"]), _ptr(b["n_valid"]), _ptr(b["cand_mask"]),
-                                            _ptr(seg), _ptr(idx_b), _ptr(env_b), C.c_void_p(self._vr_total.data_ptr()), _stream()),
-                  "bridges_valid_rows")
+                                            _ptr(rep), _ptr(seg), _ptr(lohi[0]) if rep is not None else None,
+                                            _ptr(lohi[1]) if rep is not None else None, _ptr(idx_b), _ptr(env_b),
+                                            C.c_void_p(self._vr_total.data_ptr()), _stream()), "bridges_valid_rows")
         torch.cuda.current_stream(self.device).synchronize()             # the one wait: the count is on the host now
         n = int(self._vr_total[0])
         idx, row_env = idx_b[:n], env_b[:n]
-        self._valid_rows = (self._cand_version, idx, row_env, seg)
+        segs = (lohi[0], lohi[1]) if rep is not None else (seg[:self.E], seg[1:])
+        self._valid_rows = (self._cand_version, idx, row_env, seg, segs, rep)
         return idx, row_env
 
     def valid_segments(self):
-        """Row ranges of the envs in ``valid_rows()``: int32 [E + 1] prefix sums of n_valid (from the same launch)."""
-        self.valid_rows()
-        return self._valid_rows[3]
+        """Row ranges of the envs in the last ``valid_rows()``: (lo, hi), int32 [E] each -- rows lo[e] .. hi[e] are env e's
+        (with a grouping: its representative's); without a grouping they are seg[:-1], seg[1:] of the prefix sums of n_valid."""
+        if getattr(self, "_valid_rows", None) is None or self._valid_rows[0] != self._cand_version:
+            self.valid_rows()
+        return self._valid_rows[4]
 
     # ------------------------------------------------------------------ views
     def flags(self):

@@ -501,16 +501,16 @@ int bridges_soft_update(float* target, const float* policy, int64_t n, float tau
     return BRIDGES_OK;
 }
 
-int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* next_q, const float* next_sf,
+int bridges_td_target(int32_t n_trans, const int32_t* seg_lo, const int32_t* seg_hi, const float* next_q, const float* next_sf,
                       int64_t next_sf_row_stride, const float* action_raster, const float* lin_reward,
                       const uint8_t* done, float gamma, int32_t sf_dim, float* q_target, float* sf_target,
                       int32_t* argmax_row, void* stream) {
-    if (n_trans < 0 || sf_dim < 0) return fail_arg("bridges_td_target");
+    if (n_trans < 0 || sf_dim < 0 || (n_trans > 0 && (!seg_lo || !seg_hi))) return fail_arg("bridges_td_target");
     if (n_trans == 0) return BRIDGES_OK;
     if (sf_dim > 0 && ((next_sf_row_stride & 3) || (sf_dim & 3) ||
                        ((((uintptr_t)next_sf) | ((uintptr_t)action_raster) | ((uintptr_t)sf_target)) & 15)))
         return fail_arg("td_target: sf rows must be 16-byte aligned");
-    hipLaunchKernelGGL(k_td_target, dim3(n_trans), dim3(256), 0, (hipStream_t)stream, n_trans, seg_offset, next_q,
+    hipLaunchKernelGGL(k_td_target, dim3(n_trans), dim3(256), 0, (hipStream_t)stream, n_trans, seg_lo, seg_hi, next_q,
                        next_sf, next_sf_row_stride, action_raster, lin_reward, done, gamma, sf_dim, q_target, sf_target,
                        argmax_row);
     LAUNCH_CHECK("k_td_target");
@@ -528,13 +528,13 @@ int bridges_bits_linear(int32_t n_rows, const uint64_t* bits, const int64_t* bit
     return BRIDGES_OK;
 }
 
-int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg, const float* q, const float* join, const float* u,
-                              float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset, int64_t* sel_compact,
-                              int32_t* sel_index, float* q_sel, float* explore_w, void* stream) {
-    if (E < 1 || n_rows < 1 || !seg || !q || !join || !u || !idx || !cand_offset || !sel_compact || !sel_index || !q_sel || !explore_w)
+int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg_lo, const int32_t* seg_hi, const float* q, const float* join,
+                              const float* u, float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset,
+                              const int32_t* rep, int64_t* sel_compact, int32_t* sel_index, float* q_sel, float* explore_w, void* stream) {
+    if (E < 1 || n_rows < 1 || !seg_lo || !seg_hi || !q || !join || !u || !idx || !cand_offset || !sel_compact || !sel_index || !q_sel || !explore_w)
         return fail_arg("bridges_eps_greedy_select");
-    hipLaunchKernelGGL(k_eps_greedy_select, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, E, n_rows, seg, q, join, u, eps,
-                       (int)greedy, idx, cand_offset, sel_compact, sel_index, q_sel, explore_w);
+    hipLaunchKernelGGL(k_eps_greedy_select, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, E, n_rows, seg_lo, seg_hi, q, join, u, eps,
+                       (int)greedy, idx, cand_offset, rep, sel_compact, sel_index, q_sel, explore_w);
     LAUNCH_CHECK("k_eps_greedy_select");
     return BRIDGES_OK;
 }
@@ -578,13 +578,29 @@ int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec
 }
 
 int bridges_valid_rows(int32_t E, const int32_t* cand_offset, const int32_t* n_cand, const int32_t* n_valid, const uint8_t* cand_mask,
-                       int32_t* seg, int64_t* idx, int64_t* row_env, int32_t* h_total, void* stream) {
-    if (E < 1 || !cand_offset || !n_cand || !n_valid || !cand_mask || !seg || !idx || !row_env || !h_total) return fail_arg("bridges_valid_rows");
+                       const int32_t* rep, int32_t* seg, int32_t* seg_lo, int32_t* seg_hi, int64_t* idx, int64_t* row_env,
+                       int32_t* h_total, void* stream) {
+    if (E < 1 || !cand_offset || !n_cand || !n_valid || !cand_mask || !seg || !idx || !row_env || !h_total || (rep && (!seg_lo || !seg_hi)) ||
+        ((seg_lo == nullptr) != (seg_hi == nullptr)))
+        return fail_arg("bridges_valid_rows");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, E, n_valid, seg, h_total);
+    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, E, n_valid, rep, seg, h_total);
     LAUNCH_CHECK("k_valid_scan");
-    hipLaunchKernelGGL(k_valid_fill, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, E, cand_offset, n_cand, cand_mask, (const int32_t*)seg, idx, row_env);
+    hipLaunchKernelGGL(k_valid_fill, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, E, cand_offset, n_cand, cand_mask, (const int32_t*)seg, rep,
+                       seg_lo, seg_hi, idx, row_env);
     LAUNCH_CHECK("k_valid_fill");
+    return BRIDGES_OK;
+}
+
+int bridges_env_groups(int32_t E, int32_t K, const int32_t* n_blocks, const int32_t* blk_shape, const double* blk_pose,
+                       const uint8_t* blk_occ, const uint8_t* flag, uint64_t* hkey, int32_t* rep, void* stream) {
+    if (E < 1 || K < 1 || K > 64 || !n_blocks || !blk_shape || !blk_pose || !blk_occ || !hkey || !rep) return fail_arg("bridges_env_groups");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_env_hash, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, E, K, n_blocks, blk_shape, blk_pose, blk_occ, flag, hkey);
+    LAUNCH_CHECK("k_env_hash");
+    hipLaunchKernelGGL(k_env_match, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, st, E, K, n_blocks, blk_shape, blk_pose, blk_occ, flag,
+                       (const uint64_t*)hkey, rep);
+    LAUNCH_CHECK("k_env_match");
     return BRIDGES_OK;
 }
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const 
 // train_policy_net target construction (successor_dqn.py:197-213, 222, 230).  One workgroup per transition:
 // segmented first-argmax over its next-action rows, then the q target and (optionally) the successor-feature
 // target row, 16 B per lane.
-__global__ __launch_bounds__(256) void k_td_target(int n_trans, const int32_t* __restrict__ seg_offset,
+__global__ __launch_bounds__(256) void k_td_target(int n_trans, const int32_t* __restrict__ seg_lo, const int32_t* __restrict__ seg_hi,
                                                    const float* __restrict__ next_q, const float* __restrict__ next_sf,
                                                    int64_t sf_row_stride, const float* __restrict__ action_raster,
                                                    const float* __restrict__ lin_reward, const uint8_t* __restrict__ done,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_td_target(int n_trans, const int32_t* _
     __shared__ float s_val[256];
     __shared__ int s_idx[256];
     const int i = blockIdx.x, t = threadIdx.x;
-    const int lo = seg_offset[i], hi = seg_offset[i + 1];
+    const int lo = seg_lo[i], hi = seg_hi[i];
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     for (int j = lo + t; j < hi; j += 256) {
@@ -290,20 +290,24 @@ __global__ __launch_bounds__(256) void k_bias_relu_pool2(const float* __restrict
 // EpsilonGreedy.select (successor_dqn.py:98-132) for every env of the vectorised loop in one launch: per env, over its rows
 // seg[e] .. seg[e + 1] of the Q pass, the greedy row = first maximum of q, the exploring row = first minimum of the overlap
 // `join` of the candidate with the count image of the env's episode step (count-based exploration); the env explores when
-// its uniform draw u[e] <= eps (and the call is not greedy).  An env without rows gets row 0 with weight 0.  Replaces two
+// its uniform draw u[e] <= eps (and the call is not greedy).  An env without rows gets row 0 with weight 0.  The rows of
+// env e are seg_lo[e] .. seg_hi[e] (envs in the same state share their representative's rows, rep[e]: the compact index of
+// the chosen row is then a candidate of the REPRESENTATIVE, whose candidates are env e's own, one for one).  Replaces two
 // segmented arg-max launches and ~20 element-wise / index launches.  One wave per env.
-//   sel_compact[e] = idx[row]  (compact candidate index), sel_index[e] = sel_compact - cand_offset[e] (>= 0),
+//   sel_compact[e] = idx[row]  (compact candidate index), sel_index[e] = sel_compact - cand_offset[rep[e]] (>= 0),
 //   q_sel[e] = q[row] (0 without rows), explore_w[e] = 1.0 if the env explored and has rows else 0.0
-__global__ __launch_bounds__(256) void k_eps_greedy_select(int E, int n_rows, const int32_t* __restrict__ seg, const float* __restrict__ q,
+__global__ __launch_bounds__(256) void k_eps_greedy_select(int E, int n_rows, const int32_t* __restrict__ seg_lo,
+                                                           const int32_t* __restrict__ seg_hi, const float* __restrict__ q,
                                                            const float* __restrict__ join, const float* __restrict__ u, float eps,
                                                            int greedy, const int64_t* __restrict__ idx,
-                                                           const int32_t* __restrict__ cand_offset, int64_t* __restrict__ sel_compact,
+                                                           const int32_t* __restrict__ cand_offset, const int32_t* __restrict__ rep,
+                                                           int64_t* __restrict__ sel_compact,
                                                            int32_t* __restrict__ sel_index, float* __restrict__ q_sel,
                                                            float* __restrict__ explore_w) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
-    const int lo = seg[e], hi = seg[e + 1];
+    const int lo = seg_lo[e], hi = seg_hi[e];
     const bool explore = !greedy && u[e] <= eps;
     // first maximum of q, or of -join (= first minimum of join), over the env's rows
     float best = -INFINITY;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void k_eps_greedy_select(int E, int n_rows, co
         if (row > n_rows - 1) row = n_rows - 1;
         const int64_t c = idx[row];
         sel_compact[e] = c;
-        const int64_t rel = c - (int64_t)cand_offset[e];
+        const int64_t rel = c - (int64_t)cand_offset[rep ? rep[e] : e];
         sel_index[e] = rel > 0 ? (int32_t)rel : 0;
         q_sel[e] = has ? q[row] : 0.f;
         explore_w[e] = (explore && has) ? 1.f : 0.f;

@@ -284,8 +284,11 @@ __global__ __launch_bounds__(WAVE) void k_stability(const bridges_shape* shapes,
 // wait twice (nonzero reads its count back); here the count travels to a host word behind the two launches.
 //   k_valid_scan: seg[e] = sum of n_valid[0 .. e), seg[E] = total -> *h_total (host-visible), one workgroup
 //   k_valid_fill: one wave per env, ballot compaction of its mask bytes in candidate order
-__global__ __launch_bounds__(1024) void k_valid_scan(int E, const int32_t* __restrict__ n_valid, int32_t* __restrict__ seg,
-                                                     int32_t* __restrict__ h_total) {
+// With rep != nullptr (k_env_match: rep[e] = the first env that holds exactly env e's state) only the envs that represent
+// their group get rows; every env's row range seg_lo[e] .. seg_hi[e] is the range of its representative -- envs in the same
+// state hold the same candidates in the same order, so they share the rows (and everything computed from them).
+__global__ __launch_bounds__(1024) void k_valid_scan(int E, const int32_t* __restrict__ n_valid, const int32_t* __restrict__ rep,
+                                                     int32_t* __restrict__ seg, int32_t* __restrict__ h_total) {
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(1024) void k_valid_scan(int E, const int32_t* __res
     __syncthreads();
     for (int base = 0; base < E; base += 1024) {
         const int i = base + t;
-        int incl = i < E ? n_valid[i] : 0;
+        int incl = (i < E && (rep == nullptr || rep[i] == i)) ? n_valid[i] : 0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int up = __shfl_up(incl, o, 64);
@@ -313,10 +316,15 @@ __global__ __launch_bounds__(1024) void k_valid_scan(int E, const int32_t* __res
 
 __global__ __launch_bounds__(256) void k_valid_fill(int E, const int32_t* __restrict__ cand_offset, const int32_t* __restrict__ n_cand,
                                                     const uint8_t* __restrict__ cand_mask, const int32_t* __restrict__ seg,
-                                                    int64_t* __restrict__ idx, int64_t* __restrict__ row_env) {
+                                                    const int32_t* __restrict__ rep, int32_t* __restrict__ seg_lo,
+                                                    int32_t* __restrict__ seg_hi, int64_t* __restrict__ idx,
+                                                    int64_t* __restrict__ row_env) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
+    const int r = rep ? rep[e] : e;
+    if (lane == 0 && seg_lo) { seg_lo[e] = seg[r]; seg_hi[e] = seg[r + 1]; }
+    if (r != e) return;                                                   // the representative's rows serve this env
     const int off = cand_offset[e], n = n_cand[e], end = seg[e + 1];
     int pos = seg[e];
     for (int base = 0; base < n; base += 64) {
@@ -330,6 +338,68 @@ __global__ __launch_bounds__(256) void k_valid_fill(int E, const int32_t* __rest
         }
         pos += __popcll(b);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Environments in the same state.  Thousands of envs of one task pass through the same early states (every freshly reset
+// env holds the empty assembly; a near-deterministic policy sends many of them down the same paths), and everything a
+// Q-network is asked about a state -- its candidate rows and their values -- is a function of the state alone.
+//   k_env_hash:  hkey[e] = 64-bit hash of (n_blocks, the live slots' shape / pose bits / occupancy, flag[e])
+//   k_env_match: rep[e] = the smallest env index with the same hash whose state equals env e's WORD FOR WORD (else e itself:
+//                a hash collision only costs the sharing, never correctness).  E^2 / 64 comparisons per wave: 4096 envs, ~10 us.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_env_hash(int E, int K, const int32_t* __restrict__ n_blocks, const int32_t* __restrict__ blk_shape,
+                                                  const double* __restrict__ blk_pose, const uint8_t* __restrict__ blk_occ,
+                                                  const uint8_t* __restrict__ flag, uint64_t* __restrict__ hkey) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const int nb = n_blocks[e];
+    uint64_t h = 0ull;
+    if (lane < nb && lane < K) {
+        const size_t s = (size_t)e * K + lane;
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(blk_pose + s * 4);
+        uint64_t a = mix64((uint64_t)(uint32_t)blk_shape[s] | ((uint64_t)blk_occ[s] << 32));
+        a = mix64(a ^ p[0]); a = mix64(a ^ p[1]); a = mix64(a ^ p[2]); a = mix64(a ^ p[3]);
+        h = mix64(a + (uint64_t)(lane + 1) * 0x9E3779B97F4A7C15ull);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) h += __shfl_xor(h, m);
+    if (lane == 0) hkey[e] = mix64(h + (uint64_t)nb * 0xD6E8FEB86659FD93ull + (flag ? (uint64_t)flag[e] : 0ull));
+}
+
+__global__ __launch_bounds__(256) void k_env_match(int E, int K, const int32_t* __restrict__ n_blocks, const int32_t* __restrict__ blk_shape,
+                                                   const double* __restrict__ blk_pose, const uint8_t* __restrict__ blk_occ,
+                                                   const uint8_t* __restrict__ flag, const uint64_t* __restrict__ hkey,
+                                                   int32_t* __restrict__ rep) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const uint64_t mine = hkey[e];
+    int r = e;
+    for (int base = 0; base < e; base += 64) {                           // ascending: the first chunk with a hit holds the minimum
+        const int j = base + lane;
+        const unsigned long long hit = __ballot(j < e && hkey[j] == mine);
+        if (hit) { r = base + (__ffsll((long long)hit) - 1); break; }
+    }
+    bool same = true;
+    if (r != e) {
+        const int nb = n_blocks[e];
+        same = nb == n_blocks[r] && (flag == nullptr || flag[e] == flag[r]);
+        if (same && lane < nb && lane < K) {
+            const size_t a = (size_t)e * K + lane, b = (size_t)r * K + lane;
+            const uint64_t* pa = reinterpret_cast<const uint64_t*>(blk_pose + a * 4);
+            const uint64_t* pb = reinterpret_cast<const uint64_t*>(blk_pose + b * 4);
+            same = blk_shape[a] == blk_shape[b] && blk_occ[a] == blk_occ[b] && pa[0] == pb[0] && pa[1] == pb[1] && pa[2] == pb[2] &&
+                   pa[3] == pb[3];
+        }
+        same = __ballot(!same) == 0ull;
+    }
+    if (lane == 0) rep[e] = same ? r : e;
 }
 
 }  // namespace bridges

@@ -66,7 +66,33 @@ class VecDQN:
         self._counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()      # (env-steps, finished episodes) of a lock-step
 
     ROW_CHUNK = 2048       # rows per forward call: ONE input shape for the whole run (MIOpen tunes per shape)
-    DEDUP_ROWS = True      # feed every distinct (state, candidate, stable flag) input once (tests compare with False)
+    DEDUP_STATES = True    # envs in the same state share one set of candidate rows (tests compare with False)
+    DEDUP_ROWS = True      # conv nets: feed every distinct (state, candidate, stable flag) input once (tests compare with False)
+    TRACK_ROWS = False     # tools: count the valid rows of every Q pass (rows_seen) beside the rows actually fed (rows_fed)
+
+    def _rows(self, env, stable):
+        """The candidate rows a Q pass over ``env`` is fed: (idx, row_env, (seg_lo, seg_hi), rep).  Thousands of envs of one task
+        pass through the same states -- every freshly reset env holds the empty assembly, and the reference's policy is a
+        near-deterministic function of the state (greedy arg-max, or the least-tried candidate of the episode step) -- and
+        the rows of a state and their values depend on the state alone: envs whose block lists and stable flag are equal
+        word for word (VecAssemblyGym.state_groups) share the rows of the first of them; rows seg_lo[e] .. seg_hi[e] are env
+        e's.  Exact (the same kernels on the same inputs), two extra launches, no extra wait."""
+        cache = getattr(env, "_dqn_rows", None)
+        if cache is not None and cache[0] == env._cand_version:
+            return cache[1]
+        rep = env.state_groups(stable) if self.DEDUP_STATES else None
+        idx, row_env = env.valid_rows(rep)
+        out = (idx, row_env, env.valid_segments(), rep)
+        env._dqn_rows = (env._cand_version, out)
+        if self.TRACK_ROWS:
+            seen = env.n_valid[:env.E].sum()
+            self._rows_seen_dev = seen if getattr(self, "_rows_seen_dev", None) is None else self._rows_seen_dev + seen
+        return out
+
+    @property
+    def rows_seen(self):
+        dev = getattr(self, "_rows_seen_dev", None)
+        return int(dev) if dev is not None else 0
 
     def _distinct_rows(self, env, idx, row_env, stable_flag):
         """Candidate rows whose network input is the same tensor, bit for bit: the input of a row is (state raster of its env,
@@ -101,7 +127,6 @@ class VecDQN:
                 & (flag.index_select(0, row_env) == flag.index_select(0, renv)))
         if not bool(same.all()):
             return None
-        self.rows_seen, self.rows_fed = getattr(self, "rows_seen", 0) + n, getattr(self, "rows_fed", 0) + n_groups
         return rep, inverse
 
     def _forward_rows(self, net, env, idx, row_env, stable_flag):
@@ -109,15 +134,13 @@ class VecDQN:
         (sliced off again), so the convolution / GEMM shapes never change from lock-step to lock-step.  Rows with identical
         inputs are fed once (_distinct_rows).  -> (q [n], successor block features of the DISTINCT rows or None, successor
         binary features of the distinct rows or None, inverse [n] = the distinct row of every row (None: every row is fed))."""
-        n_all = idx.numel()
         groups = self._distinct_rows(env, idx, row_env, stable_flag)
         inverse = None
         if groups is not None:
             rep, inverse = groups
             idx, row_env = idx.index_select(0, rep), row_env.index_select(0, rep)
-        else:
-            self.rows_seen, self.rows_fed = getattr(self, "rows_seen", 0) + n_all, getattr(self, "rows_fed", 0) + n_all
         n, C = idx.numel(), self.ROW_CHUNK
+        self.rows_fed = getattr(self, "rows_fed", 0) + n
         pad = (-n) % C
         if pad:
             idx = torch.cat([idx, idx[:1].expand(pad)])
@@ -160,12 +183,6 @@ class VecDQN:
         f32_rasters=False and its rasteriser skips the 16 KiB-per-candidate expansion."""
         return not cls._factored(net)
 
-    @staticmethod
-    def _segments(env):
-        """Row ranges of the envs in ``env.valid_rows()`` (rows are env-major) from the env's own per-env counts --
-        torch.bincount would make the host wait for the device (it reads the maximum back)."""
-        counts = env.n_valid[:env.E].long()
-        return env.valid_segments(), counts                    # the prefix sums bridges_valid_rows left beside the rows
 
     @staticmethod
     def _stable_flags(env):
@@ -190,6 +207,7 @@ class VecDQN:
         # the first layer consumes the BIT-PACKED rasters (bridges_bits_linear): a raster times a weight slice is the
         # sum of the ~35 weight rows of its set pixels, so neither f32 images nor a [n, 4096] GEMM
         px = 64 * 64
+        self.rows_fed = getattr(self, "rows_fed", 0) + idx.numel()
         W1 = net.first_layer().weight
         # the part of the first layer that does not depend on the images: a two-row table indexed by the env's stable flag
         # (the other binary features are 0, as in the reference without pybullet)
@@ -207,13 +225,13 @@ class VecDQN:
         with the policy net as it is now, next value 0 when done; the env holds s' (or a fresh state when done)."""
         env, E = self.env, self.env.E
         done = rec[:, R.O_DONE] > 0.5
-        idx, row_env = env.valid_rows()
+        stable = self._stable_flags(env)
+        idx, row_env, seg, _rep = self._rows(env, stable)
         next_q = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
-            q = self._policy_q(env, idx, row_env, self._stable_flags(env))
-            seg, counts = self._segments(env)
+            q = self._policy_q(env, idx, row_env, stable)
             zeros = torch.zeros(E, dtype=torch.float32, device=self.device)
-            next_q, _, _ = dqn_ops.td_target(seg, q.contiguous().float(), zeros, done | (counts == 0), 1.0)   # segmented max
+            next_q, _, _ = dqn_ops.td_target(seg, q.contiguous().float(), zeros, done | (env.n_valid[:E] == 0), 1.0)   # segmented max
         expected = rec[:, R.O_REWARD].float() + 0.95 * next_q                      # hard-coded 0.95 (successor_dqn.py:425)
         return (self._q_sel - expected).abs()
 
@@ -221,9 +239,8 @@ class VecDQN:
     @torch.no_grad()
     def act(self, greedy=False):
         env, E = self.env, self.env.E
-        idx, row_env = env.valid_rows()
         stable = self._stable_flags(env)
-        seg = env.valid_segments()
+        idx, row_env, seg, rep = self._rows(env, stable)
         self._q_sel = torch.zeros(E, dtype=torch.float32, device=self.device)
         if idx.numel():
             step_of_row = env.n_blocks[row_env].long()
@@ -238,7 +255,7 @@ class VecDQN:
             # (bridges_eps_greedy_select; an `if explore.any()` here would make the host wait for the Q pass it has just queued)
             u = torch.rand(E, generator=self.explore_gen, device=self.device)
             sel_compact, sel_index, self._q_sel, ex_w = ops.eps_greedy_select(seg, q, join, u, self.epsilon, greedy, idx,
-                                                                              env.cand_offset[:E])
+                                                                              env.cand_offset[:E], rep=rep)
             # count images of the explored choices; every env takes part with weight 0 or 1, so no host decision
             step_of_env = env.n_blocks.long()
             if env.img == 64:                                     # the set pixels of the chosen rasters, by float atomics
@@ -289,11 +306,10 @@ class VecDQN:
         bits_s, lin, stable_s, done_rec, stable_n = renv.load_records(rec.contiguous())
         block_f = renv.crop(ops.bits_to_f32(bits_s)).unsqueeze(1)
         action_f = renv.crop(ops.bits_to_f32(renv.state_bits & ~bits_s)).unsqueeze(1)         # s' minus s = the new block
-        idx, row_env = renv.valid_rows()
-        seg, counts = self._segments(renv)
-        done = done_rec.bool() | (counts == 0)
-        use_sf = 'mse_block_features' in self.loss_parts
         stable_n = stable_n.bool()
+        idx, row_env, seg, _rep = self._rows(renv, stable_n)      # transitions with the same next state share its rows
+        done = done_rec.bool() | (renv.n_valid[:E] == 0)
+        use_sf = 'mse_block_features' in self.loss_parts
         if idx.numel() and self._factored(self.target_net):
             # q of every next candidate through the factored forward on the bit-packed rasters; the 8204-wide output
             # (successor features) is only needed for the arg-max row of each transition
@@ -566,7 +582,7 @@ class VecDQN:
         self._counts_host.copy_(torch.stack([valid.sum(), done_rec.sum()]), non_blocking=True)
         arrived = torch.cuda.Event()
         arrived.record()
-        self.env.valid_rows()
+        self._rows(self.env, self._stable_flags(self.env))
         arrived.synchronize()                           # passed already unless the rows came out of the env's cache
         n_valid, n_done = int(self._counts_host[0]), int(self._counts_host[1])
         self.env_steps += n_valid

@@ -305,21 +305,33 @@ int bridges_stability_penalty(const bridges_shape* shapes_dev, int32_t n, int32_
 int bridges_shapes_upload(const bridges_shape* shapes_host, int32_t n_shapes, bridges_shape** out_dev);
 int bridges_shapes_free(bridges_shape* dev);
 
+/* Environments in the same state: rep[e] = the smallest env index whose state -- n_blocks and the shape id, pose (bit
+ * pattern) and face occupancy of its live block slots, plus the caller's flag[e] byte (may be NULL) -- equals env e's word
+ * for word (found through a 64-bit hash, hkey [E] scratch, then verified: a hash collision costs the sharing, never
+ * correctness).  What a Q-network is asked about a state (its candidate rows, their values) depends on the state alone, so
+ * the envs of a group share their representative's rows (bridges_valid_rows with rep).  K = block slots per env (<= 64). */
+int bridges_env_groups(int32_t E, int32_t K, const int32_t* n_blocks, const int32_t* blk_shape, const double* blk_pose,
+                       const uint8_t* blk_occ, const uint8_t* flag, uint64_t* hkey, int32_t* rep, void* stream);
+
 /* The rows a Q-network is fed (filter_actions, actions.py:71-82, for every env at once): compact indices of the candidates
  * with cand_mask != 0, env-major in candidate order, their owning env, and seg[e] .. seg[e + 1] = the rows of env e
  * (seg [E + 1]; n_valid[e] = the env's count, as bridges_env_step leaves it).  idx / row_env need room for every candidate.
+ * With rep (bridges_env_groups; may be NULL) only the envs with rep[e] == e get rows; seg_lo[e] .. seg_hi[e] ([E] each; may
+ * both be NULL when rep is) is then the row range of env e's representative -- the rows every env of the group reads.
  * The total goes to *h_total, a HOST-visible word (pinned, device-accessible): valid once the stream has passed the call. */
 int bridges_valid_rows(int32_t E, const int32_t* cand_offset, const int32_t* n_cand, const int32_t* n_valid, const uint8_t* cand_mask,
-                       int32_t* seg, int64_t* idx, int64_t* row_env, int32_t* h_total, void* stream);
+                       const int32_t* rep, int32_t* seg, int32_t* seg_lo, int32_t* seg_hi, int64_t* idx, int64_t* row_env,
+                       int32_t* h_total, void* stream);
 
-/* EpsilonGreedy.select (successor_dqn.py:98-132) for every env at once.  Rows seg[e] .. seg[e + 1] of q / join / idx belong to
- * env e (bridges_valid_rows).  The env explores when u[e] <= eps and greedy == 0: its row is then the FIRST minimum of join (the
+/* EpsilonGreedy.select (successor_dqn.py:98-132) for every env at once.  Rows seg_lo[e] .. seg_hi[e] of q / join / idx belong to
+ * env e (bridges_valid_rows; a prefix-sum array seg is passed as seg, seg + 1); rep (may be NULL): the env whose candidates
+ * those rows index (bridges_env_groups).  The env explores when u[e] <= eps and greedy == 0: its row is then the FIRST minimum of join (the
  * overlap of the candidate raster with the count image of the env's episode step), else the FIRST maximum of q.
- * -> sel_compact[e] = idx[row], sel_index[e] = max(sel_compact - cand_offset[e], 0), q_sel[e] = q[row],
+ * -> sel_compact[e] = idx[row], sel_index[e] = max(sel_compact - cand_offset[rep ? rep[e] : e], 0), q_sel[e] = q[row],
  *    explore_w[e] = 1 if the env explored (the weight of its count-image update) -- an env without rows: idx[0], 0, 0. */
-int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg, const float* q, const float* join, const float* u,
-                              float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset, int64_t* sel_compact,
-                              int32_t* sel_index, float* q_sel, float* explore_w, void* stream);
+int bridges_eps_greedy_select(int32_t E, int32_t n_rows, const int32_t* seg_lo, const int32_t* seg_hi, const float* q, const float* join,
+                              const float* u, float eps, int32_t greedy, const int64_t* idx, const int32_t* cand_offset,
+                              const int32_t* rep, int64_t* sel_compact, int32_t* sel_index, float* q_sel, float* explore_w, void* stream);
 
 /* --- transition records of the vectorised loop ------------------------------------------------------------------
  * One float64 row per transition: the compact form of the reference's Transition (successor_dqn.py:27-44) -- the block
@@ -366,10 +378,11 @@ int bridges_replay_unpack(int32_t E, int32_t n_rec, int32_t K, const double* rec
  * sum rounded separately in float32 as torch evaluates it (one_minus_tau = (float)(1.0 - tau) from the host). */
 int bridges_soft_update(float* target, const float* policy, int64_t n, float tau, float one_minus_tau, void* stream);
 /* train_policy_net target construction (successor_dqn.py:197-213, 222, 230):
- * per transition i with rows [seg_offset[i], seg_offset[i+1]) of the target net's output:
+ * per transition i with rows [seg_lo[i], seg_hi[i]) of the target net's output (a prefix-sum array: seg, seg + 1;
+ * transitions whose next states are the same state may share a range, bridges_valid_rows with rep):
  *   j* = argmax next_q (first maximum), q_target[i] = lin_reward[i] + gamma * (done ? 0 : next_q[j*]),
  *   sf_target[i,:] = action_raster[i,:] + gamma * (done ? 0 : next_sf[j*,:])   (sf_dim may be 0). */
-int bridges_td_target(int32_t n_trans, const int32_t* seg_offset, const float* next_q, const float* next_sf,
+int bridges_td_target(int32_t n_trans, const int32_t* seg_lo, const int32_t* seg_hi, const float* next_q, const float* next_sf,
                       int64_t next_sf_row_stride, const float* action_raster, const float* lin_reward,
                       const uint8_t* done, float gamma, int32_t sf_dim, float* q_target, float* sf_target,
                       int32_t* argmax_row, void* stream);

@@ -100,9 +100,9 @@ def test_valid_rows_operator_equals_nonzero(shape, E):
         want = torch.nonzero(env.buf["cand_mask"][:total]).squeeze(1)
         assert torch.equal(idx, want)
         assert torch.equal(row_env, env.buf["cand_env"][want].long())
-        seg = env.valid_segments()
-        assert seg.dtype == torch.int32 and int(seg[0]) == 0 and int(seg[E]) == idx.numel()
-        assert torch.equal(seg[1:] - seg[:-1], env.n_valid[:E])
+        lo, hi = env.valid_segments()
+        assert lo.dtype == hi.dtype == torch.int32 and int(lo[0]) == 0 and int(hi[E - 1]) == idx.numel()
+        assert torch.equal(hi - lo, env.n_valid[:E]) and torch.equal(lo[1:], hi[:-1])
         assert env.valid_rows()[0] is idx                                  # cached until the candidate set changes
         if prev is not None:
             assert torch.equal(prev[0], prev[1])                           # the rows of the call before are untouched
@@ -456,8 +456,8 @@ def test_valid_rows_operator_on_ragged_and_empty_inputs(E, amax, p_valid):
     idx = torch.full((max(total, 1),), -7, dtype=torch.int64, device=dev)
     renv = torch.full((max(total, 1),), -7, dtype=torch.int64, device=dev)
     host = torch.full((1,), -7, dtype=torch.int32).pin_memory()
-    abi.check(abi.lib().bridges_valid_rows(E, _ptr(off_d), _ptr(nc_d), _ptr(nv_d), _ptr(mask_d), _ptr(seg), _ptr(idx), _ptr(renv),
-                                           C.c_void_p(host.data_ptr()), _stream()), "bridges_valid_rows")
+    abi.check(abi.lib().bridges_valid_rows(E, _ptr(off_d), _ptr(nc_d), _ptr(nv_d), _ptr(mask_d), None, _ptr(seg), None, None, _ptr(idx),
+                                           _ptr(renv), C.c_void_p(host.data_ptr()), _stream()), "bridges_valid_rows")
     torch.cuda.synchronize()
     want = torch.nonzero(mask[:total]).squeeze(1)
     n = int(host[0])
@@ -556,3 +556,110 @@ def test_distinct_row_forward_equals_the_forward_of_every_row(model, loss):
         assert agent._distinct_rows(env, idx, row_env, stable) is None
     finally:
         VecDQN.DEDUP_ROWS = True
+
+
+def _state_keys(env, flag):
+    nb = env.n_blocks.cpu().numpy()
+    shape, pose, occ = env.blk_shape.cpu().numpy(), env.blk_pose.cpu().numpy().view(np.int64), env.blk_occ.cpu().numpy()
+    fl = flag.cpu().numpy().astype(np.uint8)
+    return [(int(nb[e]), shape[e, :nb[e]].tobytes(), pose[e, :nb[e]].tobytes(), occ[e, :nb[e]].tobytes(), int(fl[e])) for e in range(env.E)]
+
+
+@pytest.mark.parametrize("shape,E", [("trapezoid", 256), ("hexagon", 100)])
+def test_state_groups_and_shared_rows(shape, E):
+    """bridges_env_groups: rep[e] = the first env whose state (block count, live shapes / pose bits / occupancy, flag byte)
+    equals env e's, against a dictionary of the states built on the host; bridges_valid_rows with rep: only representatives
+    get rows, and the range every env is given holds exactly its own valid candidates (same rasters, descriptors and poses in
+    the same order)."""
+    from bridges_hip.shapes import load_urdf
+    from bridges_hip.vec_env import VecAssemblyGym
+    H = 0.8
+    env = VecAssemblyGym(E, [load_urdf(f"shapes/{shape}.urdf")], [(0.5, 0., i * H + H / 2) for i in range(2)],
+                         [(0.5, 0, 2 * H + H / 2)], max_steps=12, seed=3)
+    shared_some = False
+    for it in range(6):
+        flag = (env.step_flags[:, 1] != 0) | (env.n_blocks == 0)
+        rep = env.state_groups(flag).cpu().numpy()
+        first = {}
+        want = np.array([first.setdefault(k, e) for e, k in enumerate(_state_keys(env, flag))])
+        assert np.array_equal(rep, want), it
+        if it == 0:
+            assert (rep == 0).all()                                        # every env holds the reset state
+        # stale data in dead block slots must not split a group: scribble over them
+        dead = torch.arange(env.K, device=env.device)[None, :] >= env.n_blocks[:, None]
+        env.blk_pose[dead] = float(it) + 0.5
+        env.blk_shape[dead] = 7
+        assert np.array_equal(env.state_groups(flag).cpu().numpy(), want)
+        # the flag byte is part of the state
+        odd = (torch.arange(E, device=env.device) % 2).bool()
+        rep_f = env.state_groups(odd).cpu().numpy()
+        first = {}
+        assert np.array_equal(rep_f, np.array([first.setdefault(k, e) for e, k in enumerate(_state_keys(env, odd))]))
+        idx_all, env_all = env.valid_rows()
+        idx_all, env_all = idx_all.clone(), env_all.clone()
+        lo_all, hi_all = (t.clone() for t in env.valid_segments())
+        rep_d = env.state_groups(flag)
+        idx, row_env = env.valid_rows(rep_d)
+        lo, hi = env.valid_segments()
+        is_rep = torch.tensor(want == np.arange(E), device=env.device)
+        assert idx.numel() == int(env.n_valid[:E][is_rep].sum()) <= idx_all.numel()
+        assert bool(is_rep[row_env].all())                                 # rows belong to representatives only
+        shared_some |= idx.numel() < idx_all.numel()
+        assert torch.equal(hi - lo, env.n_valid[:E])                       # every env: as many rows as it has valid candidates
+        for e in range(E):
+            mine, theirs = idx_all[lo_all[e]:hi_all[e]], idx[lo[e]:hi[e]]
+            assert torch.equal(env.cand_bits[mine], env.cand_bits[theirs])
+            assert torch.equal(env.cand_desc[mine], env.cand_desc[theirs]) and torch.equal(env.cand_pose[mine], env.cand_pose[theirs])
+            assert torch.equal(mine - env.cand_offset[e], theirs - env.cand_offset[int(want[e])])       # same candidate numbers
+        env.select_random()
+        env.step()
+    assert shared_some
+
+
+def test_acting_on_shared_rows_selects_what_acting_on_every_row_selects():
+    """VecDQN with DEDUP_STATES: q of the shared rows equals q of every env's own rows (1e-5; the head's column split
+    depends on the row count), and with the same q values bridges_eps_greedy_select picks the same candidate NUMBER for every
+    env, exploring or greedy, through (seg_lo, seg_hi, rep) as through the prefix sums of all rows."""
+    from bridges_hip import ops
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    args = vars(build_parser().parse_args(["--model", "SuccessorMLP"]))
+    dev = torch.device("cuda")
+    env = make_env(256, seed=17, tower=2, max_steps=10)
+    torch.manual_seed(12)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4), env, 4096, 8, 0.95, 0.01, "mse_q_values", seed=4)
+    E = env.E
+    try:
+        for it in range(5):
+            stable = agent._stable_flags(env)
+            VecDQN.DEDUP_STATES = False
+            env._dqn_rows = None
+            idx_a, env_a, (lo_a, hi_a), rep_a = agent._rows(env, stable)
+            assert rep_a is None
+            idx_a, env_a, lo_a, hi_a = idx_a.clone(), env_a.clone(), lo_a.clone(), hi_a.clone()
+            q_a = agent._policy_q(env, idx_a, env_a, stable).clone()
+            VecDQN.DEDUP_STATES = True
+            env._dqn_rows = None
+            idx_s, env_s, (lo_s, hi_s), rep = agent._rows(env, stable)
+            q_s = agent._policy_q(env, idx_s, env_s, stable)
+            assert idx_s.numel() < idx_a.numel()
+            # row of the shared set that serves every row of the full set
+            src = torch.cat([torch.arange(int(lo_s[e]), int(hi_s[e]), device=dev) for e in range(E)])
+            assert src.numel() == idx_a.numel()
+            assert torch.allclose(q_s[src], q_a, rtol=1e-5, atol=1e-5), float((q_s[src] - q_a).abs().max())
+            step_of = env.n_blocks.long()
+            join_s = ops.bits_dot(env.cand_bits, agent.step_images + 0.25 * it, step_of[env_s], bits_row=idx_s)
+            join_a = ops.bits_dot(env.cand_bits, agent.step_images + 0.25 * it, step_of[env_a], bits_row=idx_a)
+            assert torch.equal(join_s[src], join_a)
+            u = torch.rand(E, device=dev)
+            for eps, greedy in ((0.5, False), (0.0, True)):
+                got_s = ops.eps_greedy_select((lo_s, hi_s), q_s, join_s, u, eps, greedy, idx_s, env.cand_offset[:E], rep=rep)
+                got_a = ops.eps_greedy_select((lo_a, hi_a), q_s[src].contiguous(), join_a, u, eps, greedy, idx_a, env.cand_offset[:E])
+                assert torch.equal(got_s[1], got_a[1])                      # the same candidate number in every env
+                assert torch.equal(got_s[2], got_a[2]) and torch.equal(got_s[3], got_a[3])
+                assert torch.equal(env.cand_bits[got_s[0]], env.cand_bits[got_a[0]])
+            rec, valid = agent.act()
+            agent.ring.push(rec[valid])
+    finally:
+        VecDQN.DEDUP_STATES = True
