@@ -218,15 +218,19 @@ def side_modes(args):
     if os.environ.get("BENCH_TRAIN_MODES", "1") != "0":
         tool = os.path.join(ROOT, "tools", "train_throughput.py")
         n_ls = os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")
+        # every leg starts from 4096 (1024) freshly reset -- i.e. identical -- environments; the warm-up lock-steps let the
+        # episodes (4-5 steps each) drift apart before anything is timed, so that the share of environments that are in the same
+        # state (and share their candidate rows, VecDQN._rows) is the steady-state one; it is reported as rows_fed_fraction
+        n_warm = os.environ.get("BENCH_TRAIN_WARMUP", "20")
         for name, extra in (("train_config3_successor_mlp", ["--envs", "4096", "--tower", "4", "--max_steps", "15", "--model",
                                                              "SuccessorMLP", "--loss", "mse_block_features", "--locksteps", n_ls,
-                                                             "--warmup", "6"]),
+                                                             "--warmup", n_warm]),
                             ("train_config2_convnet", ["--envs", "1024", "--tower", "2", "--max_steps", "10", "--model",
-                                                       "ConvNet", "--loss", "mse_q_values", "--locksteps", n_ls, "--warmup", "6"]),
-                            # BASELINE.json configs[4] on one GPU: a lock-step is ~1.8 s (U-Net over ~10^5 candidate rows)
+                                                       "ConvNet", "--loss", "mse_q_values", "--locksteps", n_ls, "--warmup", n_warm]),
+                            # BASELINE.json configs[4] on one GPU
                             ("train_config5_unet_hexagon", ["--envs", "4096", "--max_steps", "15", "--model", "UNet", "--loss",
                                                             "mse_q_values+mse_block_features", "--shapes", "hexagon",
-                                                            "--bridge_length", "3", "--locksteps", "3", "--warmup", "3"])):
+                                                            "--bridge_length", "3", "--locksteps", n_ls, "--warmup", n_warm])):
             try:
                 sub, err = _child_json([sys.executable, tool, *extra], 900)
                 if sub is None:
@@ -234,7 +238,11 @@ def side_modes(args):
                     continue
                 out[name] = {"value": sub["env_steps_per_s"], "unit": "env-steps/s (acting + replay + 25 optimiser steps per lock-step)",
                              "ms_per_lockstep": sub["ms_per_lockstep"], "ms_act": sub["ms_act"], "ms_targets": sub["ms_targets"],
-                             "ms_per_train_step": sub["ms_per_train_step"], "config": sub["config"]}
+                             "ms_per_train_step": sub["ms_per_train_step"],
+                             # candidate rows of all envs per lock-step, and the share of them a network was actually fed: envs in
+                             # the same state share one set of rows (exact; tools/train_throughput.py --no_dedup feeds all)
+                             "rows_per_lockstep": sub.get("rows_per_lockstep"), "rows_fed_fraction": sub.get("rows_fed_fraction"),
+                             "config": sub["config"]}
             except Exception as exc:
                 out[name] = {"error": repr(exc)[:300]}
     return out

@@ -520,9 +520,9 @@ def test_distinct_row_forward_equals_the_forward_of_every_row(model, loss):
             with torch.no_grad():
                 pol.eval()
                 VecDQN.DEDUP_ROWS = True
-                agent.rows_seen = agent.rows_fed = 0
+                agent.rows_fed = 0
                 q_d, sf_d, sb_d, inv = agent._forward_rows(pol, env, idx, row_env, stable)
-                fed.append((agent.rows_fed, agent.rows_seen))
+                fed.append((agent.rows_fed, idx.numel()))
                 VecDQN.DEDUP_ROWS = False
                 q_a, sf_a, sb_a, none = agent._forward_rows(pol, env, idx, row_env, stable)
             assert none is None and q_a.shape == q_d.shape == (idx.numel(),)

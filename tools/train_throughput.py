@@ -21,7 +21,8 @@ ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--train_steps", type=int, default=25)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--no_fused_adam", action="store_true")
-ap.add_argument("--no_dedup", action="store_true", help="feed every candidate row, also those with identical inputs (A/B)")
+ap.add_argument("--no_dedup", action="store_true",
+                help="A/B: every env its own candidate rows and every row fed, also when envs are in the same state / rows have identical inputs")
 ap.add_argument("--miopen_search", action="store_true", help="let MIOpen benchmark its algorithms (one shape per run)")
 ap.add_argument("--channels_last", action="store_true")
 ap.add_argument("--shapes", default="trapezoid", choices=["trapezoid", "hexagon", "both"])
@@ -46,13 +47,14 @@ env = VecAssemblyGym(a.envs, [load_urdf(f"shapes/{n}.urdf") for n in names], obs
                      device=dev, f32_rasters=VecDQN.acting_needs_f32_rasters(pol), candidate_snapshots=False)
 opt = torch.optim.Adam(pol.parameters(), lr=1e-4, fused=not a.no_fused_adam)
 agent = VecDQN(pol, tgt, opt, env, 200000, a.batch, 0.95, 0.01, a.loss)
+VecDQN.TRACK_ROWS = True
 if a.no_dedup:
-    VecDQN.DEDUP_ROWS = False
+    VecDQN.DEDUP_ROWS = VecDQN.DEDUP_STATES = False
 for i in range(a.warmup):
     agent.lockstep(a.train_steps)
     print("warm-up lock-step", i, "done", flush=True)
 # 1) the loop as run_vectorised runs it: nothing between lock-steps waits for the optimiser steps (deferred loss readback)
-agent.rows_seen = agent.rows_fed = 0
+agent._rows_seen_dev, agent.rows_fed = None, 0
 torch.cuda.synchronize(); s0 = agent.env_steps; t0 = time.perf_counter()
 pending, per_step, tp = None, [], t0
 for _ in range(a.locksteps):
