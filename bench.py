@@ -265,7 +265,7 @@ def train_config4_leg(args, dev, rank, world, backend):
     from robotoddler.training.vec_dqn import VecDQN
     loss = "mse_q_values+mse_block_features"
     E = int(os.environ.get("BENCH_CONFIG4_ENVS", args.envs))
-    n_ls, n_warm, n_train = int(os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")), 6, 25
+    n_ls, n_warm, n_train = int(os.environ.get("BENCH_TRAIN_LOCKSTEPS", "12")), int(os.environ.get("BENCH_TRAIN_WARMUP", "20")), 25
     targs = vars(build_parser().parse_args(["--model", "SuccessorMLP", "--loss_function", loss, "--learning_rate", "1e-4"]))
     torch.manual_seed(0)                                          # identical initial weights on every rank
     pol, tgt = make_nets(targs, dev)

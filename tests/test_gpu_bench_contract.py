@@ -51,7 +51,7 @@ def test_bench_launches_its_own_ranks_for_gpus_2():
     """`python bench.py --gpus 2` with no torchrun environment starts two ranks itself (gloo here: both share the one
     card of the test box; on a node the same path runs RCCL) and rank 0 prints the one line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(BENCH_DIST_BACKEND="gloo", BENCH_TRAIN_LOCKSTEPS="4")
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_TRAIN_LOCKSTEPS="4", BENCH_TRAIN_WARMUP="4")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
                           "--envs", "256"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]

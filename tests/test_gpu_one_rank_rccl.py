@@ -42,7 +42,7 @@ def test_config4_bench_leg_on_a_one_rank_rccl_group():
     training) with backend nccl: init_process_group("nccl", device_id=...), the RCCL all-gather of device float64 rows,
     the all_gather / all_reduce of the hashes and times on device tensors."""
     out = _torchrun([os.path.join(ROOT, "bench.py"), "--config4-leg", "--gpus", "1", "--envs", "512"],
-                    _env(BRIDGES_FORCE_COLLECTIVE="1", BENCH_TRAIN_LOCKSTEPS="4"))
+                    _env(BRIDGES_FORCE_COLLECTIVE="1", BENCH_TRAIN_LOCKSTEPS="4", BENCH_TRAIN_WARMUP="4"))
     assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
