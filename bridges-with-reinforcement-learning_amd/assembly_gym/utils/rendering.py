@@ -12,7 +12,14 @@ def render_blocks_2d_bits(blocks, xlim, ylim, img_size=(64, 64)):
 
 
 def render_blocks_2d(blocks, xlim, ylim, img_size=(512, 512)):
-    """Square images of up to 64 pixels (the training loop's default is 64x64, successor_dqn.py:585); the
-    reference's own default of 512x512 is only used by its plotting helpers and raises NotImplementedError here."""
-    bits = render_blocks_2d_bits(blocks, xlim, ylim, img_size)
-    return ops.crop(ops.bits_to_f32(bits), img_size)[0].cpu().numpy().astype(bool)
+    """bool image of the union of the blocks, any size (rendering.py:105-113; default 512 x 512 like the reference).  Square
+    images of up to 64 pixels -- the training loop's 64x64, successor_dqn.py:585 -- come from the bit rasteriser, every other
+    size from the per-pixel operator (bridges_render_blocks); both apply the same pixel test.  The reference builds its grid
+    with meshgrid(linspace(xlim, img_size[0]), linspace(ylim, img_size[1])) -- an [img_size[1], img_size[0]] array of rows top to
+    bottom -- and then reshapes it to img_size: for a non-square size that is a re-interpretation of the row-major buffer, not
+    a transpose, and it is reproduced as is."""
+    w, h = int(img_size[0]), int(img_size[1])
+    if w == h and 2 <= w <= 64:
+        bits = render_blocks_2d_bits(blocks, xlim, ylim, img_size)
+        return ops.crop(ops.bits_to_f32(bits), img_size)[0].cpu().numpy().astype(bool)
+    return ops.render_blocks(list(blocks), xlim, ylim, (w, h)).cpu().numpy().astype(bool).reshape(tuple(img_size))

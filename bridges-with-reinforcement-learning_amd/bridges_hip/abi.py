@@ -210,6 +210,7 @@ def lib():
         "bridges_contains_points": [vp, i32, vp, i32, vp, vp, vp],
         "bridges_raster": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
         "bridges_raster_sized": [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp],
+        "bridges_render_blocks": [vp, i32, vp, vp, vp, i32, vp, i32, vp, vp],
         "bridges_bits_or": [i32, vp, vp, vp, vp],
         "bridges_action_features": [vp, i32, vp, vp, vp, vp, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp, vp, vp, vp],
         "bridges_bits_to_f32": [i32, vp, vp, vp],
@@ -260,7 +261,7 @@ EXPORTED_SYMBOLS = (
     "bridges_env_candidate_stability",
     "bridges_gate_create", "bridges_gate_destroy", "bridges_env_set_gate",
     "bridges_env_timing_begin", "bridges_env_timing_end",
-    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_action_features", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_bits_dot", "bridges_bits_accumulate", "bridges_head_sigmoid_dot", "bridges_linear_backward_log", "bridges_mlp_mid_rows", "bridges_mlp_mid_supported", "bridges_mlp_mid_forward", "bridges_mlp_mid_backward", "bridges_eps_greedy_select", "bridges_valid_rows", "bridges_env_groups", "bridges_record_state", "bridges_record_result", "bridges_replay_unpack", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
+    "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_render_blocks", "bridges_action_features", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_bits_dot", "bridges_bits_accumulate", "bridges_head_sigmoid_dot", "bridges_linear_backward_log", "bridges_mlp_mid_rows", "bridges_mlp_mid_supported", "bridges_mlp_mid_forward", "bridges_mlp_mid_backward", "bridges_eps_greedy_select", "bridges_valid_rows", "bridges_env_groups", "bridges_record_state", "bridges_record_result", "bridges_replay_unpack", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
     "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_mlp_input_batches", "bridges_successor_loss", "bridges_adam_step", "bridges_linear_backward_adam",
 )

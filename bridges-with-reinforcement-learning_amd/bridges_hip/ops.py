@@ -115,6 +115,31 @@ def raster_bits(blocks, xlim, ylim, img_size=(64, 64)):
     return bits
 
 
+def render_blocks(blocks, xlim, ylim, img_size):
+    """render_blocks_2d at any image size (bridges_render_blocks): the union of the posed blocks on the grid
+    X = linspace(xlim, img_size[0]), Y = linspace(ylim[1], ylim[0], img_size[1]) -> uint8 [img_size[1], img_size[0]] (rows
+    top to bottom) on the device."""
+    L = abi.require_gpu()
+    dev = device()
+    W, H = int(img_size[0]), int(img_size[1])
+    if W < 1 or H < 1:
+        raise ValueError(f"image size {img_size}")
+    n = len(blocks)
+    verts = np.zeros((max(n, 1), 6, 2))
+    ids = np.zeros(max(n, 1), dtype=np.int32)
+    for i, b in enumerate(blocks):
+        verts[i, :len(b.verts_2d)] = b.verts_2d
+        ids[i] = REGISTRY.id_of(b.geometry)
+    tab = REGISTRY.device_table()
+    v = torch.tensor(verts, dtype=torch.float64, device=dev)
+    s = torch.tensor(ids, dtype=torch.int32, device=dev)
+    gx = torch.tensor(np.linspace(xlim[0], xlim[1], W), dtype=torch.float64, device=dev)
+    gy = torch.tensor(np.linspace(ylim[1], ylim[0], H), dtype=torch.float64, device=dev)
+    out = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    abi.check(L.bridges_render_blocks(tab, n, _ptr(v), _ptr(s), _ptr(gx), W, _ptr(gy), H, _ptr(out), _stream()), "bridges_render_blocks")
+    return out
+
+
 def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, reward_map=None, img_size=(64, 64), want_f32=False):
     """bridges_action_features for a list of posed candidate blocks against one state: -> (bits [n,64] int64, img
     [n,64,64] f32 or None, mask [n] bool, lin [n] f32 or None) on the device.  state_bits / obstacle_bits: [64] int64 bit

@@ -395,6 +395,17 @@ static int grid_for_waves(int64_t n_items) {
     return (int)blocks;
 }
 
+int bridges_render_blocks(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                          const double* grid_x, int32_t W, const double* grid_y, int32_t H, uint8_t* out, void* stream) {
+    if (!shapes_dev || n < 0 || W < 1 || H < 1 || !grid_x || !grid_y || !out || (n > 0 && (!verts || !shape_id)))
+        return fail_arg("bridges_render_blocks");
+    const int64_t px = (int64_t)W * H;
+    hipLaunchKernelGGL(k_render_blocks, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, (hipStream_t)stream, shapes_dev, n, verts,
+                       shape_id, grid_x, W, grid_y, H, out);
+    LAUNCH_CHECK("k_render_blocks");
+    return BRIDGES_OK;
+}
+
 int bridges_raster_sized(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
                          const double* grid_x, const double* grid_y, int32_t size, uint64_t* bits, float* img,
                          void* stream) {

@@ -143,6 +143,47 @@ __global__ __launch_bounds__(256) void k_raster_generic(const bridges_shape* sha
     }
 }
 
+// render_blocks_2d (rendering.py:105-113) at ANY image size: the union of n posed outlines on a W x H pixel grid
+// (grid_x [W], grid_y [H]; the reference's default is 512 x 512, which its plotting helpers use).  One thread per pixel, the
+// outlines' face frames staged in LDS 16 blocks at a time; the pixel test is the path's own, operation for operation
+// (oracle/raster.py contains_2d): ((X - c.x) * n.x) + ((Y - c.z) * n.z) <= 0 for every face.  out [H, W] u8 (row 0 = top).
+#define RENDER_TILE 16
+__global__ __launch_bounds__(256) void k_render_blocks(const bridges_shape* shapes, int n, const double* __restrict__ verts,
+                                                       const int32_t* __restrict__ shape_id, const double* __restrict__ gx, int W,
+                                                       const double* __restrict__ gy, int H, uint8_t* __restrict__ out) {
+    __shared__ double fr[RENDER_TILE][MAXV][4];
+    __shared__ int nv_s[RENDER_TILE];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < (int64_t)W * H;
+    const int r = live ? (int)(p / W) : 0, q = live ? (int)(p % W) : 0;
+    const double X = gx[q], Y = gy[r];
+    bool any = false;
+    for (int b0 = 0; b0 < n; b0 += RENDER_TILE) {
+        __syncthreads();
+        const int nt = n - b0 < RENDER_TILE ? n - b0 : RENDER_TILE;
+        for (int i = threadIdx.x; i < nt * MAXV; i += blockDim.x) {
+            const int b = i / MAXV, f = i % MAXV;
+            const bridges_shape& sh = shapes[shape_id[b0 + b]];
+            if (f == 0) nv_s[b] = sh.nv;
+            if (f < sh.nv) {
+                const double* v = verts + (size_t)(b0 + b) * MAXV * 2;
+                const Frame2 e = edge_frame(v[2 * sh.fa[f]], v[2 * sh.fa[f] + 1], v[2 * sh.fb[f]], v[2 * sh.fb[f] + 1]);
+                fr[b][f][0] = e.cx; fr[b][f][1] = e.cz; fr[b][f][2] = e.nx; fr[b][f][3] = e.nz;
+            }
+        }
+        __syncthreads();
+        for (int b = 0; b < nt && !any; ++b) {
+            bool inside = true;
+            for (int f = 0; f < nv_s[b]; ++f) {
+                const double d = ((X - fr[b][f][0]) * fr[b][f][2]) + ((Y - fr[b][f][1]) * fr[b][f][3]);
+                inside = inside && d <= 0.0;
+            }
+            any = inside;
+        }
+    }
+    if (live) out[p] = any ? 1 : 0;
+}
+
 // get_action_features + filter_actions + the linear reward for n posed candidate outlines against ONE state (the
 // stand-alone form of what k_raster does inside the lock-step; robotoddler/training/successor_dqn.py:84-94, 397-401,
 // robotoddler/utils/actions.py:71-82, gym_env.py:304-323): raster of every outline, mask[i] = all vertices inside

@@ -234,6 +234,11 @@ int bridges_contains_points(const bridges_shape* shapes_dev, int32_t shape_id, c
  * -> bits [n,64] and/or f32 [n,64,64] (either may be NULL). */
 int bridges_raster(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
                    const double* grid_x, const double* grid_y, uint64_t* bits, float* img, void* stream);
+/* render_blocks_2d (rendering.py:105-113) at any image size (the reference's default is 512 x 512): the UNION of n posed
+ * outlines on the pixel grid grid_x [W] x grid_y [H] (DEVICE; row 0 = grid_y[0]) -> out [H, W] u8 {0, 1}.  Same pixel test,
+ * operation for operation, as the 64-wide rasterisers. */
+int bridges_render_blocks(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,
+                          const double* grid_x, int32_t W, const double* grid_y, int32_t H, uint8_t* out, void* stream);
 /* The same for S x S images, 2 <= S <= 64 (render_blocks_2d's img_size argument, rendering.py:105): grid_x/grid_y
  * hold S values; the outputs keep the 64-word / 64x64 layout, the image is the top-left S x S corner, the rest 0. */
 int bridges_raster_sized(const bridges_shape* shapes_dev, int32_t n, const double* verts, const int32_t* shape_id,

@@ -407,3 +407,35 @@ def test_candidate_block_cache_does_not_outlive_a_reset():
     assert b3 is not b1 and b3.shape is trap and np.array_equal(b3.verts_2d, b1.verts_2d)
     env.step(a)
     assert env.create_blocks([a])[0] is not b3                  # the assembly changed: a new candidate set
+
+
+def test_render_blocks_2d_at_the_reference_default_and_at_non_square_sizes():
+    """render_blocks_2d's default img_size is (512, 512) (rendering.py:105); any size goes through bridges_render_blocks,
+    pixel for pixel the oracle's image.  A non-square size comes back the way the reference returns it: the [img_size[1],
+    img_size[0]] grid of rows re-interpreted (reshape, not transpose) as img_size."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import Action, AssemblyGym, bridge_setup, sparse_reward
+    from assembly_gym.utils.rendering import render_blocks_2d
+    from oracle import raster as o_raster
+    from oracle.env import OracleGym
+    from oracle.env import bridge_setup as o_bridge_setup
+    env = AssemblyGym(**bridge_setup(num_stories=2, hexagon=True), reward_fct=sparse_reward, restrict_2d=True, max_steps=10,
+                      assembly_env=AssemblyEnv(render=False))
+    og = OracleGym(**o_bridge_setup(num_stories=2, hexagon=True), max_steps=10)
+    acts = [(-1, 0, 0, 3, -1.3333333333333335, 0.0), (0, 1, 1, 0, 0.0, 0.0), (-1, 0, 1, 0, -2.0, 0.0)]
+    assert render_blocks_2d([], (-3, 7), (0, 10)).shape == (512, 512) and not render_blocks_2d([], (-3, 7), (0, 10)).any()
+    for a in acts:
+        obs = env.step(Action(*a))[0]
+        og.step(a)
+        img = render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10))                        # the reference's default size
+        want = o_raster.render_blocks_2d(og.blocks, (-3, 7), (0, 10), (512, 512))
+        assert img.dtype == bool and img.shape == (512, 512) and np.array_equal(img, want) and want.any()
+        for size in ((128, 128), (65, 65), (200, 120), (96, 160)):
+            got = render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10), img_size=size)
+            ref = o_raster.render_blocks_2d(og.blocks, (-3, 7), (0, 10), size)                       # [size[1], size[0]]
+            assert ref.shape == (size[1], size[0]) and got.shape == size
+            assert np.array_equal(got, ref.reshape(size))
+        # 64 x 64 through the bit rasteriser and through the per-pixel operator: the same image
+        from bridges_hip import ops
+        assert np.array_equal(ops.render_blocks(obs["blocks"], (-3, 7), (0, 10), (64, 64)).cpu().numpy().astype(bool),
+                              render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10), img_size=(64, 64)))

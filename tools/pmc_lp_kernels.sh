@@ -18,9 +18,14 @@ base, tag = sys.argv[1], sys.argv[2]
 out = {}
 for f in glob.glob(f"{base}/pmc_{tag}_lp_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        for key in ("k_step", "k_candidate_stability<1152", "k_candidate_stability<4096", "k_enumerate", "k_raster"):
-            if key in r["Kernel_Name"]:
-                out.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"]
+        # the first pass is whatever instantiation is not the queue pass's <4096, ...> (its LDS tableau size is a tunable)
+        key = next((k for k in ("k_step", "k_enumerate", "k_raster") if k in name), None)
+        if "k_candidate_stability<" in name:
+            key = "k_candidate_stability<4096 (queue pass)" if "k_candidate_stability<4096" in name else \
+                  "k_candidate_stability<%s (first pass)" % name.split("k_candidate_stability<")[1].split(",")[0]
+        if key:
+            out.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 res = {}
 for k, d in out.items():
     res[k] = {c: {"per_launch_mean": sum(v) / len(v), "launches": len(v)} for c, v in d.items()}
