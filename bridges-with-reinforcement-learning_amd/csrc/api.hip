@@ -233,6 +233,12 @@ int bridges_env_timing_end(bridges_env* env, double* raster_ms_total, int32_t* n
     return BRIDGES_OK;
 }
 
+// Unused dynamic LDS per rasteriser workgroup (4 waves): caps how many of them a CU holds (160 KB of LDS) and so leaves
+// registers / wave slots to the latency-bound task kernels of the other env groups.  0 = no cap: 8 workgroups per CU fill every
+// wave slot (tools/raster_occupancy.sh measures the alternatives).
+#ifndef RASTER_DYN_LDS
+#define RASTER_DYN_LDS 0
+#endif
 static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     const DevCtx& c = env->ctx;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(SCAN_THREADS), 0, s, c, after_step);
@@ -250,8 +256,8 @@ static int refresh(bridges_env* env, hipStream_t s, int after_step) {
     const bool timed = env->ev_cap > 0 && env->ev_used < env->ev_cap;
     if (env->gate && env->gate->last) HIP_TRY(hipStreamWaitEvent(s, env->gate->last, 0));
     if (timed) HIP_TRY(hipEventRecord(env->ev_start[env->ev_used], s));
-    if (env->max_faces <= 4) hipLaunchKernelGGL(k_raster<4>, dim3((unsigned)rblocks), dim3(256), 0, s, c);
-    else hipLaunchKernelGGL(k_raster<MAXV>, dim3((unsigned)rblocks), dim3(256), 0, s, c);
+    if (env->max_faces <= 4) hipLaunchKernelGGL(k_raster<4>, dim3((unsigned)rblocks), dim3(256), RASTER_DYN_LDS, s, c);
+    else hipLaunchKernelGGL(k_raster<MAXV>, dim3((unsigned)rblocks), dim3(256), RASTER_DYN_LDS, s, c);
     LAUNCH_CHECK("k_raster");
     if (timed) { HIP_TRY(hipEventRecord(env->ev_stop[env->ev_used], s)); env->ev_used++; }
     if (env->gate) {
