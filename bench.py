@@ -37,7 +37,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_FILE = os.path.join("profiles", "r03_pmc_k_raster.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_k_raster.json")
 
 
 def algorithmic_bytes(sum_cand, sum_blocks, n_envsteps_units, V=4, f32_rasters=True):

@@ -17,7 +17,7 @@ f, nf = per_launch(sys.argv[2], "FETCH_SIZE")
 bench = json.load(open(sys.argv[1] + ".json"))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 print(json.dumps({
-    "kernel": "k_raster", "round": 3,
+    "kernel": "k_raster", "round": 4,
     "config": "bench.py --steps 20 --warmup 5 --groups 1 (4096 envs, tower_height=4), separate --pmc passes with --kernel-trace only",
     "launches_averaged": [nw, nf],
     "WRITE_SIZE_bytes_per_launch": w,
