@@ -229,6 +229,17 @@ class FusedSuccessorStep:
                 else:
                     st["step"] = float(self.adam_step)
 
+    def check_hyperparameters(self):
+        """lr, betas and eps were read off the optimiser when it was adopted and are launch arguments since (a captured graph
+        holds them as constants): a later change of the param group would be ignored silently, so it is refused instead."""
+        if self.fused_adam:
+            g = self.optimizer.param_groups[0]
+            now = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+            if now != (self.lr, self.beta1, self.beta2, self.eps):
+                raise RuntimeError(f"the optimiser's hyper-parameters changed after the fused step adopted them "
+                                   f"({(self.lr, self.beta1, self.beta2, self.eps)} -> {now}): rebuild the step (VecDQN re-captures "
+                                   "its graph when _graph_state is reset)")
+
     def launch(self, counter, block_all, action_all, binary_all, reward, obstacle, q_target_all, sf_target_all, losses):
         L, rows, px, nf, B = self.L, self.rows, self.px, self.nf, self.batch
         st = _stream()

@@ -51,6 +51,87 @@ class ShapeRegistry:
 REGISTRY = ShapeRegistry()
 
 
+class _Stager:
+    """Small host arrays -> device tensors through ONE pinned staging buffer and ONE asynchronous copy per call.
+
+    ``torch.tensor(array, device=...)`` of pageable memory is a blocking copy: the host waits for everything queued on the
+    stream before it.  An operator of the single-environment API takes three to seven such arrays (stability: poses,
+    vertices, shape ids, count, frozen mask), i.e. as many host waits per call -- 30 of the ~50 waits of one env-step of the
+    reference-style loop.  Here the arrays are packed (16-byte aligned) into one of a ring of pinned buffers, copied with one
+    non-blocking transfer, and handed out as typed views of one device buffer; a slot is reused only after the event
+    recorded behind its copy has passed."""
+    SLOTS, MIN_BYTES = 16, 1 << 16
+
+    def __init__(self):
+        self.slots, self.turn = [], 0
+
+    def upload(self, dev, *arrays):
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        offs, total = [], 0
+        for a in arrays:
+            offs.append(total)
+            total += -(-max(a.nbytes, 1) // 16) * 16
+        if len(self.slots) < self.SLOTS:
+            self.slots.append([torch.empty(max(total, self.MIN_BYTES), dtype=torch.uint8).pin_memory(), None])
+            slot = self.slots[-1]
+        else:
+            slot = self.slots[self.turn]
+            self.turn = (self.turn + 1) % self.SLOTS
+            if slot[1] is not None:
+                slot[1].synchronize()                       # (passed long ago unless 16 uploads are in flight)
+            if slot[0].numel() < total:
+                slot[0] = torch.empty(total, dtype=torch.uint8).pin_memory()
+        host = slot[0].numpy()
+        for a, off in zip(arrays, offs):
+            host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        d = torch.empty(total, dtype=torch.uint8, device=dev)
+        d.copy_(slot[0][:total], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        out = []
+        for a, off in zip(arrays, offs):
+            t = d[off:off + a.nbytes].view(getattr(torch, a.dtype.name))
+            out.append(t.reshape(a.shape))
+        return out
+
+
+_STAGER = _Stager()
+
+
+def upload(dev, *arrays):
+    """numpy arrays (any dtypes) -> device tensors of the same shapes, one pinned staging copy for all of them."""
+    return _STAGER.upload(dev, *arrays)
+
+
+def download(*tensors):
+    """Device tensors -> numpy arrays with ONE device-to-host copy (one host wait): they are packed into a float64 buffer on
+    the device first (integer and byte tensors are exact in float64 here: counts, flags, small ids)."""
+    flat = torch.cat([t.reshape(-1).to(torch.float64) for t in tensors])
+    host = flat.cpu().numpy()
+    out, off = [], 0
+    for t in tensors:
+        n = t.numel()
+        a = host[off:off + n].reshape(tuple(t.shape))
+        off += n
+        out.append(a if t.dtype == torch.float64 else a.astype(np.dtype(str(t.dtype).replace("torch.", ""))))
+    return out
+
+
+_grids = {}
+
+
+def pixel_grid(dev, xlim, ylim, S):
+    """(grid_x, grid_y) of render_blocks_2d on the device, cached per (device, limits, size)."""
+    key = (str(dev), float(xlim[0]), float(xlim[1]), float(ylim[0]), float(ylim[1]), int(S))
+    g = _grids.get(key)
+    if g is None:
+        if len(_grids) > 64:
+            _grids.clear()
+        g = _grids[key] = tuple(upload(dev, np.linspace(xlim[0], xlim[1], S), np.linspace(ylim[1], ylim[0], S)))
+    return g
+
+
 def device():
     abi.require_gpu()
     return torch.device("cuda", torch.cuda.current_device())
@@ -63,16 +144,14 @@ def place(frame1, geom, face, ox, oy):
     dev = device()
     sid = REGISTRY.id_of(geom)
     tab = REGISTRY.device_table()
-    f1 = torch.tensor([list(frame1)], dtype=torch.float64, device=dev)
-    sh = torch.tensor([sid], dtype=torch.int32, device=dev)
-    fc = torch.tensor([int(face)], dtype=torch.int32, device=dev)
-    oxs = torch.tensor([float(ox)], dtype=torch.float64, device=dev)
-    oys = torch.tensor([float(oy)], dtype=torch.float64, device=dev)
+    f1, sh, fc, oxs, oys = upload(dev, np.array([list(frame1)], dtype=np.float64), np.array([sid], dtype=np.int32),
+                                  np.array([int(face)], dtype=np.int32), np.array([float(ox)]), np.array([float(oy)]))
     pose = torch.empty((1, 4), dtype=torch.float64, device=dev)
     verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
     abi.check(L.bridges_place(tab, 1, _ptr(f1), _ptr(sh), _ptr(fc), _ptr(oxs), _ptr(oys), _ptr(pose), _ptr(verts),
                               _stream()), "bridges_place")
-    return pose[0].cpu().numpy(), verts[0, :len(geom.verts)].cpu().numpy()
+    pose_h, verts_h = download(pose, verts)
+    return pose_h[0], verts_h[0, :len(geom.verts)]
 
 
 def image_size(img_size):
@@ -105,10 +184,8 @@ def raster_bits(blocks, xlim, ylim, img_size=(64, 64)):
         verts[i, :len(b.verts_2d)] = b.verts_2d
         ids[i] = REGISTRY.id_of(b.geometry)
     tab = REGISTRY.device_table()
-    v = torch.tensor(verts, dtype=torch.float64, device=dev)
-    s = torch.tensor(ids, dtype=torch.int32, device=dev)
-    gx = torch.tensor(np.linspace(xlim[0], xlim[1], S), dtype=torch.float64, device=dev)
-    gy = torch.tensor(np.linspace(ylim[1], ylim[0], S), dtype=torch.float64, device=dev)
+    v, s = upload(dev, verts, ids)
+    gx, gy = pixel_grid(dev, xlim, ylim, S)
     bits = torch.empty((n, 64), dtype=torch.int64, device=dev)
     abi.check(L.bridges_raster_sized(tab, n, _ptr(v), _ptr(s), _ptr(gx), _ptr(gy), S, _ptr(bits), None, _stream()),
               "bridges_raster")
@@ -131,19 +208,26 @@ def render_blocks(blocks, xlim, ylim, img_size):
         verts[i, :len(b.verts_2d)] = b.verts_2d
         ids[i] = REGISTRY.id_of(b.geometry)
     tab = REGISTRY.device_table()
-    v = torch.tensor(verts, dtype=torch.float64, device=dev)
-    s = torch.tensor(ids, dtype=torch.int32, device=dev)
-    gx = torch.tensor(np.linspace(xlim[0], xlim[1], W), dtype=torch.float64, device=dev)
-    gy = torch.tensor(np.linspace(ylim[1], ylim[0], H), dtype=torch.float64, device=dev)
+    v, s, gx, gy = upload(dev, verts, ids, np.linspace(xlim[0], xlim[1], W), np.linspace(ylim[1], ylim[0], H))
     out = torch.empty((H, W), dtype=torch.uint8, device=dev)
     abi.check(L.bridges_render_blocks(tab, n, _ptr(v), _ptr(s), _ptr(gx), W, _ptr(gy), H, _ptr(out), _stream()), "bridges_render_blocks")
     return out
 
 
-def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, reward_map=None, img_size=(64, 64), want_f32=False):
+def reward_prefix(reward_map):
+    """float64 row prefix sums [64, 65] of a reward map ([64,64] f32 tensor), accumulated left to right on the host: what
+    bridges_action_features takes the linear reward of a candidate from (build it once per task)."""
+    pre = np.zeros((64, 65), dtype=np.float64)
+    pre[:, 1:] = np.cumsum(reward_map.detach().cpu().numpy().astype(np.float64).reshape(64, 64), axis=1)
+    return upload(reward_map.device, pre)[0]
+
+
+def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, reward_map=None, img_size=(64, 64), want_f32=False,
+                    prefix=None):
     """bridges_action_features for a list of posed candidate blocks against one state: -> (bits [n,64] int64, img
     [n,64,64] f32 or None, mask [n] bool, lin [n] f32 or None) on the device.  state_bits / obstacle_bits: [64] int64 bit
-    rasters (None = empty); reward_map: [64,64] f32 tensor (None: no linear reward)."""
+    rasters (None = empty); reward_map: [64,64] f32 tensor (None: no linear reward) or ``prefix`` = reward_prefix(map),
+    built once."""
     S = image_size(img_size)
     L = abi.require_gpu()
     dev = device()
@@ -151,7 +235,7 @@ def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, rew
     bits = torch.empty((n, 64), dtype=torch.int64, device=dev)
     img = torch.empty((n, 64, 64), dtype=torch.float32, device=dev) if want_f32 else None
     mask = torch.zeros(n, dtype=torch.uint8, device=dev)
-    lin = torch.zeros(n, dtype=torch.float32, device=dev) if reward_map is not None else None
+    lin = torch.zeros(n, dtype=torch.float32, device=dev) if (reward_map is not None or prefix is not None) else None
     if n == 0:
         return bits, img, mask.bool(), lin
     verts = np.zeros((n, 6, 2))
@@ -160,15 +244,10 @@ def action_features(blocks, xlim, ylim, state_bits=None, obstacle_bits=None, rew
         verts[i, :len(b.verts_2d)] = b.verts_2d
         ids[i] = REGISTRY.id_of(b.geometry)
     tab = REGISTRY.device_table()
-    v = torch.tensor(verts, dtype=torch.float64, device=dev)
-    s_ = torch.tensor(ids, dtype=torch.int32, device=dev)
-    gx = torch.tensor(np.linspace(xlim[0], xlim[1], S), dtype=torch.float64, device=dev)
-    gy = torch.tensor(np.linspace(ylim[1], ylim[0], S), dtype=torch.float64, device=dev)
-    prefix = None
-    if reward_map is not None:
-        pre = np.zeros((64, 65), dtype=np.float64)
-        pre[:, 1:] = np.cumsum(reward_map.detach().cpu().numpy().astype(np.float64).reshape(64, 64), axis=1)
-        prefix = torch.from_numpy(pre).to(dev)
+    v, s_ = upload(dev, verts, ids)
+    gx, gy = pixel_grid(dev, xlim, ylim, S)
+    if prefix is None and reward_map is not None:
+        prefix = reward_prefix(reward_map)
     abi.check(L.bridges_action_features(tab, n, _ptr(v), _ptr(s_), _ptr(gx), _ptr(gy), S, float(xlim[0]), float(xlim[1]),
                                         float(ylim[0]), float(ylim[1]), _ptr(state_bits), _ptr(obstacle_bits), _ptr(prefix),
                                         _ptr(bits), _ptr(img), _ptr(mask), _ptr(lin), _stream()), "bridges_action_features")
@@ -181,7 +260,7 @@ def bits_or(bits):
     out = torch.zeros(64, dtype=torch.int64, device=dev)
     if bits.shape[0] == 0:
         return out
-    off = torch.tensor([0, bits.shape[0]], dtype=torch.int32, device=dev)
+    off, = upload(dev, np.array([0, bits.shape[0]], dtype=np.int32))
     abi.check(L.bridges_bits_or(1, _ptr(off), _ptr(bits), _ptr(out), _stream()), "bridges_bits_or")
     return out
 
@@ -359,14 +438,12 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension
         if i in fixed:
             mask |= 1 << i
     tab = REGISTRY.device_table()
-    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)
     ws_stride = abi.lp_ws_stride(K)
     ws = torch.empty((1, ws_stride), dtype=torch.float64, device=dev)
     stable = torch.zeros(1, dtype=torch.uint8, device=dev)
     info = torch.zeros((1, 8), dtype=torch.float64, device=dev)
-    # keep every argument tensor alive until the call returned (a temporary's storage would be recycled at once)
-    a_pose, a_verts, a_ids = t(pose, torch.float64), t(verts, torch.float64), t(ids, torch.int32)
-    a_n, a_mask = t([n], torch.int32), t([mask], torch.int32)
+    # one staging copy for all five inputs; the tensors stay alive until the call returned
+    a_pose, a_verts, a_ids, a_n, a_mask = upload(dev, pose, verts, ids, np.array([n], dtype=np.int32), np.array([mask], dtype=np.int32))
     forces = None
     if tension_tol is None:
         abi.check(L.bridges_stability(tab, 1, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
@@ -378,13 +455,16 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension
                                               float(mu), float(density), float(floor_half_width), float(floor_depth),
                                               float(tension_tol), _ptr(stable), _ptr(info), _ptr(forces), _ptr(ws), ws_stride,
                                               _stream()), "bridges_stability_penalty")
-    inf = info[0].cpu().numpy()
+    if forces is None:
+        inf, st = download(info[0], stable)                   # verdict and diagnostics in ONE copy back
+    else:
+        inf, st, fo = download(info[0], stable, forces[0])
     if inf[3] != 0:
         return None, dict(error="lp", objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
     out = dict(objective=float(inf[0]), n_interfaces=int(inf[1]), pivots=int(inf[2]))
     if forces is not None:
-        out["forces"] = forces[0, :int(inf[1])].cpu().numpy()
-    return bool(stable.item()), out
+        out["forces"] = fo[:int(inf[1])]
+    return bool(st[0]), out
 
 
 def create_blocks(target_blocks, target_faces, geoms, faces, oxs, oys):
@@ -406,17 +486,15 @@ def create_blocks(target_blocks, target_faces, geoms, faces, oxs, oys):
         if t is not None:
             tv[i, :len(t.verts_2d)] = t.verts_2d
             tf[i] = int(target_faces[i])
-    t_ = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
     pose = torch.empty((n, 4), dtype=torch.float64, device=dev)
     verts = torch.empty((n, 6, 2), dtype=torch.float64, device=dev)
     frames = torch.empty((n, 6, 6), dtype=torch.float64, device=dev)
-    sh, a_tv, a_ts, a_tf = t_(sid, torch.int32), t_(tv, torch.float64), t_(tsid, torch.int32), t_(tf, torch.int32)
-    a_face = t_(np.asarray(faces, dtype=np.int32), torch.int32)
-    a_ox, a_oy = t_(np.asarray(oxs, dtype=np.float64), torch.float64), t_(np.asarray(oys, dtype=np.float64), torch.float64)
+    sh, a_tv, a_ts, a_tf, a_face, a_ox, a_oy = upload(dev, sid, tv, tsid, tf, np.asarray(faces, dtype=np.int32),
+                                                      np.asarray(oxs, dtype=np.float64), np.asarray(oys, dtype=np.float64))
     abi.check(L.bridges_create_block(tab, n, _ptr(a_tv), _ptr(a_ts), _ptr(a_tf), _ptr(sh), _ptr(a_face), _ptr(a_ox),
                                      _ptr(a_oy), _ptr(pose), _ptr(verts), None, _stream()), "bridges_create_block")
     abi.check(L.bridges_face_frames(tab, n, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
-    pose_h, verts_h, frames_h = pose.cpu().numpy(), verts.cpu().numpy(), frames.cpu().numpy()
+    pose_h, verts_h, frames_h = download(pose, verts, frames)
     return [(pose_h[i], verts_h[i, :len(g.verts)], frames_h[i, :len(g.verts)]) for i, g in enumerate(geoms)]
 
 
@@ -432,14 +510,14 @@ def pose_block(geom, pose4):
     dev = device()
     sid = REGISTRY.id_of(geom)
     tab = REGISTRY.device_table()
-    sh = torch.tensor([sid], dtype=torch.int32, device=dev)
-    p = torch.tensor([list(pose4)], dtype=torch.float64, device=dev)
+    sh, p = upload(dev, np.array([sid], dtype=np.int32), np.array([list(pose4)], dtype=np.float64))
     verts = torch.empty((1, 6, 2), dtype=torch.float64, device=dev)
     frames = torch.empty((1, 6, 6), dtype=torch.float64, device=dev)
     abi.check(L.bridges_pose_block(tab, 1, _ptr(sh), _ptr(p), _ptr(verts), _stream()), "bridges_pose_block")
     abi.check(L.bridges_face_frames(tab, 1, _ptr(sh), _ptr(verts), _ptr(frames), _stream()), "bridges_face_frames")
     nv = len(geom.verts)
-    return verts[0, :nv].cpu().numpy(), frames[0, :nv].cpu().numpy()
+    verts_h, frames_h = download(verts, frames)
+    return verts_h[0, :nv], frames_h[0, :nv]
 
 
 def contains_points(block, points):
@@ -452,8 +530,7 @@ def contains_points(block, points):
     tab = REGISTRY.device_table()
     v = np.zeros((6, 2))
     v[:len(block.verts_2d)] = block.verts_2d
-    tv = torch.tensor(v, dtype=torch.float64, device=dev)
-    tp = torch.tensor(pts, dtype=torch.float64, device=dev)
+    tv, tp = upload(dev, v, pts)
     out = torch.zeros(n, dtype=torch.uint8, device=dev)
     abi.check(L.bridges_contains_points(tab, sid, _ptr(tv), n, _ptr(tp), _ptr(out), _stream()), "bridges_contains_points")
     return out.cpu().numpy().astype(bool)

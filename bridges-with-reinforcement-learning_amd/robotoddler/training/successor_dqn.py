@@ -49,11 +49,19 @@ def _image(bits, img_size):
 
 
 # ---- feature extraction (successor_dqn.py:47-94) ---------------------------------------------------------------
-def get_state_features(observation, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
+def _state_features(observation, xlim, ylim, img_size, device):
+    """get_state_features plus the state's bit raster (what the candidate filter tests overlaps against)."""
     binary = [observation['stable'], observation['collision'], observation['collision_block'],
               observation['collision_obstacle'], observation['collision_floor'], observation['collision_boundary']]
-    image = _image(render_blocks_2d_bits(observation['blocks'], xlim, ylim, img_size), img_size)      # [1,S,S] f32
-    return image.to(device), torch.tensor(binary, dtype=torch.float32, device=image.device).to(device)
+    bits = render_blocks_2d_bits(observation['blocks'], xlim, ylim, img_size)
+    image = _image(bits, img_size)                                                                     # [1,S,S] f32
+    binary_t, = ops.upload(image.device, np.asarray(binary, dtype=np.float32))                         # (no blocking copy)
+    return image.to(device), binary_t.to(device), bits
+
+
+def get_state_features(observation, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
+    image, binary, _bits = _state_features(observation, xlim, ylim, img_size, device)
+    return image, binary
 
 
 def get_task_features(obs, xlim=(0, 1), ylim=(0, 1), img_size=(64, 64), device=None):
@@ -101,6 +109,80 @@ class EpsilonGreedy:
 
 
 # ---- training (successor_dqn.py:157-288) ------------------------------------------------------------------------
+def _task_key(*tensors):
+    """Fingerprint of an episode's task features (reward map, obstacle raster): transitions whose tensors carry the same key
+    share them VALUE for value, which is what lets a batch go through the hand-written optimiser step (one reward / obstacle
+    vector per batch).  One host read per episode."""
+    import hashlib
+    h = hashlib.sha1()
+    for t in tensors:
+        h.update(t.detach().float().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _tagged(t, key):
+    t._task_key = key
+    return t
+
+
+class _FusedTrainer:
+    """train_policy_net's optimiser steps for a SuccessorMLP on the hand-written step of the vectorised loop
+    (bridges_hip/mlp_ops.py FusedSuccessorStep: forward, both MSE losses, backward and Adam as ~11 launches on the f32
+    matrix cores instead of ~60 library / element-wise ones, no host wait per step).  Same losses as the autograd form:
+    the reference's q target is the [B, B] broadcast  lin_reward[j] + gamma q'[i]  (successor_dqn.py:222 with :435), whose
+    mean-squared error against q[i] is  mean_i (q[i] - (mean(lin) + gamma q'[i]))^2 + var(lin)  -- the same gradient as the
+    element-wise target mean(lin) + gamma q'[i]; the constant var(lin) is added to the logged loss."""
+
+    def __init__(self, policy_net, optimizer, batch_size, loss_parts):
+        from bridges_hip.mlp_ops import FusedSuccessorStep
+        self.key = (id(optimizer), batch_size, tuple(loss_parts))
+        self.use_q, self.use_sf = 'mse_q_values' in loss_parts, 'mse_block_features' in loss_parts
+        self.step = FusedSuccessorStep(policy_net, batch_size, self.use_q, self.use_sf, optimizer=optimizer)
+        if not self.step.fused_adam:
+            raise ValueError("the optimiser is not a plain Adam over the net's flattened parameters")
+        dev = self.step.flat.device
+        self.counter = torch.zeros((), dtype=torch.int64, device=dev)
+        self.loss1 = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def applies(policy_net, optimizer, loss_parts, scheduler, transitions, batch):
+        if scheduler is not None or not isinstance(policy_net, SuccessorMLP) or getattr(policy_net, "_flat_params", None) is None:
+            return False
+        if not set(loss_parts) <= {'mse_q_values', 'mse_block_features'} or type(optimizer) is not torch.optim.Adam:
+            return False
+        if not transitions or not batch.block_features.is_cuda or batch.block_features.dtype != torch.float32:
+            return False
+        keys = {getattr(t.reward_features, "_task_key", None) for t in transitions}
+        return len(keys) == 1 and None not in keys and all(getattr(t.obstacle_features, "_task_key", None) in keys for t in transitions)
+
+    def run(self, batch, q_sel, sf_target, gamma):
+        B = batch.block_features.shape[0]
+        st = self.step
+        st.check_hyperparameters()
+        lin = batch.lin_reward.reshape(-1).float()
+        extra = None
+        q_target = None
+        if self.use_q:
+            m = lin.mean()
+            q_target = (m + gamma * q_sel).contiguous()
+            extra = ((lin - m) ** 2).mean()
+        self.counter.zero_()
+        px = st.px
+        st.launch(self.counter, batch.block_features.reshape(B, px).contiguous(), batch.action_features.reshape(B, px).contiguous(),
+                  batch.binary_features.contiguous(), batch.reward_features[0].reshape(px).contiguous(),
+                  batch.obstacle_features[0].reshape(px).contiguous(), q_target,
+                  sf_target.reshape(B, px).contiguous() if self.use_sf else None, self.loss1)
+        return self.loss1[0] + extra if extra is not None else self.loss1[0].clone()
+
+
+def sync_fused_optimizer(policy_net):
+    """Hand Adam's step count back to the torch optimiser (its moments already are the fused step's buffers): call before
+    optimizer.state_dict() / optimizer.step() when train_policy_net may have run on the hand-written step."""
+    tr = getattr(policy_net, "_fused_trainer", None)
+    if tr is not None:
+        tr.step.export_state()
+
+
 def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, loss_fct='mse_q_values', scheduler=None,
                      n_steps=10, batch_size=16, verbose=False, device='cuda'):
     if len(replay_buffer) < batch_size:
@@ -112,6 +194,33 @@ def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, lo
     losses = []
     for _ in range(n_steps):
         transitions, batch = replay_buffer.sample(batch_size=batch_size, stack_tensors=True, device=device)
+        fused = _FusedTrainer.applies(policy_net, optimizer, loss_fct, scheduler, transitions, batch)
+        if fused:
+            tr = getattr(policy_net, "_fused_trainer", None)
+            if tr is None or tr.key != (id(optimizer), batch.block_features.shape[0], tuple(loss_fct)):
+                try:
+                    sync_fused_optimizer(policy_net)
+                    tr = policy_net._fused_trainer = _FusedTrainer(policy_net, optimizer, batch.block_features.shape[0], loss_fct)
+                except ValueError:
+                    fused = False
+        if not fused:
+            sync_fused_optimizer(policy_net)                  # optimizer.step() takes over: it needs the true step count
+        if fused:
+            with torch.no_grad():
+                next_q, next_sf, _next_bin = target_net(
+                    batch.next_block_features, batch.next_binary_features, batch.next_actions_features,
+                    batch.next_reward_features, batch.next_obstacle_features)
+                num_actions = [max(1, len(a)) for a in batch.next_available_actions]
+                seg, done = ops.upload(next_q.device, np.cumsum([0] + num_actions).astype(np.int32), np.asarray(batch.done, dtype=np.bool_))
+                zeros = torch.zeros(len(num_actions), dtype=torch.float32, device=next_q.device)
+                nq = next_q.contiguous().float()
+                q_sel, _, _ = dqn_ops.td_target(seg, nq, zeros, done, 1.0)
+                sf_target = None
+                if 'mse_block_features' in loss_fct:
+                    _, sf_target, _ = dqn_ops.td_target(seg, nq, zeros, done, gamma, next_sf=next_sf[:, 0],
+                                                        action_raster=batch.action_features.squeeze(1))
+            losses.append(tr.run(batch, q_sel, sf_target, gamma))
+            continue
         q_values, succ_block_features, succ_binary_features = policy_net(
             batch.block_features, batch.binary_features, batch.action_features, batch.reward_features,
             batch.obstacle_features)
@@ -146,8 +255,8 @@ def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, lo
         optimizer.step()
         if scheduler is not None:
             scheduler.step()
-        losses.append(loss.item())
-    return losses
+        losses.append(loss.detach())
+    return torch.stack([l.reshape(()) for l in losses]).tolist() if losses else []      # ONE host read for all steps
 
 
 def update_target_net(policy_net, target_net, tau=0.01):
@@ -180,14 +289,28 @@ def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_v
     obs, info = env.reset(**setup_fct())
     kw = dict(img_size=img_size, device=device, xlim=xlim, ylim=ylim)
     reward_features, obstacle_features = get_task_features(obs, **kw)
-    block_features, binary_features = get_state_features(obs, **kw)
+    task_key = _task_key(reward_features, obstacle_features)        # lets train_policy_net batch transitions of one task
+    block_features, binary_features, state_bits = _state_features(obs, xlim, ylim, img_size, device)
+    obstacle_bits = render_blocks_2d_bits(obs['obstacle_blocks'], xlim, ylim, img_size)
+    batched = hasattr(env, "create_blocks") and tuple(img_size)[0] == tuple(img_size)[1] <= 64
 
-    def candidates(block_f):
+    def candidates(block_f, bits_s):
+        """generate_actions -> get_action_features -> filter_actions (successor_dqn.py:375-377) of the current state.  With the
+        drop-in gym the three are ONE operator call (bridges_action_features: rasters of every candidate, the bounds test of
+        collision_on_action and the two overlap tests of filter_actions; tests/test_gpu_api_golden.py shows it equal to the
+        composition) and one mask copied back, instead of a reduction pair and a host read per action."""
         acts = [*generate_actions(env, x_discr_ground=x_discr_ground, offset_values=offset_values)]
-        feats = get_action_features(env, acts, **kw)
-        return filter_actions(env, acts, feats, block_features=block_f, obstacle_features=obstacle_features, xlim=xlim, ylim=ylim)
+        if not batched or not acts:
+            feats = get_action_features(env, acts, **kw)
+            return filter_actions(env, acts, feats, block_features=block_f, obstacle_features=obstacle_features, xlim=xlim, ylim=ylim)
+        _bits, img, mask, _lin = ops.action_features(env.create_blocks(acts), xlim, ylim, state_bits=bits_s, obstacle_bits=obstacle_bits,
+                                                     img_size=img_size, want_f32=True)
+        keep = np.flatnonzero(mask.cpu().numpy())                                          # the one host read of the filter
+        rows, = ops.upload(img.device, keep.astype(np.int64))
+        feats = ops.crop(img, img_size).index_select(0, rows).unsqueeze(1).contiguous().to(device)
+        return [acts[i] for i in keep], feats
 
-    available_actions, action_features = candidates(block_features)
+    available_actions, action_features = candidates(block_features, state_bits)
     num_actions = len(available_actions)
     step_index = 0
 
@@ -210,22 +333,24 @@ def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_v
             lin_reward = torch.sum(selected_action_features * reward_features).view(-1) / 100
         if unfrozen_stable:
             lin_reward = torch.sum(selected_action_features * reward_features).view(-1)
-        next_block_features, next_binary_features = get_state_features(next_observation, **kw)
-        next_available_actions, next_action_features = candidates(next_block_features)
+        next_block_features, next_binary_features, state_bits = _state_features(next_observation, xlim, ylim, img_size, device)
+        next_available_actions, next_action_features = candidates(next_block_features, state_bits)
         num_actions = len(next_available_actions)
         if num_actions == 0:
             done = True
             next_action_features = torch.zeros([1, 1, *img_size], device=device)
-        q_value = q_values[sel].item()
-        next_q_value = 0
+        # q(s, a) and max_a' q(s', a') travel to the host together (one read instead of two)
+        pair = [q_values[sel].reshape(1).float()]
         if not done:
-            next_q_value = qnet(next_block_features, next_binary_features, next_action_features, num_actions)[0].max().item()
+            pair.append(qnet(next_block_features, next_binary_features, next_action_features, num_actions)[0].max().reshape(1).float())
+        pair = torch.cat(pair).tolist()
+        q_value, next_q_value = pair[0], (pair[1] if not done else 0)
         td_error = abs(q_value - (reward + 0.95 * next_q_value))          # successor_dqn.py:425 (hard-coded 0.95)
         n1 = max(1, num_actions)
         transitions.append(Transition(
             block_features=block_features.unsqueeze(0), binary_features=binary_features.unsqueeze(0),
-            action_features=selected_action_features.unsqueeze(0), reward_features=reward_features.unsqueeze(0),
-            obstacle_features=obstacle_features.unsqueeze(0), action=action, lin_reward=lin_reward.unsqueeze(0),
+            action_features=selected_action_features.unsqueeze(0), reward_features=_tagged(reward_features.unsqueeze(0), task_key),
+            obstacle_features=_tagged(obstacle_features.unsqueeze(0), task_key), action=action, lin_reward=lin_reward.unsqueeze(0),
             reward=torch.Tensor([reward]), done=done,
             next_block_features=next_block_features.expand(n1, -1, -1, -1),
             next_binary_features=next_binary_features.expand(n1, -1), next_actions_features=next_action_features,
@@ -448,6 +573,7 @@ def main(argv=None):
         if args['verbose']:
             print(f"episode {i}: {log_info}")
         if args['save_checkpoint'] and i % args['checkpoint_every'] == 0:     # utils.py:54-89 layout
+            sync_fused_optimizer(policy_net)
             save_checkpoint(args['save_checkpoint'], policy_net, target_net, replay_buffer, optimizer, i,
                             {k: (str(v) if not isinstance(v, (int, float, str, bool, type(None))) else v) for k, v in args.items()})
         if i % args['evaluate_every'] == 0:

@@ -477,6 +477,7 @@ class VecDQN:
         if st is not None:
             n = n_steps * B
             if st.get("fused"):
+                st["step"].check_hyperparameters()
                 # the first layer's input rows of all n_steps batches in one launch, straight from the target pass's tensors
                 # (no staging copy of the 13 MB block / action images: a replayed step reads only x_all, q and sf)
                 st["step"].prepare_inputs(n_steps, block_f.reshape(n, -1).contiguous(), action_f.reshape(n, -1).contiguous(),
@@ -712,4 +713,5 @@ def run_vectorised(args, device, aim_run=None, wandb_run=None, return_agent=Fals
         pending = (info, losses, stats_host, done)
     if pending is not None:
         finish(pending)
+    agent.sync_optimizer_state()       # the captured step counts Adam's steps itself: hand the count back before anyone reads opt.state
     return (history, agent) if return_agent else history

@@ -513,3 +513,64 @@ def test_eps_greedy_select_matches_the_segmented_torch_formulation(E, amax, eps,
         assert int(sel_index[e]) == max(int(idx[row]) - int(cand_offset[e]), 0)
         assert float(q_sel[e]) == (float(q[row]) if hi > lo else 0.0)
         assert float(ex_w[e]) == (1.0 if (explore and hi > lo) else 0.0)
+
+
+@pytest.mark.parametrize("loss_fct,B,size,hidden", [("mse_q_values", 32, (64, 64), [256, 128, 64, 128, 256]),
+                                                   ("mse_block_features", 32, (64, 64), [256, 128, 64, 128, 256]),
+                                                   ("mse_q_values+mse_block_features", 8, (64, 64), [128, 64, 128])])
+def test_train_policy_net_on_the_hand_written_step_follows_the_autograd_form(loss_fct, B, size, hidden):
+    """The single-environment train_policy_net (successor_dqn.py:157-277) takes the hand-written SuccessorMLP step when every
+    sampled transition carries the same task fingerprint (rollout_episode tags them): per-step losses -- incl. the [B,B]
+    broadcast of the q target, i.e. the var(lin_reward) term -- within 1e-5 of the autograd form on the same batches, the
+    weights after three Adam steps within what two correct float32 Adam runs agree to; untagged transitions keep the
+    autograd form; the optimiser's state is the true one after sync_fused_optimizer."""
+    import warnings
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.training import successor_dqn as S
+    from robotoddler.utils.replay_memory import ReplayBuffer
+    from robotoddler.utils.utils import init_weights
+    warnings.filterwarnings("ignore", message="Using a target size")
+    gamma = 0.8
+    trans = synthetic_transitions(3 * B, size, 5)
+    reward, obstacle = trans[0].reward_features.to(DEV), trans[0].obstacle_features.to(DEV)
+    key = S._task_key(reward, obstacle)
+    dev_t = lambda t: t.to(DEV) if torch.is_tensor(t) else t
+    shared, plain = [], []
+    for t in trans:
+        n1 = t.next_block_features.shape[0]
+        d = {f: dev_t(getattr(t, f)) for f in t._fields}
+        d.update(next_reward_features=reward.expand(n1, -1, -1, -1), next_obstacle_features=obstacle.expand(n1, -1, -1, -1))
+        plain.append(Transition(**dict(d, reward_features=reward.clone(), obstacle_features=obstacle.clone())))
+        shared.append(Transition(**dict(d, reward_features=S._tagged(reward.clone(), key), obstacle_features=S._tagged(obstacle.clone(), key))))
+    torch.manual_seed(1)
+    mk = lambda: SuccessorMLP(img_size=size, hidden_dims=hidden).to(DEV)
+    nets = {}
+    for name, items in (("fused", shared), ("autograd", plain)):
+        pol, tgt = mk(), mk()
+        if nets:
+            pol.load_state_dict(nets["fused"][4])
+        else:
+            pol.apply(init_weights)
+        init = {k: v.clone() for k, v in pol.state_dict().items()}
+        tgt.load_state_dict(init)
+        S.flatten_nets(pol, tgt)
+        opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+        rb = ReplayBuffer(capacity=1000)
+        rb.push(items)
+        random.seed(21)
+        losses = S.train_policy_net(pol, tgt, opt, rb, gamma, loss_fct=loss_fct, n_steps=3, batch_size=B, device=DEV)
+        nets[name] = (pol, opt, losses, getattr(pol, "_fused_trainer", None), init)
+    assert nets["fused"][3] is not None and nets["autograd"][3] is None          # the tagged run took the hand-written step
+    np.testing.assert_allclose(nets["fused"][2], nets["autograd"][2], rtol=2e-5, atol=1e-6)
+    for pa, pb in zip(nets["autograd"][0].parameters(), nets["fused"][0].parameters()):
+        err = float((pa.detach().double() - pb.detach().double()).norm() / (pa.detach().double().norm() + 1e-30))
+        assert err < 2e-4, err
+    S.sync_fused_optimizer(nets["fused"][0])
+    steps = {float(st["step"]) for st in nets["fused"][1].state.values()}
+    assert steps == {3.0}
+    # a further step by the autograd form on the same net (untagged batch): the optimiser carries on from step 3
+    rb = ReplayBuffer(capacity=1000)
+    rb.push(plain)
+    random.seed(22)
+    more = S.train_policy_net(nets["fused"][0], mk(), nets["fused"][1], rb, gamma, loss_fct=loss_fct, n_steps=1, batch_size=B, device=DEV)
+    assert len(more) == 1 and np.isfinite(more[0]) and {float(st["step"]) for st in nets["fused"][1].state.values()} == {4.0}

@@ -45,9 +45,16 @@ out = dict(env_steps_per_s=steps / dt, s_per_episode=dt / len(hist), episodes=le
            reference_recorded="3-4 env-steps/s, 33-42 s per episode (BASELINE.md section 1: pyomo + IPOPT on CPU)")
 if a.count_syncs:
     seen = []
+    import collections, traceback
+    where = collections.Counter()
     def hook(message, category, filename, lineno, file=None, line=None):
         if "synchroniz" in str(message):
             seen.append(1)
+            # the innermost frame of this repo on the stack: which line of the drop-in surface made the host wait
+            for fr in reversed(traceback.extract_stack()[:-1]):
+                if ROOT in fr.filename and "tools/" not in fr.filename:
+                    where[f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"] += 1
+                    break
     warnings.showwarning = hook
     warnings.simplefilter("always")
     torch.cuda.set_sync_debug_mode("warn")
@@ -55,4 +62,5 @@ if a.count_syncs:
     torch.cuda.set_sync_debug_mode("default")
     n2 = sum(h["num_steps"] for h in h2)
     out["host_syncs_per_env_step_rollout_only"] = len(seen) / max(n2, 1)
+    out["host_syncs_by_site_per_env_step"] = {k: round(v / max(n2, 1), 2) for k, v in where.most_common(25)}
 print(json.dumps(out))
