@@ -203,8 +203,9 @@ def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, lo
                     tr = policy_net._fused_trainer = _FusedTrainer(policy_net, optimizer, batch.block_features.shape[0], loss_fct)
                 except ValueError:
                     fused = False
-        if not fused:
-            sync_fused_optimizer(policy_net)                  # optimizer.step() takes over: it needs the true step count
+        if not fused and getattr(policy_net, "_fused_trainer", None) is not None:
+            sync_fused_optimizer(policy_net)                  # optimizer.step() takes over: it needs the true step count,
+            policy_net._fused_trainer = None                  # and a later fused batch adopts the optimiser's state afresh
         if fused:
             with torch.no_grad():
                 next_q, next_sf, _next_bin = target_net(
