@@ -1,6 +1,8 @@
 """Oracle parity at BASELINE.json's full sizes: the HIP lock-step environment against the plain-C oracle (oracle/c) for
 every env and every lock-step -- selected action, both stability booleans, termination / truncation, reward, linear
-reward, targets reached, block count, candidate / valid counts and the state's bit raster.
+reward, targets reached, block count, candidate / valid counts and the state's bit raster; with --candidates also
+is_action_stable_rbe of EVERY valid candidate of every env after every `--candidates`-th lock-step (the fused
+candidate-stability kernel against the oracle's orc_candidate_stability).
 
 The policy's draws are keyed by (seed, global env id, draw counter), so the oracle's trajectories do not depend on the
 GPU's: the oracle shards run FIRST in a fork pool (one env at a time per core, before this process touches the GPU),
@@ -36,7 +38,7 @@ def _setup(cfg):
 def oracle_shard(job):
     """Lock-steps of envs e0..e1 on the C oracle: dict of [L, n] arrays (+ state bits [L, n, 64])."""
     import ctypes as C
-    cfg, seed, e0, e1, L = job
+    cfg, seed, e0, e1, L, cand_every = job
     from oracle.c_env import CEnv, IMG
     from oracle.env import OracleGym
     gym = OracleGym(**_setup(cfg), max_steps=cfg["max_steps"])
@@ -45,6 +47,9 @@ def oracle_shard(job):
     out["reward"] = np.zeros((L, n))
     out["lin_reward"] = np.zeros((L, n))
     out["state_bits"] = np.zeros((L, n, IMG), dtype=np.uint64)
+    a_max = CEnv(gym).cfg.a_max
+    n_cs = len(range(cand_every - 1, L, cand_every)) if cand_every else 0
+    out["cand_stable"] = np.zeros((n_cs, n, a_max), dtype=np.uint8)       # 1 stable, 0 unstable or masked out
     envs = [CEnv(gym) for _ in range(n)]
     nc, nv = C.c_int32(), C.c_int32()
     for i, ce in enumerate(envs):
@@ -56,6 +61,9 @@ def oracle_shard(job):
             ce.L.orc_candidates(ce.h, C.byref(nc), C.byref(nv))
             out["n_cand"][it, i], out["n_valid"][it, i] = nc.value, nv.value
             out["state_bits"][it, i] = np.ctypeslib.as_array(ce.L.orc_state_bits(ce.h), shape=(IMG,))
+            if cand_every and it % cand_every == cand_every - 1:
+                cs = ce.candidate_stability()
+                out["cand_stable"][it // cand_every, i, :cs.size] = cs
     return out
 
 
@@ -67,6 +75,8 @@ def main():
     ap.add_argument("--seed", type=int, default=41)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--groups", type=int, default=2, help="env groups on their own HIP streams, as bench.py runs them")
+    ap.add_argument("--candidates", type=int, default=0, metavar="N",
+                    help="> 0: also compare is_action_stable_rbe of every valid candidate after every N-th lock-step")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
     E = a.envs or cfg["envs"]
@@ -75,10 +85,11 @@ def main():
     c_env.lib()                                                  # build / load once before forking
     t0 = time.time()
     per = -(-E // (workers * 4))                                 # 4 jobs per worker: even out the episode-length lottery
-    jobs = [(cfg, a.seed, e0, min(E, e0 + per), a.locksteps) for e0 in range(0, E, per)]
+    jobs = [(cfg, a.seed, e0, min(E, e0 + per), a.locksteps, a.candidates) for e0 in range(0, E, per)]
     with mp.get_context("fork").Pool(workers) as pool:
         parts = pool.map(oracle_shard, jobs)
     ora = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+    ora_cs = ora.pop("cand_stable")
     t_oracle = time.time() - t0
 
     import torch                                                  # only now: the pool is gone, nothing forked holds the GPU
@@ -87,8 +98,10 @@ def main():
     setup = _setup(cfg)
     t1 = time.time()
     vec = VecAssemblyGymGroups(E, [load_urdf(f"shapes/{n}.urdf") for n in cfg["names"]], setup["obstacles"], setup["targets"],
-                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True)
+                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True,
+                               candidate_snapshots=bool(a.candidates))
     mism, steps, lp_err, overflow = 0, 0, 0, 0
+    cs_decisions = cs_mism = cs_err = 0
     cat = lambda name: torch.cat([getattr(g, name) for g in vec.envs]).cpu().numpy()
     for it in range(a.locksteps):
         for g, st in zip(vec.envs, vec.streams):                 # select, read the selection back, then step (per group stream)
@@ -114,6 +127,26 @@ def main():
         # after the lock-step (auto-reset included) both sides hold the same state and the same candidate set
         nb_after = np.where(v & (o["done"] == 0), o["n_blocks"], 0)          # the oracle reports the count before its auto-reset
         ok &= (nb == nb_after) & (ncand == o["n_cand"]) & (nval == o["n_valid"]) & (sb == o["state_bits"]).all(axis=1)
+        if a.candidates and it % a.candidates == a.candidates - 1:
+            # is_action_stable_rbe of every valid candidate of the states just reached, group by group
+            e_base = 0
+            for g, st in zip(vec.envs, vec.streams):
+                with torch.cuda.stream(st):
+                    g.candidate_stability_mask()
+                st.synchronize()
+                off, nc = g.cand_offset.cpu().numpy(), g.n_cand.cpu().numpy()
+                got, msk = g.cand_stable.cpu().numpy(), g.cand_mask.cpu().numpy()
+                want = ora_cs[it // a.candidates, e_base:e_base + g.E]
+                for e in range(g.E):
+                    sl = slice(off[e], off[e] + nc[e])
+                    valid = msk[sl] != 0
+                    cs_decisions += int(valid.sum())
+                    cs_err += int((got[sl][valid] == 2).sum())
+                    bad_c = int((got[sl] != want[e, :nc[e]]).sum())
+                    if bad_c and cs_mism < 5:
+                        print("CANDIDATE MISMATCH lock-step", it, "env", e_base + e, "gpu", got[sl].tolist(), "oracle", want[e, :nc[e]].tolist())
+                    cs_mism += bad_c
+                e_base += g.E
         steps += int(v.sum())
         lp_err += int(((fl[:, 7] & 1) != 0).sum())
         overflow += int(((fl[:, 7] & 2) != 0).sum())
@@ -133,8 +166,9 @@ def main():
     stats = vec.read_stats()
     print(f"RESULT config={a.config} envs={E} locksteps={a.locksteps} groups={a.groups}: {steps} env-steps ({2 * steps} stability decisions) "
           f"compared, {mism} mismatches, lp_errors={lp_err} contact_overflows={overflow} cand_overflow={stats.get('cand_overflow', 0)} "
-          f"f32_equals_bits={f32_ok}; oracle {t_oracle:.1f} s on {workers} workers, gpu + compare {time.time() - t1:.1f} s")
-    sys.exit(0 if (mism == 0 and f32_ok and steps > 0) else 1)
+          f"f32_equals_bits={f32_ok}; candidate_decisions={cs_decisions} candidate_mismatches={cs_mism} candidate_errors={cs_err}; "
+          f"oracle {t_oracle:.1f} s on {workers} workers, gpu + compare {time.time() - t1:.1f} s")
+    sys.exit(0 if (mism == 0 and f32_ok and steps > 0 and cs_mism == 0 and cs_err == 0) else 1)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,25 @@ def test_config4_bench_leg_on_a_one_rank_rccl_group():
     assert leg["ring_records"] > 512 and leg["value"] > 1e3
 
 
+def test_headline_bench_and_its_child_leg_on_a_one_rank_rccl_group():
+    """`bench.py --gpus 1` under torchrun with the forced process group: the N > 1 flow end to end on one GPU -- nccl init with
+    device_id, the barriers and the MAX / SUM all-reduces of the timing contract on device tensors, destroy_process_group, then
+    the configs[3] leg started by rank 0 as a child torchrun job with its own nccl group -- and ONE JSON line at the end."""
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--envs", "512", "--no-other-modes",
+                     "--no-cpu-baseline"],
+                    _env(BRIDGES_FORCE_COLLECTIVE="1", BENCH_TRAIN_LOCKSTEPS="3", BENCH_TRAIN_WARMUP="3"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ranks_seen"] == 1 and j["config"]["dist_backend"] == "nccl" and j["scaling"] == "weak"
+    assert j["value"] > 1e5 and len(j["config"]["per_seed"]) == 3
+    leg = j["other_modes"]["train_config4"]
+    assert "error" not in leg, leg
+    assert leg["dist_backend"] == "nccl" and leg["ranks_seen"] == 1 and leg["ring_hash_equal"] is True and leg["policy_hash_equal"] is True
+    assert leg["allgather_rows_received"] == 512 and leg["value"] > 1e3
+
+
 WORKER = r'''
 import hashlib, json, os, sys
 sys.path[:0] = [%(root)r, %(pkg)r]
