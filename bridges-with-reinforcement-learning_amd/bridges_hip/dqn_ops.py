@@ -149,6 +149,101 @@ def upconv2x2(x, weight, bias):
     return out
 
 
+def conv3x3_supported(x, c_out):
+    """Shapes bridges_conv3x3 / bridges_conv3x3_wgrad cover: float32 NCHW on the GPU, square images of 8 / 16 / 32 / 64
+    pixels, C_out a multiple of 16."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[3] in (8, 16, 32, 64)
+            and c_out % 16 == 0 and c_out >= 16)
+
+
+def conv3x3(x, weight, bias=None, mask=None, transposed=False):
+    """conv2d(x, weight, padding=1) by bridges_conv3x3 (f32 matrix cores): + bias and ReLU when ``bias`` is given; times
+    [mask > 0] when ``mask`` is given; ``transposed``: the input gradient of a layer with ``weight`` [c_in_of_x, c_out, 3, 3]."""
+    L = abi.require_gpu()
+    x = x.contiguous()
+    weight = weight.contiguous()
+    n, c_in, H, W = x.shape
+    c_out = weight.shape[1] if transposed else weight.shape[0]
+    assert (weight.shape[0] if transposed else weight.shape[1]) == c_in and tuple(weight.shape[2:]) == (3, 3) and H == W
+    assert not (bias is not None and mask is not None)
+    out = torch.empty((n, c_out, H, W), dtype=torch.float32, device=x.device)
+    mode = 1 if bias is not None else (2 if mask is not None else 0)
+    if mask is not None:
+        mask = mask.contiguous()
+        assert mask.shape == out.shape
+    abi.check(L.bridges_conv3x3(_ptr(x), _ptr(weight), _ptr(bias.contiguous() if bias is not None else None), _ptr(mask), _ptr(out), n,
+                                c_in, c_out, W, mode, int(bool(transposed)), _stream()), "bridges_conv3x3")
+    return out
+
+
+_wgrad_scratch = {}
+
+
+def conv3x3_wgrad(g, x):
+    """(dW [c_out, c_in, 3, 3], db [c_out]) of a conv3x3 layer from the gradient g at its output and its input x
+    (bridges_conv3x3_wgrad: deterministic partial sums + one reduction launch)."""
+    L = abi.require_gpu()
+    g, x = g.contiguous(), x.contiguous()
+    n, c_out, H, W = g.shape
+    c_in = x.shape[1]
+    need = C.c_int64(0)
+    abi.check(L.bridges_conv3x3_wgrad_scratch(n, c_in, c_out, W, C.byref(need)), "bridges_conv3x3_wgrad_scratch")
+    key = (str(g.device), torch.cuda.current_stream().cuda_stream)
+    sc = _wgrad_scratch.get(key)
+    if sc is None or sc.numel() < need.value:
+        sc = _wgrad_scratch[key] = torch.empty(max(need.value, 1 << 20), dtype=torch.float32, device=g.device)
+    dw = torch.empty((c_out, c_in, 3, 3), dtype=torch.float32, device=g.device)
+    db = torch.empty(c_out, dtype=torch.float32, device=g.device)
+    abi.check(L.bridges_conv3x3_wgrad(_ptr(g), _ptr(x), _ptr(dw), _ptr(db), _ptr(sc), sc.numel(), n, c_in, c_out, W, _stream()),
+              "bridges_conv3x3_wgrad")
+    return dw, db
+
+
+def maxpool2(a):
+    L = abi.require_gpu()
+    a = a.contiguous()
+    n, c, H, W = a.shape
+    y = torch.empty((n, c, H // 2, W // 2), dtype=torch.float32, device=a.device)
+    abi.check(L.bridges_maxpool2(_ptr(a), _ptr(y), n * c, H, W, _stream()), "bridges_maxpool2")
+    return y
+
+
+def maxpool2_relu_backward(a, dy):
+    """Gradient at the pre-pool activation a = relu(.) from dy at max_pool2d(a, 2) (first maximum takes it, times [a > 0])."""
+    L = abi.require_gpu()
+    a, dy = a.contiguous(), dy.contiguous()
+    n, c, H, W = a.shape
+    g = torch.empty_like(a)
+    abi.check(L.bridges_maxpool2_relu_backward(_ptr(a), _ptr(dy), _ptr(g), n * c, H, W, _stream()), "bridges_maxpool2_relu_backward")
+    return g
+
+
+class ConvBlockFunction(torch.autograd.Function):
+    """conv3x3 - ReLU - conv3x3 - ReLU - MaxPool2d(2) (cv.py:5-17) with a hand-written forward AND backward: 3 launches
+    forward, 7 backward (pool gradient, two weight gradients with their reductions, two input gradients) instead of the
+    library's ~14 + ~50."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        a1 = conv3x3(x, w1, bias=b1)
+        a2 = conv3x3(a1, w2, bias=b2)
+        y = maxpool2(a2)
+        ctx.save_for_backward(x, a1, a2, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a1, a2, w1, w2 = ctx.saved_tensors
+        g2 = maxpool2_relu_backward(a2, dy)
+        dw2, db2 = conv3x3_wgrad(g2, a1)
+        g1 = conv3x3(g2, w2, mask=a1, transposed=True)
+        dw1, db1 = conv3x3_wgrad(g1, x)
+        dx = conv3x3(g1, w1, transposed=True) if ctx.needs_input_grad[0] and x.shape[1] % 16 == 0 else None
+        if ctx.needs_input_grad[0] and dx is None:                    # a first layer whose input wants a gradient: the library's
+            dx = torch.nn.grad.conv2d_input(x.shape, w1, g1, padding=1)
+        return dx, dw1, db1, dw2, db2
+
+
 class FlatParameters:
     """All parameters and float buffers of a module re-pointed into ONE contiguous float32 device buffer, so the
     Polyak update of a 6.4 M-parameter SuccessorMLP is a single launch instead of one per state_dict key."""

@@ -1,0 +1,262 @@
+// K11: the ConvBlock stacks of the conv Q-networks (robotoddler/models/cv.py:5-17: conv3x3 - ReLU - conv3x3 - ReLU - MaxPool2d(2),
+// four of them in ConvNet, cv.py:41-73) for the TRAINING passes of train_policy_net (successor_dqn.py:157-277): forward,
+// input gradient, weight / bias gradient and the pooling pair, hand-written for the f32 matrix cores.
+//
+// Why: at the CLI's replay batch of 32 one optimiser step of ConvNet is ~130 library launches of ~9 us (Winograd forward /
+// backward-data, implicit-GEMM weight gradients wrapped in layout transposes, separate bias / ReLU / pool / bias-gradient
+// passes: profiles/r04_b_conv_lockstep_kernels.txt) for ~10 GFLOP -- 1.15 ms where the arithmetic is worth ~0.1 ms.  Here a
+// ConvBlock is 3 launches forward and 6 backward.
+//
+//   k_c3        conv3x3, padding 1, on square W x W images (W = 8, 16, 32, 64), any C_in, C_out a multiple of 16.  The same
+//               kernel is the input gradient: dX = conv3x3(G, W^T flipped) -- the weight tensor is addressed through two
+//               strides and a flip flag.  v_mfma_f32_16x16x4_f32: M = 16 pixels, N = 16 output channels, K = 4 input
+//               channels of one tap; the input patch of a band (+ halo, 16 channels at a time) is staged in LDS, the weights
+//               of a tap sit in registers.  Epilogues: raw | + bias, ReLU | x [mask > 0] (the ReLU of the layer below, whose
+//               output is this gradient's destination).
+//   k_c3_wgrad  dW[co][ci][tap] = sum_{n,y,x} G[n,co,y,x] X[n,ci,y+dy-1,x+dx-1]: M = 16 co, N = 16 ci, K = 4 pixels; both
+//               operands from LDS, nine accumulator tiles (one per tap) per wave; the pixel range is split over workgroups
+//               whose partial sums a second launch adds in a fixed order (deterministic: no atomics), together with the
+//               bias gradient sum G.
+//   k_maxpool2 / k_maxpool2_relu_bwd   MaxPool2d(2) and its gradient folded with the ReLU mask (first maximum in scan
+//               order takes the gradient, as torch's max_pool2d does).
+#include "bridges_device.h"
+
+namespace bridges {
+
+typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
+
+#define C3_EPI_RAW 0
+#define C3_EPI_BIAS_RELU 1
+#define C3_EPI_MASK 2
+
+__host__ __device__ constexpr int c3_band_rows(int W) { return W >= 64 ? 8 : (W == 32 ? 16 : W); }
+// band of the weight-gradient kernel: two operand tiles must fit into 64 KB of static LDS
+__host__ __device__ constexpr int c3_wgrad_rows(int W) { return W >= 64 ? 4 : (W == 32 ? 8 : W); }
+// smallest size >= raw with size % 64 == rem (LDS plane strides that put the 4 k-lanes of an operand read on distinct banks)
+__host__ __device__ constexpr int c3_pad(int raw, int rem) { return ((raw - rem + 63) / 64) * 64 + rem; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// x [N, c_in, W, W], weights addressed as w[cin * w_sin + cout * w_sout + (flip ? 8 - tap : tap)]:
+//   forward:        w = conv.weight [c_out, c_in, 3, 3]: w_sout = c_in * 9, w_sin = 9,  flip = 0
+//   input gradient: x = G [N, C_out_layer, ..], "c_out" = C_in_layer:   w_sin = C_in_layer * 9, w_sout = 9, flip = 1
+// grid = (N * bands, c_out / 16); a workgroup = one image band x 16 output channels.
+template <int W, int CIN_CHUNK, int EPI>
+__global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                            const float* __restrict__ mask_src, float* __restrict__ out, int c_in, int c_out,
+                                            int w_sin, int w_sout, int flip) {
+    constexpr int R = c3_band_rows(W), WP = W + 2, PLANE = c3_pad((R + 2) * WP, 16);
+    constexpr int GROUPS = CIN_CHUNK / 4, KSTEPS = 9 * GROUPS;
+    constexpr int TILES = R * W / 16, TPW = TILES / 4;              // 16-pixel tiles per band / per wave
+    static_assert(TILES % 4 == 0, "a band must give every wave the same number of tiles");
+    __shared__ float tile[CIN_CHUNK * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int px = lane & 15, q = lane >> 4;
+    constexpr int bands = W / R;
+    const int n = blockIdx.x / bands, y0 = (blockIdx.x % bands) * R;
+    const int co0 = blockIdx.y * 16;
+    c3_f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = (c3_f32x4){0.f, 0.f, 0.f, 0.f};
+    // this lane's pixel inside a tile: 16 consecutive pixels of a row (W >= 16) or two rows of 8
+    const int lp_r = (W >= 16) ? 0 : px / W, lp_c = (W >= 16) ? px : px % W;
+    const int n_chunks = (c_in + CIN_CHUNK - 1) / CIN_CHUNK;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const int c_base = chunk * CIN_CHUNK;
+        if (chunk) __syncthreads();
+        // ---- stage the band's input rows (+1 halo each side) of CIN_CHUNK channels, zeros outside the image / beyond c_in
+        constexpr int ITEMS = CIN_CHUNK * (R + 2) * WP;
+        for (int i = t; i < ITEMS; i += 256) {
+            const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+            const int rr = rem / WP, cc = rem - rr * WP;
+            const int y = y0 - 1 + rr, xx = cc - 1;
+            float v = 0.f;
+            if (y >= 0 && y < W && xx >= 0 && xx < W && c_base + c < c_in)
+                v = x[(((size_t)n * c_in + c_base + c) * W + y) * W + xx];
+            tile[c * PLANE + rr * WP + cc] = v;
+        }
+        // ---- B fragments: B[k = q][n = px] for every (tap, channel group) of this chunk
+        float bf[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int tap = s / GROUPS, g = s % GROUPS;
+            const int cin = c_base + 4 * g + q;
+            const bool live = cin < c_in;
+            const float wv = w[(size_t)(live ? cin : 0) * w_sin + (size_t)(co0 + px) * w_sout + (flip ? 8 - tap : tap)];
+            bf[s] = live ? wv : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int ti = wave * TPW + i;
+            const int row0 = (W >= 16) ? (ti * 16) / W : ti * 2, col0 = (W >= 16) ? (ti * 16) % W : 0;
+            const int base = q * PLANE + (row0 + lp_r) * WP + col0 + lp_c;      // patch row 0 = image row y0 - 1, column 0 = x = -1
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int tap = s / GROUPS, g = s % GROUPS;
+                const int dy = tap / 3, dx = tap % 3;
+                const float a = tile[base + 4 * g * PLANE + dy * WP + dx];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: lane = (output channel co0 + px, pixels 4 q .. 4 q + 3 of the tile)
+    const int co = co0 + px;
+    const float b = (EPI == C3_EPI_BIAS_RELU) ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int ti = wave * TPW + i;
+        int row, col;
+        if (W >= 16) { row = (ti * 16) / W; col = (ti * 16) % W + 4 * q; }
+        else { row = ti * 2 + (4 * q) / W; col = (4 * q) % W; }
+        const size_t o = (((size_t)n * c_out + co) * W + (y0 + row)) * W + col;
+        c3_f32x4 u = acc[i];
+        float4 p;
+        if (EPI == C3_EPI_BIAS_RELU) {
+            p.x = fmaxf(u[0] + b, 0.f); p.y = fmaxf(u[1] + b, 0.f); p.z = fmaxf(u[2] + b, 0.f); p.w = fmaxf(u[3] + b, 0.f);
+        } else if (EPI == C3_EPI_MASK) {
+            const float4 m = *reinterpret_cast<const float4*>(mask_src + o);
+            p.x = m.x > 0.f ? u[0] : 0.f; p.y = m.y > 0.f ? u[1] : 0.f; p.z = m.z > 0.f ? u[2] : 0.f; p.w = m.w > 0.f ? u[3] : 0.f;
+        } else {
+            p.x = u[0]; p.y = u[1]; p.z = u[2]; p.w = u[3];
+        }
+        *reinterpret_cast<float4*>(out + o) = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient.  grid = (co_tiles * ci_tiles, splits); split j handles the (image, band) units [j * ups, (j + 1) * ups).
+// part [splits, c_out, c_in, 9], part_b [splits, c_out] (written by the ci_tile == 0 workgroups).
+template <int W>
+__global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
+                                                  float* __restrict__ part_b, int N, int c_in, int c_out, int ups) {
+    constexpr int R = c3_wgrad_rows(W), WP = W + 2, bands = W / R;
+    constexpr int GP = c3_pad(R * W, 4), XP = c3_pad((R + 2) * WP, 4);
+    constexpr int KS = R * W / 4;                                   // k-steps (4 pixels each) per unit
+    constexpr int RED = 4 * 36 * 64;                                // cross-wave reduction scratch (floats)
+    constexpr int LDS = (16 * GP + 16 * XP) > RED ? (16 * GP + 16 * XP) : RED;
+    __shared__ float lds[LDS];
+    __shared__ float bsum[4][16];
+    float* gt = lds;                                                // [16 co][R * W] (+ pad)
+    float* xt = lds + 16 * GP;                                      // [16 ci][(R + 2) * WP] (+ pad)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int px = lane & 15, q = lane >> 4;
+    const int ci_tiles = (c_in + 15) / 16;
+    const int co0 = (blockIdx.x / ci_tiles) * 16, ci0 = (blockIdx.x % ci_tiles) * 16;
+    const int units = N * bands;
+    const int u_lo = blockIdx.y * ups, u_hi = (u_lo + ups < units) ? u_lo + ups : units;
+    c3_f32x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (c3_f32x4){0.f, 0.f, 0.f, 0.f};
+    float gsum = 0.f;
+    for (int u = u_lo; u < u_hi; ++u) {
+        const int n = u / bands, y0 = (u % bands) * R;
+        if (u != u_lo) __syncthreads();
+        for (int i = t; i < 16 * R * W; i += 256) {
+            const int c = i / (R * W), p = i - c * (R * W);
+            gt[c * GP + p] = g[(((size_t)n * c_out + co0 + c) * W + y0) * W + p];          // a band's rows are contiguous
+        }
+        for (int i = t; i < 16 * (R + 2) * WP; i += 256) {
+            const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+            const int rr = rem / WP, cc = rem - rr * WP;
+            const int y = y0 - 1 + rr, xx = cc - 1;
+            float v = 0.f;
+            if (y >= 0 && y < W && xx >= 0 && xx < W && ci0 + c < c_in)
+                v = x[(((size_t)n * c_in + ci0 + c) * W + y) * W + xx];
+            xt[c * XP + rr * WP + cc] = v;
+        }
+        __syncthreads();
+        for (int s = wave; s < KS; s += 4) {
+            const int p = 4 * s + q;                                 // this lane's pixel of the k-step (A: k = q; B: k = q)
+            const int row = p / W, col = p - row * W;
+            const float a = gt[px * GP + p];                         // A[m = co = px][k = q]
+            gsum += a;
+            const float* xb = xt + px * XP + row * WP + col;         // B[k = q][n = ci = px], tap (dy, dx) at + dy * WP + dx
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb[(tap / 3) * WP + (tap % 3)], acc[tap], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // ---- add the four waves' tiles in a fixed order; lane holds D[m = co = 4 q + u][n = ci = px] of every tap
+    float* red = lds;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[(wave * 36 + tap * 4 + u) * 64 + lane] = acc[tap][u];
+    gsum += __shfl_xor(gsum, 16);
+    gsum += __shfl_xor(gsum, 32);
+    if (q == 0) bsum[wave][px] = gsum;
+    __syncthreads();
+    for (int i = t; i < 36 * 64; i += 256) {
+        const int slot = i >> 6, l = i & 63;
+        const float v = ((red[(0 * 36 + slot) * 64 + l] + red[(1 * 36 + slot) * 64 + l]) + red[(2 * 36 + slot) * 64 + l]) + red[(3 * 36 + slot) * 64 + l];
+        const int tap = slot >> 2, u = slot & 3;
+        const int co = co0 + 4 * (l >> 4) + u, ci = ci0 + (l & 15);
+        if (ci < c_in) part[(((size_t)blockIdx.y * c_out + co) * c_in + ci) * 9 + tap] = v;
+    }
+    if (part_b && ci0 == 0 && t < 16)
+        part_b[(size_t)blockIdx.y * c_out + co0 + t] = ((bsum[0][t] + bsum[1][t]) + bsum[2][t]) + bsum[3][t];
+}
+
+// dw[i] = sum_s part[s][i], db[c] = sum_s part_b[s][c] in split order (deterministic).
+__global__ __launch_bounds__(256) void k_c3_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ dw,
+                                                   float* __restrict__ db, int n_w, int n_b, int splits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_w) {
+        float s = 0.f;
+        for (int j = 0; j < splits; ++j) s += part[(size_t)j * n_w + i];
+        dw[i] = s;
+    } else if (i < n_w + n_b) {
+        const int c = i - n_w;
+        float s = 0.f;
+        for (int j = 0; j < splits; ++j) s += part_b[(size_t)j * n_b + c];
+        db[c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y [n*C, H/2, W/2] = MaxPool2d(2)(a [n*C, H, W]); one thread per output pixel pair row (2 outputs: 4 input columns x 2 rows).
+__global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ a, float* __restrict__ y, int64_t items, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= items) return;
+    const int w4 = W >> 2, h2 = H >> 1;
+    const int64_t qd = i % w4, rest = i / w4;
+    const int64_t r = rest % h2, nc = rest / h2;
+    const float* p = a + (nc * H + 2 * r) * W + 4 * qd;
+    const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + W);
+    float2 o;
+    o.x = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
+    o.y = fmaxf(fmaxf(a0.z, a0.w), fmaxf(a1.z, a1.w));
+    *reinterpret_cast<float2*>(y + (nc * h2 + r) * (W >> 1) + 2 * qd) = o;
+}
+
+// g [n*C, H, W] = gradient at the pre-pool activation a = relu(.) given dy at the pooled output: the FIRST maximum of each
+// window in scan order takes dy (torch's max_pool2d backward), times the ReLU's [a > 0].
+__global__ __launch_bounds__(256) void k_maxpool2_relu_bwd(const float* __restrict__ a, const float* __restrict__ dy, float* __restrict__ g,
+                                                          int64_t items, int H, int W) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= items) return;
+    const int w4 = W >> 2, h2 = H >> 1;
+    const int64_t qd = i % w4, rest = i / w4;
+    const int64_t r = rest % h2, nc = rest / h2;
+    const size_t off = (nc * H + 2 * r) * W + 4 * qd;
+    const float4 a0 = *reinterpret_cast<const float4*>(a + off), a1 = *reinterpret_cast<const float4*>(a + off + W);
+    const float2 d = *reinterpret_cast<const float2*>(dy + (nc * h2 + r) * (W >> 1) + 2 * qd);
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float m = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
+        if (m > 0.f) {
+            if (a0.x == m) g0.x = d.x; else if (a0.y == m) g0.y = d.x; else if (a1.x == m) g1.x = d.x; else g1.y = d.x;
+        }
+    }
+    {
+        const float m = fmaxf(fmaxf(a0.z, a0.w), fmaxf(a1.z, a1.w));
+        if (m > 0.f) {
+            if (a0.z == m) g0.z = d.y; else if (a0.w == m) g0.w = d.y; else if (a1.z == m) g1.z = d.y; else g1.w = d.y;
+        }
+    }
+    *reinterpret_cast<float4*>(g + off) = g0;
+    *reinterpret_cast<float4*>(g + off + W) = g1;
+}
+
+}  // namespace bridges

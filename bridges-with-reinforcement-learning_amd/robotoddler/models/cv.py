@@ -46,6 +46,12 @@ class ConvBlock(nn.Module):
     def forward(self, inputs):
         if _fused_inference(inputs) and inputs.shape[-1] % 8 == 0 and inputs.shape[-2] % 2 == 0:
             return _conv_relu(self.layers[2], _conv_relu(self.layers[0], inputs), pool=True)
+        if torch.is_grad_enabled() and inputs.is_cuda and inputs.dtype == torch.float32:
+            # training pass (train_policy_net): forward and backward of the whole block on the hand-written kernels
+            from bridges_hip import dqn_ops
+            c1, c2 = self.layers[0], self.layers[2]
+            if dqn_ops.conv3x3_supported(inputs, c1.out_channels) and c1.out_channels == c2.out_channels == c2.in_channels:
+                return dqn_ops.ConvBlockFunction.apply(inputs, c1.weight, c1.bias, c2.weight, c2.bias)
         return self.layers(inputs)
 
 

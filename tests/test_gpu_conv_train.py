@@ -1,0 +1,131 @@
+"""GPU: the hand-written training passes of the ConvBlock stacks (csrc/conv_train_kernels.hip: conv3x3 forward / input
+gradient / weight gradient on the f32 matrix cores, the pooling pair) against PyTorch float32 (the library's convolutions and
+autograd) -- operator by operator, then a ConvBlock, then whole optimiser steps of ConvNet (robotoddler/models/cv.py:5-73)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+SHAPES = [(5, 4, 64, 16), (32, 16, 64, 16), (3, 16, 32, 32), (32, 32, 32, 32), (4, 32, 16, 64), (32, 64, 16, 64), (32, 64, 8, 128),
+          (7, 128, 8, 128), (2, 2, 64, 16), (1, 48, 16, 16)]
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, sparse=0.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    t = torch.randn(*shape, generator=g, device=DEV)
+    if sparse:
+        t = t * (torch.rand(*shape, generator=g, device=DEV) > sparse)
+    return t
+
+
+@pytest.mark.parametrize("n,c_in,W,c_out", SHAPES)
+def test_conv3x3_forward_modes_match_torch(n, c_in, W, c_out):
+    from bridges_hip import dqn_ops
+    x, w, b = rnd(n, c_in, W, W, seed=1, sparse=0.5), rnd(c_out, c_in, 3, 3, seed=2) * 0.2, rnd(c_out, seed=3)
+    ref = F.conv2d(x, w, padding=1)
+    assert rel(dqn_ops.conv3x3(x, w), ref) < 2e-6
+    got = dqn_ops.conv3x3(x, w, bias=b)
+    want = F.relu(ref + b[None, :, None, None])
+    assert rel(got, want) < 2e-6 and bool(((got == 0) == (want == 0)).float().mean() > 0.9999)
+    mask = rnd(n, c_out, W, W, seed=4)
+    assert rel(dqn_ops.conv3x3(x, w, mask=mask), ref * (mask > 0)) < 2e-6
+
+
+@pytest.mark.parametrize("n,c_in,W,c_out", [s for s in SHAPES if s[1] % 16 == 0])
+def test_conv3x3_input_gradient_matches_torch(n, c_in, W, c_out):
+    """transposed=True: dX of a layer c_in -> c_out from the gradient g at its output."""
+    from bridges_hip import dqn_ops
+    g, w = rnd(n, c_out, W, W, seed=5, sparse=0.6), rnd(c_out, c_in, 3, 3, seed=6) * 0.2
+    want = torch.nn.grad.conv2d_input((n, c_in, W, W), w, g, padding=1)
+    assert rel(dqn_ops.conv3x3(g, w, transposed=True), want) < 2e-6
+    a = rnd(n, c_in, W, W, seed=7)
+    assert rel(dqn_ops.conv3x3(g, w, mask=a, transposed=True), want * (a > 0)) < 2e-6
+
+
+@pytest.mark.parametrize("n,c_in,W,c_out", SHAPES)
+def test_conv3x3_weight_gradient_matches_torch_and_is_deterministic(n, c_in, W, c_out):
+    from bridges_hip import dqn_ops
+    g, x = rnd(n, c_out, W, W, seed=8, sparse=0.6), rnd(n, c_in, W, W, seed=9, sparse=0.5)
+    dw, db = dqn_ops.conv3x3_wgrad(g, x)
+    want = torch.nn.grad.conv2d_weight(x, (c_out, c_in, 3, 3), g, padding=1)
+    assert dw.shape == want.shape and rel(dw, want) < 5e-6
+    assert rel(db, g.sum(dim=(0, 2, 3))) < 5e-6
+    dw2, db2 = dqn_ops.conv3x3_wgrad(g, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)               # fixed summation order: bit-identical
+
+
+@pytest.mark.parametrize("n,c,W", [(3, 16, 64), (32, 128, 8), (5, 32, 16)])
+def test_maxpool2_pair_matches_torch_including_ties(n, c, W):
+    from bridges_hip import dqn_ops
+    a = F.relu(rnd(n, c, W, W, seed=10))
+    a[:, :, ::4, ::4] = a[:, :, 1::4, 1::4]                             # ties between the first and the last cell of many windows
+    a = a.contiguous().requires_grad_(True)
+    y = F.max_pool2d(a, 2)
+    assert torch.equal(dqn_ops.maxpool2(a.detach()), y.detach())
+    dy = rnd(n, c, W // 2, W // 2, seed=11)
+    # reference: gradient through max_pool2d, times the ReLU mask of a (a = relu(z): d/dz = [a > 0])
+    (ga,) = torch.autograd.grad(y, a, dy)
+    want = ga * (a.detach() > 0)
+    assert torch.equal(dqn_ops.maxpool2_relu_backward(a.detach(), dy), want)
+
+
+@pytest.mark.parametrize("n,c_in,W,c_out", [(32, 4, 64, 16), (32, 16, 32, 32), (6, 32, 16, 64), (32, 64, 8, 128), (9, 2, 64, 16)])
+def test_conv_block_forward_and_backward_match_autograd(n, c_in, W, c_out):
+    from robotoddler.models.cv import ConvBlock
+    torch.manual_seed(3)
+    blk = ConvBlock(c_in, c_out).to(DEV)
+    x = rnd(n, c_in, W, W, seed=12, sparse=0.5)
+    need_dx = c_in % 16 == 0
+    xa, xb = x.clone().requires_grad_(need_dx), x.clone().requires_grad_(need_dx)
+    ya = blk.layers(xa)                                                 # the module's own layers: library kernels + autograd
+    yb = blk(xb)                                                        # ConvBlock.forward: the hand-written Function
+    assert yb.grad_fn is not None and "ConvBlockFunction" in type(yb.grad_fn).__name__
+    assert rel(yb, ya) < 2e-6
+    dy = rnd(*ya.shape, seed=13)
+    params = list(blk.parameters())
+    ga = torch.autograd.grad(ya, params + ([xa] if need_dx else []), dy)
+    gb = torch.autograd.grad(yb, params + ([xb] if need_dx else []), dy)
+    for u, v in zip(gb, ga):
+        assert u.shape == v.shape and rel(u, v) < 1e-5, rel(u, v)
+
+
+def test_convnet_optimiser_steps_follow_the_library_path():
+    """Three Adam steps of ConvNet (cv.py:41-73) at the CLI's batch of 32 on 64x64 images: losses within 1e-5 and parameters
+    within what two correct float32 Adam runs agree to, hand-written ConvBlocks against the library's."""
+    from bridges_hip import dqn_ops
+    from robotoddler.models.cv import ConvNet
+    from robotoddler.utils.utils import init_weights
+    torch.manual_seed(5)
+    nets = [ConvNet(img_size=(64, 64)).to(DEV) for _ in range(2)]
+    nets[0].apply(init_weights)
+    nets[1].load_state_dict(nets[0].state_dict())
+    B = 32
+    imgs = [(rnd(B, 1, 64, 64, seed=20 + i) > 0.8).float() for i in range(4)]
+    binary = (rnd(B, 6, seed=30) > 0).float()
+    target = rnd(B, seed=31)
+    losses = [[], []]
+    for k, net in enumerate(nets):
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        orig = dqn_ops.conv3x3_supported
+        if k == 1:
+            dqn_ops.conv3x3_supported = lambda *a: False                # the library path (ConvBlock.forward falls back to self.layers)
+        try:
+            for _ in range(3):
+                q = net(imgs[0], binary, imgs[1], imgs[2], imgs[3])[0]
+                loss = F.mse_loss(q, target)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses[k].append(float(loss))
+        finally:
+            dqn_ops.conv3x3_supported = orig
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-5)
+    for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+        assert rel(pa.detach(), pb.detach()) < 5e-4
