@@ -245,9 +245,9 @@ def lib():
         "bridges_successor_loss": [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp],
         "bridges_adam_step": [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp],
         "bridges_linear_backward_adam": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, vp, i32, vp],
-        "bridges_conv3x3": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+        "bridges_conv3x3": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
         "bridges_conv3x3_wgrad_scratch": [i64, i32, i32, i32, C.POINTER(i64)],
-        "bridges_conv3x3_wgrad": [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp],
+        "bridges_conv3x3_wgrad": [vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp],
         "bridges_maxpool2": [vp, vp, i64, i32, i32, vp],
         "bridges_maxpool2_relu_backward": [vp, vp, vp, i64, i32, i32, vp],
         "bridges_td_target": [i32, vp, vp, vp, vp, i64, vp, vp, vp, f32, i32, vp, vp, vp, vp],

@@ -156,9 +156,10 @@ def conv3x3_supported(x, c_out):
             and c_out % 16 == 0 and c_out >= 16)
 
 
-def conv3x3(x, weight, bias=None, mask=None, transposed=False):
+def conv3x3(x, weight, bias=None, mask=None, transposed=False, in_mask=None):
     """conv2d(x, weight, padding=1) by bridges_conv3x3 (f32 matrix cores): + bias and ReLU when ``bias`` is given; times
-    [mask > 0] when ``mask`` is given; ``transposed``: the input gradient of a layer with ``weight`` [c_in_of_x, c_out, 3, 3]."""
+    [mask > 0] when ``mask`` is given; ``transposed``: the input gradient of a layer with ``weight`` [c_in_of_x, c_out, 3, 3];
+    ``in_mask`` (shape of x): x counts only where in_mask > 0 (x = the gradient at a ReLU's output)."""
     L = abi.require_gpu()
     x = x.contiguous()
     weight = weight.contiguous()
@@ -171,19 +172,25 @@ def conv3x3(x, weight, bias=None, mask=None, transposed=False):
     if mask is not None:
         mask = mask.contiguous()
         assert mask.shape == out.shape
-    abi.check(L.bridges_conv3x3(_ptr(x), _ptr(weight), _ptr(bias.contiguous() if bias is not None else None), _ptr(mask), _ptr(out), n,
-                                c_in, c_out, W, mode, int(bool(transposed)), _stream()), "bridges_conv3x3")
+    if in_mask is not None:
+        in_mask = in_mask.contiguous()
+        assert in_mask.shape == x.shape
+    abi.check(L.bridges_conv3x3(_ptr(x), _ptr(in_mask), _ptr(weight), _ptr(bias.contiguous() if bias is not None else None), _ptr(mask),
+                                _ptr(out), n, c_in, c_out, W, mode, int(bool(transposed)), _stream()), "bridges_conv3x3")
     return out
 
 
 _wgrad_scratch = {}
 
 
-def conv3x3_wgrad(g, x):
-    """(dW [c_out, c_in, 3, 3], db [c_out]) of a conv3x3 layer from the gradient g at its output and its input x
-    (bridges_conv3x3_wgrad: deterministic partial sums + one reduction launch)."""
+def conv3x3_wgrad(g, x, g_mask=None):
+    """(dW [c_out, c_in, 3, 3], db [c_out]) of a conv3x3 layer from the gradient g at its output (times [g_mask > 0] when
+    given: the layer's ReLU) and its input x (bridges_conv3x3_wgrad: deterministic partial sums + one reduction launch)."""
     L = abi.require_gpu()
     g, x = g.contiguous(), x.contiguous()
+    if g_mask is not None:
+        g_mask = g_mask.contiguous()
+        assert g_mask.shape == g.shape
     n, c_out, H, W = g.shape
     c_in = x.shape[1]
     need = C.c_int64(0)
@@ -194,7 +201,7 @@ def conv3x3_wgrad(g, x):
         sc = _wgrad_scratch[key] = torch.empty(max(need.value, 1 << 20), dtype=torch.float32, device=g.device)
     dw = torch.empty((c_out, c_in, 3, 3), dtype=torch.float32, device=g.device)
     db = torch.empty(c_out, dtype=torch.float32, device=g.device)
-    abi.check(L.bridges_conv3x3_wgrad(_ptr(g), _ptr(x), _ptr(dw), _ptr(db), _ptr(sc), sc.numel(), n, c_in, c_out, W, _stream()),
+    abi.check(L.bridges_conv3x3_wgrad(_ptr(g), _ptr(g_mask), _ptr(x), _ptr(dw), _ptr(db), _ptr(sc), sc.numel(), n, c_in, c_out, W, _stream()),
               "bridges_conv3x3_wgrad")
     return dw, db
 
@@ -242,6 +249,39 @@ class ConvBlockFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0] and dx is None:                    # a first layer whose input wants a gradient: the library's
             dx = torch.nn.grad.conv2d_input(x.shape, w1, g1, padding=1)
         return dx, dw1, db1, dw2, db2
+
+
+class Conv3x3ReLUFunction(torch.autograd.Function):
+    """relu(conv2d(x, w, b, padding=1)) with hand-written forward and backward (the U-Net's conv layers, cv.py:138-254): one
+    launch forward; backward the weight / bias gradient (two launches) and the input gradient (one), both reading the incoming
+    gradient through the ReLU's mask -- no element-wise pass in between."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        a = conv3x3(x, w, bias=b)
+        ctx.save_for_backward(x, a, w)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, a, w = ctx.saved_tensors
+        da = da.contiguous()
+        dw, db = conv3x3_wgrad(da, x, g_mask=a)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x.shape[1] % 16 == 0:
+                dx = conv3x3(da, w, transposed=True, in_mask=a)
+            else:
+                dx = torch.nn.grad.conv2d_input(x.shape, w, da * (a > 0), padding=1)
+        return dx, dw, db
+
+
+def conv3x3_relu_train(conv, x):
+    """relu(conv(x)) for a training pass: the hand-written Function where it applies, else the library."""
+    if (torch.is_grad_enabled() and conv3x3_supported(x, conv.out_channels) and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.stride) == (1, 1) and conv.groups == 1 and conv.bias is not None):
+        return Conv3x3ReLUFunction.apply(x, conv.weight, conv.bias)
+    return torch.relu(conv(x))
 
 
 class FlatParameters:

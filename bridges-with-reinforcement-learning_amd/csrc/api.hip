@@ -1021,15 +1021,15 @@ int bridges_upconv2x2(const float* x, const float* w, const float* bias, float* 
 
 // ---- K11: ConvBlock training passes (csrc/conv_train_kernels.hip) ---------------------------------------------------------
 template <int W, int CH>
-static void launch_c3(int mode, dim3 grid, hipStream_t s, const float* x, const float* w, const float* bias, const float* mask,
-                      float* out, int c_in, int c_out, int w_sin, int w_sout, int flip) {
-    if (mode == C3_EPI_BIAS_RELU) hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_BIAS_RELU>), grid, dim3(256), 0, s, x, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
-    else if (mode == C3_EPI_MASK) hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_MASK>), grid, dim3(256), 0, s, x, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
-    else hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_RAW>), grid, dim3(256), 0, s, x, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
+static void launch_c3(int mode, dim3 grid, hipStream_t s, const float* x, const float* in_mask, const float* w, const float* bias,
+                      const float* mask, float* out, int c_in, int c_out, int w_sin, int w_sout, int flip) {
+    if (mode == C3_EPI_BIAS_RELU) hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_BIAS_RELU>), grid, dim3(256), 0, s, x, in_mask, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
+    else if (mode == C3_EPI_MASK) hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_MASK>), grid, dim3(256), 0, s, x, in_mask, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
+    else hipLaunchKernelGGL((k_c3<W, CH, C3_EPI_RAW>), grid, dim3(256), 0, s, x, in_mask, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
 }
 
-int bridges_conv3x3(const float* x, const float* w, const float* bias, const float* mask, float* out, int64_t n, int32_t c_in,
-                    int32_t c_out, int32_t W, int32_t mode, int32_t transposed, void* stream) {
+int bridges_conv3x3(const float* x, const float* in_mask, const float* w, const float* bias, const float* mask, float* out, int64_t n,
+                    int32_t c_in, int32_t c_out, int32_t W, int32_t mode, int32_t transposed, void* stream) {
     if (n < 0 || !x || !w || !out || c_in < 1 || c_out < 16 || (c_out & 15)) return fail_arg("bridges_conv3x3: channels (C_out must be a multiple of 16)");
     if (W != 8 && W != 16 && W != 32 && W != 64) return fail_arg("bridges_conv3x3: W must be 8, 16, 32 or 64 (square images)");
     if (mode < C3_EPI_RAW || mode > C3_EPI_MASK || (mode == C3_EPI_BIAS_RELU && !bias) || (mode == C3_EPI_MASK && !mask)) return fail_arg("bridges_conv3x3: mode");
@@ -1042,8 +1042,8 @@ int bridges_conv3x3(const float* x, const float* w, const float* bias, const flo
     const int w_sin = transposed ? c_out * 9 : 9, w_sout = transposed ? 9 : c_in * 9, flip = transposed ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
 #define C3_DISPATCH(WW)                                                                                                \
-    if (c_in <= 4) launch_c3<WW, 4>(mode, grid, s, x, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);           \
-    else launch_c3<WW, 16>(mode, grid, s, x, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
+    if (c_in <= 4) launch_c3<WW, 4>(mode, grid, s, x, in_mask, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);  \
+    else launch_c3<WW, 16>(mode, grid, s, x, in_mask, w, bias, mask, out, c_in, c_out, w_sin, w_sout, flip);
     if (W == 64) { C3_DISPATCH(64) } else if (W == 32) { C3_DISPATCH(32) } else if (W == 16) { C3_DISPATCH(16) } else { C3_DISPATCH(8) }
 #undef C3_DISPATCH
     LAUNCH_CHECK("k_c3");
@@ -1062,8 +1062,8 @@ int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_
     return BRIDGES_OK;
 }
 
-int bridges_conv3x3_wgrad(const float* g, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats, int64_t n,
-                          int32_t c_in, int32_t c_out, int32_t W, void* stream) {
+int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
+                          int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream) {
     if (!g || !x || !dw || !db || !scratch) return fail_arg("bridges_conv3x3_wgrad");
     int64_t need = 0;
     int rc = bridges_conv3x3_wgrad_scratch(n, c_in, c_out, W, &need);
@@ -1078,10 +1078,10 @@ int bridges_conv3x3_wgrad(const float* g, const float* x, float* dw, float* db, 
     float* part_b = scratch + (int64_t)splits * n_w;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (W == 64) hipLaunchKernelGGL(k_c3_wgrad<64>, grid, dim3(256), 0, s, g, x, part, part_b, (int)n, c_in, c_out, ups);
-    else if (W == 32) hipLaunchKernelGGL(k_c3_wgrad<32>, grid, dim3(256), 0, s, g, x, part, part_b, (int)n, c_in, c_out, ups);
-    else if (W == 16) hipLaunchKernelGGL(k_c3_wgrad<16>, grid, dim3(256), 0, s, g, x, part, part_b, (int)n, c_in, c_out, ups);
-    else hipLaunchKernelGGL(k_c3_wgrad<8>, grid, dim3(256), 0, s, g, x, part, part_b, (int)n, c_in, c_out, ups);
+    if (W == 64) hipLaunchKernelGGL(k_c3_wgrad<64>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
+    else if (W == 32) hipLaunchKernelGGL(k_c3_wgrad<32>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
+    else if (W == 16) hipLaunchKernelGGL(k_c3_wgrad<16>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
+    else hipLaunchKernelGGL(k_c3_wgrad<8>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
     LAUNCH_CHECK("k_c3_wgrad");
     const int64_t tot = n_w + c_out;
     hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,

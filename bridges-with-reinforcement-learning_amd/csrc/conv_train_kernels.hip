@@ -36,14 +36,14 @@ __host__ __device__ constexpr int c3_wgrad_rows(int W) { return W >= 64 ? 4 : (W
 __host__ __device__ constexpr int c3_pad(int raw, int rem) { return ((raw - rem + 63) / 64) * 64 + rem; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// x [N, c_in, W, W], weights addressed as w[cin * w_sin + cout * w_sout + (flip ? 8 - tap : tap)]:
+// x [N, c_in, W, W] (in_mask, optional, same shape: x counts only where in_mask > 0), weights addressed as w[cin * w_sin + cout * w_sout + (flip ? 8 - tap : tap)]:
 //   forward:        w = conv.weight [c_out, c_in, 3, 3]: w_sout = c_in * 9, w_sin = 9,  flip = 0
 //   input gradient: x = G [N, C_out_layer, ..], "c_out" = C_in_layer:   w_sin = C_in_layer * 9, w_sout = 9, flip = 1
 // grid = (N * bands, c_out / 16); a workgroup = one image band x 16 output channels.
 template <int W, int CIN_CHUNK, int EPI>
-__global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                            const float* __restrict__ mask_src, float* __restrict__ out, int c_in, int c_out,
-                                            int w_sin, int w_sout, int flip) {
+__global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const float* __restrict__ in_mask, const float* __restrict__ w,
+                                            const float* __restrict__ bias, const float* __restrict__ mask_src, float* __restrict__ out,
+                                            int c_in, int c_out, int w_sin, int w_sout, int flip) {
     constexpr int R = c3_band_rows(W), WP = W + 2, PLANE = c3_pad((R + 2) * WP, 16);
     constexpr int GROUPS = CIN_CHUNK / 4, KSTEPS = 9 * GROUPS;
     constexpr int TILES = R * W / 16, TPW = TILES / 4;              // 16-pixel tiles per band / per wave
@@ -70,8 +70,11 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
             const int rr = rem / WP, cc = rem - rr * WP;
             const int y = y0 - 1 + rr, xx = cc - 1;
             float v = 0.f;
-            if (y >= 0 && y < W && xx >= 0 && xx < W && c_base + c < c_in)
-                v = x[(((size_t)n * c_in + c_base + c) * W + y) * W + xx];
+            if (y >= 0 && y < W && xx >= 0 && xx < W && c_base + c < c_in) {
+                const size_t idx = (((size_t)n * c_in + c_base + c) * W + y) * W + xx;
+                v = x[idx];
+                if (in_mask && !(in_mask[idx] > 0.f)) v = 0.f;       // x = a gradient at a ReLU's output: times [its activation > 0]
+            }
             tile[c * PLANE + rr * WP + cc] = v;
         }
         // ---- B fragments: B[k = q][n = px] for every (tap, channel group) of this chunk
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
 // Weight gradient.  grid = (co_tiles * ci_tiles, splits); split j handles the (image, band) units [j * ups, (j + 1) * ups).
 // part [splits, c_out, c_in, 9], part_b [splits, c_out] (written by the ci_tile == 0 workgroups).
 template <int W>
-__global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
-                                                  float* __restrict__ part_b, int N, int c_in, int c_out, int ups) {
+__global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, const float* __restrict__ g_mask, const float* __restrict__ x,
+                                                  float* __restrict__ part, float* __restrict__ part_b, int N, int c_in, int c_out, int ups) {
     constexpr int R = c3_wgrad_rows(W), WP = W + 2, bands = W / R;
     constexpr int GP = c3_pad(R * W, 4), XP = c3_pad((R + 2) * WP, 4);
     constexpr int KS = R * W / 4;                                   // k-steps (4 pixels each) per unit
@@ -153,7 +156,10 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
         if (u != u_lo) __syncthreads();
         for (int i = t; i < 16 * R * W; i += 256) {
             const int c = i / (R * W), p = i - c * (R * W);
-            gt[c * GP + p] = g[(((size_t)n * c_out + co0 + c) * W + y0) * W + p];          // a band's rows are contiguous
+            const size_t idx = (((size_t)n * c_out + co0 + c) * W + y0) * W + p;             // a band's rows are contiguous
+            float v = g[idx];
+            if (g_mask && !(g_mask[idx] > 0.f)) v = 0.f;             // g = the gradient at a ReLU's output: times [activation > 0]
+            gt[c * GP + p] = v;
         }
         for (int i = t; i < 16 * (R + 2) * WP; i += 256) {
             const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);

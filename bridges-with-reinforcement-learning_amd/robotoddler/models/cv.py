@@ -235,8 +235,9 @@ class UNet(nn.Module):
 
     def forward(self, block_features, binary_features, action_features, reward_features, obstacle_features):
         x = torch.cat([block_features, action_features, reward_features, obstacle_features], dim=1)
-        cr = _conv_relu if (_fused_inference(x) and x.shape[-1] % 16 == 0) else (lambda conv, t: F.relu(conv(t)))
         from bridges_hip import dqn_ops
+        cr = _conv_relu if (_fused_inference(x) and x.shape[-1] % 16 == 0) else (
+            dqn_ops.conv3x3_relu_train if (torch.is_grad_enabled() and x.is_cuda) else (lambda conv, t: F.relu(conv(t))))
         if _fused_inference(x) and dqn_ops.conv3x3_relu_o16_applies(x, self.e11):
             # 64x64 inference: the four 16-channel layers on the hand-written kernel with their neighbours folded in -- the
             # first pooling comes out of e12 together with the skip tensor, d41 reads (upconv4, skip) without the

@@ -518,17 +518,19 @@ int bridges_upconv2x2(const float* x, const float* w, const float* bias, float* 
  *   mode 0: nothing else;  1: + bias, ReLU;  2: x [mask > 0] (mask [n, c_out, W, W]: the ReLU of the layer whose output the
  *   gradient flows into);
  *   transposed 0: w = Conv2d.weight [c_out, c_in, 3, 3];  1: the INPUT GRADIENT of a layer with weight w [c_in, c_out, 3, 3]
- *   (x = the gradient at that layer's output with c_in channels, out = the gradient at its input with c_out channels).
+ *   (x = the gradient at that layer's output with c_in channels, out = the gradient at its input with c_out channels);
+ *   in_mask (may be NULL; shape of x): x counts only where in_mask > 0 -- x = the gradient at a ReLU's output, in_mask = that
+ *   ReLU's activation (likewise g_mask of bridges_conv3x3_wgrad).
  * bridges_conv3x3_wgrad: dw [c_out, c_in, 3, 3] and db [c_out] from g [n, c_out, W, W] (gradient at the layer's output, ReLU
  *   mask applied) and the layer's input x [n, c_in, W, W]; partial sums over pixel ranges are added in a fixed order
  *   (deterministic); scratch: bridges_conv3x3_wgrad_scratch floats.
  * bridges_maxpool2 / bridges_maxpool2_relu_backward: MaxPool2d(2) of a [nc, H, W] and, from dy [nc, H/2, W/2], the gradient at
  *   the pre-pool activation a = relu(.): the first maximum of a window in scan order takes dy (as torch), times [a > 0]. */
-int bridges_conv3x3(const float* x, const float* w, const float* bias, const float* mask, float* out, int64_t n, int32_t c_in,
-                    int32_t c_out, int32_t W, int32_t mode, int32_t transposed, void* stream);
+int bridges_conv3x3(const float* x, const float* in_mask, const float* w, const float* bias, const float* mask, float* out, int64_t n,
+                    int32_t c_in, int32_t c_out, int32_t W, int32_t mode, int32_t transposed, void* stream);
 int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_t W, int64_t* floats);
-int bridges_conv3x3_wgrad(const float* g, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats, int64_t n,
-                          int32_t c_in, int32_t c_out, int32_t W, void* stream);
+int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
+                          int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream);
 int bridges_maxpool2(const float* a, float* y, int64_t nc, int32_t H, int32_t W, void* stream);
 int bridges_maxpool2_relu_backward(const float* a, const float* dy, float* g, int64_t nc, int32_t H, int32_t W, void* stream);
 

@@ -14,6 +14,7 @@ SHAPES = [(5, 4, 64, 16), (32, 16, 64, 16), (3, 16, 32, 32), (32, 32, 32, 32), (
 
 
 def rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
@@ -120,6 +121,60 @@ def test_convnet_optimiser_steps_follow_the_library_path():
             for _ in range(3):
                 q = net(imgs[0], binary, imgs[1], imgs[2], imgs[3])[0]
                 loss = F.mse_loss(q, target)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses[k].append(float(loss))
+        finally:
+            dqn_ops.conv3x3_supported = orig
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-5)
+    for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+        assert rel(pa.detach(), pb.detach()) < 5e-4
+
+
+@pytest.mark.parametrize("n,c_in,W,c_out", [(32, 4, 64, 16), (8, 16, 64, 16), (32, 64, 32, 32), (5, 32, 16, 64), (32, 32, 64, 16)])
+def test_conv3x3_relu_function_matches_autograd(n, c_in, W, c_out):
+    """relu(conv(x)) as one Function (the U-Net's layers): output, weight / bias gradient and input gradient against autograd on
+    the library's convolution -- the incoming gradient is read through the ReLU's mask inside the two backward kernels."""
+    from bridges_hip import dqn_ops
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(c_in, c_out, 3, padding=1).to(DEV)
+    x = rnd(n, c_in, W, W, seed=14, sparse=0.4)
+    need_dx = c_in % 16 == 0
+    xa, xb = x.clone().requires_grad_(need_dx), x.clone().requires_grad_(need_dx)
+    ya, yb = torch.relu(conv(xa)), dqn_ops.conv3x3_relu_train(conv, xb)
+    assert "Conv3x3ReLUFunction" in type(yb.grad_fn).__name__ and rel(yb.detach(), ya.detach()) < 2e-6
+    dy = rnd(*ya.shape, seed=15)
+    ga = torch.autograd.grad(ya, list(conv.parameters()) + ([xa] if need_dx else []), dy)
+    gb = torch.autograd.grad(yb, list(conv.parameters()) + ([xb] if need_dx else []), dy)
+    for u, v in zip(gb, ga):
+        assert u.shape == v.shape and rel(u, v) < 1e-5, rel(u, v)
+
+
+def test_unet_policy_optimiser_steps_follow_the_library_path():
+    """Policy (U-Net successor image + ConvNet stability head, cv.py:257-271) with the combined loss: three Adam steps through
+    the hand-written conv layers against the library path -- losses 2e-5, parameters to float32 Adam agreement."""
+    from bridges_hip import dqn_ops
+    from robotoddler.models.cv import Policy
+    from robotoddler.utils.utils import init_weights
+    torch.manual_seed(6)
+    nets = [Policy().to(DEV) for _ in range(2)]
+    nets[0].apply(init_weights)
+    nets[1].load_state_dict(nets[0].state_dict())
+    B = 32
+    imgs = [(rnd(B, 1, 64, 64, seed=40 + i) > 0.8).float() for i in range(4)]
+    binary = (rnd(B, 6, seed=50) > 0).float()
+    q_t, sf_t = rnd(B, seed=51), (rnd(B, 64, 64, seed=52) > 0.5).float()
+    losses = [[], []]
+    for k, net in enumerate(nets):
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        orig = dqn_ops.conv3x3_supported
+        if k == 1:
+            dqn_ops.conv3x3_supported = lambda *a: False
+        try:
+            for _ in range(3):
+                q, sf, _ = net(imgs[0], binary, imgs[1], imgs[2], imgs[3])
+                loss = F.mse_loss(q, q_t) + F.mse_loss(sf[:, 0], sf_t)
                 opt.zero_grad()
                 loss.backward()
                 opt.step()
