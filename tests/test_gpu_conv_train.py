@@ -181,6 +181,7 @@ def test_unet_policy_optimiser_steps_follow_the_library_path():
                 losses[k].append(float(loss))
         finally:
             dqn_ops.conv3x3_supported = orig
-    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-5)
+    np.testing.assert_allclose(losses[0][0], losses[1][0], rtol=1e-5)        # the first loss: forward passes on the same weights
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-4)              # after one / two Adam updates (losses of O(100))
     for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
         assert rel(pa.detach(), pb.detach()) < 5e-4
