@@ -1084,7 +1084,7 @@ int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, f
     else hipLaunchKernelGGL(k_c3_wgrad<8>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
     LAUNCH_CHECK("k_c3_wgrad");
     const int64_t tot = n_w + c_out;
-    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
                        (int)n_w, c_out, splits);
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;

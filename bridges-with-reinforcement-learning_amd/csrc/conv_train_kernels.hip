@@ -49,6 +49,12 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
     constexpr int TILES = R * W / 16, TPW = TILES / 4;              // 16-pixel tiles per band / per wave
     static_assert(TILES % 4 == 0, "a band must give every wave the same number of tiles");
     __shared__ float tile[CIN_CHUNK * PLANE];
+    // the chunk's weights, staged with coalesced loads: 16 rows (the index with the large stride in memory: the output channel
+    // forward, the input channel for an input gradient) of CIN_CHUNK * 9 (resp. 16 * 9) contiguous floats, rows padded to an odd
+    // stride.  (Fetching the fragments straight from global memory was 36 uncoalesced loads per lane and chunk: 40 us for a
+    // 64 -> 64 layer on 16 x 16 images, most of it waiting for them.)
+    constexpr int WROW = 16 * 9 + 1;
+    __shared__ float wl[16 * WROW];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int px = lane & 15, q = lane >> 4;
     constexpr int bands = W / R;
@@ -77,17 +83,31 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
             }
             tile[c * PLANE + rr * WP + cc] = v;
         }
+        // ---- the chunk's weights -> LDS.  forward: row = output channel co0 + r, inner = (cin_local, tap) contiguous in memory;
+        //      input gradient (flip): row = input channel c_base + r (the layer's output channel), inner = (cout_local, tap)
+        {
+            constexpr int INNER = (CIN_CHUNK < 16 ? CIN_CHUNK : 16) * 9;
+            const int inner_n = flip ? 16 * 9 : INNER;
+            for (int i = t; i < 16 * inner_n; i += 256) {
+                const int r = i / inner_n, j = i - r * inner_n;
+                float v = 0.f;
+                if (flip) {
+                    if (c_base + r < c_in) v = w[(size_t)(c_base + r) * w_sin + (size_t)co0 * 9 + j];
+                } else {
+                    if (c_base + j / 9 < c_in) v = w[(size_t)(co0 + r) * w_sout + (size_t)c_base * 9 + j];
+                }
+                wl[r * WROW + j] = v;
+            }
+        }
+        __syncthreads();
         // ---- B fragments: B[k = q][n = px] for every (tap, channel group) of this chunk
         float bf[KSTEPS];
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int tap = s / GROUPS, g = s % GROUPS;
-            const int cin = c_base + 4 * g + q;
-            const bool live = cin < c_in;
-            const float wv = w[(size_t)(live ? cin : 0) * w_sin + (size_t)(co0 + px) * w_sout + (flip ? 8 - tap : tap)];
-            bf[s] = live ? wv : 0.f;
+            const int cl = 4 * g + q;                                // input channel inside the chunk
+            bf[s] = flip ? wl[cl * WROW + px * 9 + (8 - tap)] : wl[px * WROW + cl * 9 + tap];
         }
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int ti = wave * TPW + i;
@@ -204,19 +224,35 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
         part_b[(size_t)blockIdx.y * c_out + co0 + t] = ((bsum[0][t] + bsum[1][t]) + bsum[2][t]) + bsum[3][t];
 }
 
-// dw[i] = sum_s part[s][i], db[c] = sum_s part_b[s][c] in split order (deterministic).
+// dw[i] = sum_s part[s][i], db[c] = sum_s part_b[s][c] in a FIXED order (deterministic): a workgroup owns 16 outputs, 16 lanes
+// per output each add the splits j = lane, lane + 16, ... (four loads in flight), then a fixed butterfly over the 16 lanes.
+// (One thread per output walking 512 splits was a chain of 512 dependent-latency loads: 41 us per launch.)
 __global__ __launch_bounds__(256) void k_c3_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ dw,
                                                    float* __restrict__ db, int n_w, int n_b, int splits) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_w) {
-        float s = 0.f;
-        for (int j = 0; j < splits; ++j) s += part[(size_t)j * n_w + i];
-        dw[i] = s;
-    } else if (i < n_w + n_b) {
-        const int c = i - n_w;
-        float s = 0.f;
-        for (int j = 0; j < splits; ++j) s += part_b[(size_t)j * n_b + c];
-        db[c] = s;
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;           // output within the group / split lane
+    const int i = blockIdx.x * 16 + o;
+    const bool is_w = i < n_w, live = i < n_w + n_b;
+    const float* src = is_w ? part + i : part_b + (i - n_w);
+    const size_t stride = is_w ? (size_t)n_w : (size_t)n_b;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (live) {
+        int j = sl;
+        for (; j + 48 < splits; j += 64) {
+            s0 += src[(size_t)j * stride]; s1 += src[(size_t)(j + 16) * stride];
+            s2 += src[(size_t)(j + 32) * stride]; s3 += src[(size_t)(j + 48) * stride];
+        }
+        for (; j < splits; j += 16) s0 += src[(size_t)j * stride];
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    __shared__ float red[16][17];
+    red[sl][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && blockIdx.x * 16 + threadIdx.x < n_w + n_b) {
+        const int oo = threadIdx.x, ii = blockIdx.x * 16 + oo;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][oo];
+        if (ii < n_w) dw[ii] = v; else db[ii - n_w] = v;
     }
 }
 
