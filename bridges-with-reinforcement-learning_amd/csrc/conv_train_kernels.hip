@@ -40,21 +40,25 @@ __host__ __device__ constexpr int c3_pad(int raw, int rem) { return ((raw - rem 
 //   forward:        w = conv.weight [c_out, c_in, 3, 3]: w_sout = c_in * 9, w_sin = 9,  flip = 0
 //   input gradient: x = G [N, C_out_layer, ..], "c_out" = C_in_layer:   w_sin = C_in_layer * 9, w_sout = 9, flip = 1
 // grid = (N * bands, c_out / 16); a workgroup = one image band x 16 output channels.
+// Input channels staged per pass: as many as 64 KB of LDS hold next to their weights -- the kernel is a chain of
+// "global round trip, LDS, a few hundred MFMAs" per pass, and on the small images of the deep layers the round trips are
+// what it costs (64 -> 128 channels on 8 x 8 images: 8 passes of 16 channels took 39 us, the arithmetic < 2).
+__host__ __device__ constexpr int c3_stage(int W, int CIN_CHUNK) { return CIN_CHUNK < 16 ? CIN_CHUNK : (W <= 16 ? 32 : 16); }
+
 template <int W, int CIN_CHUNK, int EPI>
 __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const float* __restrict__ in_mask, const float* __restrict__ w,
                                             const float* __restrict__ bias, const float* __restrict__ mask_src, float* __restrict__ out,
                                             int c_in, int c_out, int w_sin, int w_sout, int flip) {
     constexpr int R = c3_band_rows(W), WP = W + 2, PLANE = c3_pad((R + 2) * WP, 16);
+    constexpr int STAGE = c3_stage(W, CIN_CHUNK), SUB = STAGE / CIN_CHUNK;      // sub-chunks of CIN_CHUNK channels per pass
     constexpr int GROUPS = CIN_CHUNK / 4, KSTEPS = 9 * GROUPS;
     constexpr int TILES = R * W / 16, TPW = TILES / 4;              // 16-pixel tiles per band / per wave
     static_assert(TILES % 4 == 0, "a band must give every wave the same number of tiles");
-    __shared__ float tile[CIN_CHUNK * PLANE];
-    // the chunk's weights, staged with coalesced loads: 16 rows (the index with the large stride in memory: the output channel
-    // forward, the input channel for an input gradient) of CIN_CHUNK * 9 (resp. 16 * 9) contiguous floats, rows padded to an odd
-    // stride.  (Fetching the fragments straight from global memory was 36 uncoalesced loads per lane and chunk: 40 us for a
-    // 64 -> 64 layer on 16 x 16 images, most of it waiting for them.)
+    __shared__ float tile[STAGE * PLANE];
+    // a sub-chunk's weights: 16 rows (the index with the large stride in memory: the output channel forward, the input channel
+    // for an input gradient) of 16 * 9 contiguous floats (CIN_CHUNK * 9 for the 4-channel first layer), rows padded to an odd stride
     constexpr int WROW = 16 * 9 + 1;
-    __shared__ float wl[16 * WROW];
+    __shared__ float wl[SUB * 16 * WROW];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int px = lane & 15, q = lane >> 4;
     constexpr int bands = W / R;
@@ -65,60 +69,114 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
     for (int i = 0; i < TPW; ++i) acc[i] = (c3_f32x4){0.f, 0.f, 0.f, 0.f};
     // this lane's pixel inside a tile: 16 consecutive pixels of a row (W >= 16) or two rows of 8
     const int lp_r = (W >= 16) ? 0 : px / W, lp_c = (W >= 16) ? px : px % W;
-    const int n_chunks = (c_in + CIN_CHUNK - 1) / CIN_CHUNK;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-        const int c_base = chunk * CIN_CHUNK;
-        if (chunk) __syncthreads();
-        // ---- stage the band's input rows (+1 halo each side) of CIN_CHUNK channels, zeros outside the image / beyond c_in
-        constexpr int ITEMS = CIN_CHUNK * (R + 2) * WP;
-        for (int i = t; i < ITEMS; i += 256) {
-            const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-            const int rr = rem / WP, cc = rem - rr * WP;
-            const int y = y0 - 1 + rr, xx = cc - 1;
-            float v = 0.f;
-            if (y >= 0 && y < W && xx >= 0 && xx < W && c_base + c < c_in) {
-                const size_t idx = (((size_t)n * c_in + c_base + c) * W + y) * W + xx;
-                v = x[idx];
-                if (in_mask && !(in_mask[idx] > 0.f)) v = 0.f;       // x = a gradient at a ReLU's output: times [its activation > 0]
+    const int n_pass = (c_in + STAGE - 1) / STAGE;
+    constexpr int ITEMS = STAGE * (R + 2) * WP, SLOTS = (ITEMS + 255) / 256;
+    constexpr int INNER = (CIN_CHUNK < 16 ? CIN_CHUNK : 16) * 9;
+    constexpr int WSLOTS = (SUB * 16 * 16 * 9 + 255) / 256;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const int p_base = pass * STAGE;
+        if (pass) __syncthreads();
+        // ---- every global load of the pass is issued before the first LDS write (unconditional, clamped addresses: a guarded
+        //      load is not hoisted and costs a memory latency of its own): the band's input rows (+1 halo each side) of STAGE
+        //      channels -- zeros outside the image / beyond c_in -- and the weights of its sub-chunks
+        if (in_mask == nullptr) {
+            float st[SLOTS];
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const int i = t + 256 * u;
+                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+                const int rr = rem / WP, cc = rem - rr * WP;
+                const int y = y0 - 1 + rr, xx = cc - 1;
+                const bool ok = i < ITEMS && y >= 0 && y < W && xx >= 0 && xx < W && p_base + c < c_in;
+                const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                const int ch = p_base + c < c_in ? p_base + c : c_in - 1;
+                const float v = x[(((size_t)n * c_in + ch) * W + yc) * W + xc];
+                st[u] = ok ? v : 0.f;
             }
-            tile[c * PLANE + rr * WP + cc] = v;
-        }
-        // ---- the chunk's weights -> LDS.  forward: row = output channel co0 + r, inner = (cin_local, tap) contiguous in memory;
-        //      input gradient (flip): row = input channel c_base + r (the layer's output channel), inner = (cout_local, tap)
-        {
-            constexpr int INNER = (CIN_CHUNK < 16 ? CIN_CHUNK : 16) * 9;
+            float ws[WSLOTS];
+#pragma unroll
+            for (int u = 0; u < WSLOTS; ++u) {
+                const int i = t + 256 * u;
+                const int inner_n = flip ? 16 * 9 : INNER;
+                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
+                const int r = i2 / inner_n, j = i2 - r * inner_n;
+                const int c_base = p_base + sub * CIN_CHUNK;
+                bool ok = sub < SUB;
+                size_t a;
+                if (flip) { ok = ok && c_base + r < c_in; a = (size_t)(ok ? c_base + r : 0) * w_sin + (size_t)co0 * 9 + j; }
+                else { ok = ok && c_base + j / 9 < c_in; a = (size_t)(co0 + r) * w_sout + (size_t)(ok ? c_base : 0) * 9 + (ok ? j : 0); }
+                const float v = w[a];
+                ws[u] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) {
+                const int i = t + 256 * u;
+                if (i < ITEMS) {
+                    const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+                    tile[c * PLANE + rem] = st[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WSLOTS; ++u) {
+                const int i = t + 256 * u;
+                const int inner_n = flip ? 16 * 9 : INNER;
+                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
+                const int r = i2 / inner_n, j = i2 - r * inner_n;
+                if (sub < SUB) wl[sub * 16 * WROW + r * WROW + j] = ws[u];
+            }
+        } else {
+            // x = a gradient at a ReLU's output, counted only where that ReLU's activation in_mask is > 0 (the U-Net's layers)
+            for (int i = t; i < ITEMS; i += 256) {
+                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+                const int rr = rem / WP, cc = rem - rr * WP;
+                const int y = y0 - 1 + rr, xx = cc - 1;
+                float v = 0.f;
+                if (y >= 0 && y < W && xx >= 0 && xx < W && p_base + c < c_in) {
+                    const size_t idx = (((size_t)n * c_in + p_base + c) * W + y) * W + xx;
+                    v = in_mask[idx] > 0.f ? x[idx] : 0.f;
+                }
+                tile[c * PLANE + rem] = v;
+            }
             const int inner_n = flip ? 16 * 9 : INNER;
-            for (int i = t; i < 16 * inner_n; i += 256) {
-                const int r = i / inner_n, j = i - r * inner_n;
+            for (int i = t; i < SUB * 16 * inner_n; i += 256) {
+                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
+                const int r = i2 / inner_n, j = i2 - r * inner_n;
+                const int c_base = p_base + sub * CIN_CHUNK;
                 float v = 0.f;
                 if (flip) {
                     if (c_base + r < c_in) v = w[(size_t)(c_base + r) * w_sin + (size_t)co0 * 9 + j];
                 } else {
                     if (c_base + j / 9 < c_in) v = w[(size_t)(co0 + r) * w_sout + (size_t)c_base * 9 + j];
                 }
-                wl[r * WROW + j] = v;
+                wl[sub * 16 * WROW + r * WROW + j] = v;
             }
         }
         __syncthreads();
-        // ---- B fragments: B[k = q][n = px] for every (tap, channel group) of this chunk
-        float bf[KSTEPS];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const int tap = s / GROUPS, g = s % GROUPS;
-            const int cl = 4 * g + q;                                // input channel inside the chunk
-            bf[s] = flip ? wl[cl * WROW + px * 9 + (8 - tap)] : wl[px * WROW + cl * 9 + tap];
-        }
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int ti = wave * TPW + i;
-            const int row0 = (W >= 16) ? (ti * 16) / W : ti * 2, col0 = (W >= 16) ? (ti * 16) % W : 0;
-            const int base = q * PLANE + (row0 + lp_r) * WP + col0 + lp_c;      // patch row 0 = image row y0 - 1, column 0 = x = -1
+        for (int sub = 0; sub < SUB; ++sub) {
+            if (p_base + sub * CIN_CHUNK >= c_in) break;              // (uniform) the last pass of a 48- or 16-channel input
+            // ---- B fragments: B[k = q][n = px] for every (tap, channel group) of this sub-chunk
+            float bf[KSTEPS];
+            const float* wsub = wl + sub * 16 * WROW;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 const int tap = s / GROUPS, g = s % GROUPS;
-                const int dy = tap / 3, dx = tap % 3;
-                const float a = tile[base + 4 * g * PLANE + dy * WP + dx];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
+                const int cl = 4 * g + q;                            // input channel inside the sub-chunk
+                bf[s] = flip ? wsub[cl * WROW + px * 9 + (8 - tap)] : wsub[px * WROW + cl * 9 + tap];
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int ti = wave * TPW + i;
+                const int row0 = (W >= 16) ? (ti * 16) / W : ti * 2, col0 = (W >= 16) ? (ti * 16) % W : 0;
+                // patch row 0 = image row y0 - 1, column 0 = x = -1
+                const int base = (sub * CIN_CHUNK + q) * PLANE + (row0 + lp_r) * WP + col0 + lp_c;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const int tap = s / GROUPS, g = s % GROUPS;
+                    const int dy = tap / 3, dx = tap % 3;
+                    const float a = tile[base + 4 * g * PLANE + dy * WP + dx];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
+                }
             }
         }
     }
