@@ -29,7 +29,9 @@ typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
 #define C3_EPI_BIAS_RELU 1
 #define C3_EPI_MASK 2
 
-__host__ __device__ constexpr int c3_band_rows(int W) { return W >= 64 ? 8 : (W == 32 ? 16 : W); }
+// band rows of a workgroup: 8 everywhere -- at the CLI's batch of 32 that makes >= 256 workgroups for every layer of ConvNet
+// (one per CU; 16-row bands left half the chip idle on the 32- and 16-pixel layers)
+__host__ __device__ constexpr int c3_band_rows(int W) { return 8; }
 // band of the weight-gradient kernel: two operand tiles must fit into 64 KB of static LDS
 __host__ __device__ constexpr int c3_wgrad_rows(int W) { return W >= 64 ? 4 : (W == 32 ? 8 : W); }
 // smallest size >= raw with size % 64 == rem (LDS plane strides that put the 4 k-lanes of an operand read on distinct banks)
@@ -232,21 +234,41 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
     for (int u = u_lo; u < u_hi; ++u) {
         const int n = u / bands, y0 = (u % bands) * R;
         if (u != u_lo) __syncthreads();
-        for (int i = t; i < 16 * R * W; i += 256) {
-            const int c = i / (R * W), p = i - c * (R * W);
-            const size_t idx = (((size_t)n * c_out + co0 + c) * W + y0) * W + p;             // a band's rows are contiguous
-            float v = g[idx];
-            if (g_mask && !(g_mask[idx] > 0.f)) v = 0.f;             // g = the gradient at a ReLU's output: times [activation > 0]
-            gt[c * GP + p] = v;
-        }
-        for (int i = t; i < 16 * (R + 2) * WP; i += 256) {
-            const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-            const int rr = rem / WP, cc = rem - rr * WP;
-            const int y = y0 - 1 + rr, xx = cc - 1;
-            float v = 0.f;
-            if (y >= 0 && y < W && xx >= 0 && xx < W && ci0 + c < c_in)
-                v = x[(((size_t)n * c_in + ci0 + c) * W + y) * W + xx];
-            xt[c * XP + rr * WP + cc] = v;
+        {
+            // every global load of the unit before the first LDS write (unconditional, clamped addresses)
+            constexpr int GS = (16 * R * W + 255) / 256, XS = (16 * (R + 2) * WP + 255) / 256;
+            float gv[GS], xv[XS];
+#pragma unroll
+            for (int k = 0; k < GS; ++k) {
+                const int i = t + 256 * k;
+                const int c = i / (R * W), p = i - c * (R * W);
+                const size_t idx = (((size_t)n * c_out + co0 + (c < 16 ? c : 15)) * W + y0) * W + p;      // a band's rows are contiguous
+                float v = g[idx];
+                if (g_mask) v = g_mask[idx] > 0.f ? v : 0.f;         // g = the gradient at a ReLU's output: times [activation > 0]
+                gv[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < XS; ++k) {
+                const int i = t + 256 * k;
+                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
+                const int rr = rem / WP, cc = rem - rr * WP;
+                const int y = y0 - 1 + rr, xx = cc - 1;
+                const bool ok = c < 16 && y >= 0 && y < W && xx >= 0 && xx < W && ci0 + c < c_in;
+                const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                const int ch = ci0 + c < c_in ? ci0 + c : c_in - 1;
+                const float v = x[(((size_t)n * c_in + ch) * W + yc) * W + xc];
+                xv[k] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < GS; ++k) {
+                const int i = t + 256 * k;
+                if (i < 16 * R * W) { const int c = i / (R * W); gt[c * GP + (i - c * (R * W))] = gv[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < XS; ++k) {
+                const int i = t + 256 * k;
+                if (i < 16 * (R + 2) * WP) { const int c = i / ((R + 2) * WP); xt[c * XP + (i - c * ((R + 2) * WP))] = xv[k]; }
+            }
         }
         __syncthreads();
         for (int s = wave; s < KS; s += 4) {
