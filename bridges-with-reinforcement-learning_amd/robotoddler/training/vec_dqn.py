@@ -484,6 +484,7 @@ class VecDQN:
                                           binary.contiguous(), st["reward"], st["obstacle"])
             else:
                 st["block"][:n].copy_(block_f); st["binary"][:n].copy_(binary); st["action"][:n].copy_(action_f)
+                self._guard_snapshot(st)
             st["q"][:n].copy_(q_target)
             if use_sf:
                 st["sf"][:n].copy_(sf_target.reshape(n, -1))
@@ -494,6 +495,8 @@ class VecDQN:
             else:
                 for _ in range(n_steps):
                     st["graph"].replay()
+            if not st.get("fused"):
+                self._guard_restore(st, st["losses"][:n_steps])
             if defer:
                 host = torch.empty(n_steps, dtype=torch.float32, pin_memory=True)
                 host.copy_(st["losses"][:n_steps], non_blocking=True)
@@ -520,6 +523,31 @@ class VecDQN:
             done.record()
             return DeferredLosses(host, done, None)
         return torch.stack(losses).tolist()
+
+    # The replayed autograd step of the conv nets holds library reductions; one of that kind once returned garbage inside a
+    # replayed graph (see _check_graph_losses).  The host learns of a bad loss one lock-step late (deferred read-back), so the
+    # weights are protected ON THE DEVICE: parameters and Adam state are copied before the replays of a call and put back --
+    # a torch.where on a device flag, no host decision -- when any of the call's losses is negative or not finite.  The
+    # call's optimiser steps are then lost, not applied as garbage; the host switches to the eager step when it sees the loss.
+    def _guard_tensors(self):
+        flat = getattr(self.policy_net, "_flat_params", None)
+        ts = [flat.flat] if flat is not None else [p.data for p in self.policy_net.parameters()]
+        for s in self.opt.state.values():
+            ts += [t for t in s.values() if torch.is_tensor(t) and t.is_cuda]
+        return ts
+
+    def _guard_snapshot(self, st):
+        ts = self._guard_tensors()
+        snap = st.get("guard")
+        if snap is None or len(snap) != len(ts) or any(a.shape != b.shape for a, b in zip(snap, ts)):
+            st["guard"] = [t.clone() for t in ts]
+        else:
+            torch._foreach_copy_(snap, ts)
+
+    def _guard_restore(self, st, losses):
+        bad = ~(torch.isfinite(losses).all() & (losses >= 0).all())
+        for t, s in zip(self._guard_tensors(), st["guard"]):
+            torch.where(bad, s, t, out=t)
 
     def _check_graph_losses(self, losses):
         """Guard for the anomaly recorded in DESIGN.md: a multi-workgroup reduction inside a replayed graph once returned

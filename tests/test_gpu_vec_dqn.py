@@ -663,3 +663,35 @@ def test_acting_on_shared_rows_selects_what_acting_on_every_row_selects():
             agent.ring.push(rec[valid])
     finally:
         VecDQN.DEDUP_STATES = True
+
+
+def test_graph_guard_puts_weights_and_adam_state_back_on_the_device(monkeypatch):
+    """The conv nets' replayed autograd step: parameters and Adam state are copied before the replays of a call and restored by a
+    device-side torch.where when one of the call's losses is negative or not finite -- no host decision in between; good losses
+    leave the updated weights alone."""
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    from robotoddler.training.vec_dqn import VecDQN
+    monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", "1")
+    args = vars(build_parser().parse_args(["--model", "ConvNet", "--loss_function", "mse_q_values"]))
+    dev = torch.device("cuda")
+    env = make_env(64, seed=3, tower=2, max_steps=10)
+    torch.manual_seed(2)
+    pol, tgt = make_nets(args, dev)
+    agent = VecDQN(pol, tgt, torch.optim.Adam(pol.parameters(), lr=1e-4, fused=True), env, 10000, 16, 0.95, 0.01, "mse_q_values", seed=1)
+    for _ in range(5):
+        losses, _ = agent.lockstep(2)
+    st = agent._graph_state
+    assert st is not None and not st.get("fused") and "guard" in st          # the captured autograd step ran, with its snapshot
+    tensors = agent._guard_tensors()
+    assert len(tensors) > 10                                                  # flat parameters + every Adam moment / step count
+    agent._guard_snapshot(st)
+    before = [t.clone() for t in tensors]
+    for t in tensors:
+        t.add_(1)
+    agent._guard_restore(st, torch.tensor([0.5, 0.25], device=dev))           # good losses: nothing is put back
+    assert all(torch.equal(t, b + 1) for t, b in zip(tensors, before))
+    for bad in ([0.5, -1e-3], [float("nan"), 0.1], [float("inf"), 0.1]):
+        for t in tensors:
+            t.fill_(float("nan")) if t.is_floating_point() else t.zero_()
+        agent._guard_restore(st, torch.tensor(bad, device=dev))
+        assert all(torch.equal(t, b) for t, b in zip(tensors, before)), bad
