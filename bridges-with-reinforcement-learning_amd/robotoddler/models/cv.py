@@ -15,9 +15,6 @@ from torch import nn
 import torch.nn.functional as F
 
 
-K_C3_INFERENCE = False     # tools/conv_infer_bench.py flips it: the deeper layers' inference through k_c3 instead of the library
-
-
 def _fused_inference(x):
     """True when the fused epilogues apply: no autograd graph is being recorded, float32 tensors on the GPU."""
     return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype == torch.float32
@@ -28,10 +25,6 @@ def _conv_relu(conv, x, pool=False):
     from bridges_hip import dqn_ops
     if dqn_ops.conv3x3_relu_o16_applies(x, conv):           # the 64-wide, 16-channel layers: hand-written MFMA kernel
         return dqn_ops.conv3x3_relu_o16(x, conv.weight, conv.bias, pool)
-    if K_C3_INFERENCE and dqn_ops.conv3x3_supported(x, conv.out_channels) and tuple(conv.kernel_size) == (3, 3) \
-            and tuple(conv.padding) == (1, 1) and tuple(conv.stride) == (1, 1) and conv.groups == 1:
-        a = dqn_ops.conv3x3(x, conv.weight, bias=conv.bias)  # the training kernel's forward: bias + ReLU in its epilogue
-        return dqn_ops.maxpool2(a) if pool else a
     y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups).contiguous()
     if pool:
         return dqn_ops.bias_relu_pool2(y, conv.bias)
