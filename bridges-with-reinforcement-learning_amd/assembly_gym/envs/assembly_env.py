@@ -147,18 +147,32 @@ class Block(Shape):
         self._target_faces_2d = None           # Block drops the shape's face restrictions (assembly_env.py:153)
         self._receiving_faces_2d = None
         self.position = [float(position[0]), float(position[1]), float(position[2])]
-        self.orientation = orientation if orientation is not None else Quaternion(1., 0., 0., 0.)
         self.object_id = object_id
         self.is_static = False
+        self._bounding_box = None
         if _posed is not None:                 # (pose, verts, frames) straight from bridges_create_block
             self.pose, self._verts, self._frames_w = _posed
+            self._orientation = orientation    # None: made from the pose's (cos, sin) when somebody asks (most candidates never do)
         else:
-            c, s = self.orientation.cos_sin() if hasattr(self.orientation, "cos_sin") else Quaternion(*self.orientation).cos_sin()
+            self._orientation = orientation if orientation is not None else Quaternion(1., 0., 0., 0.)
+            c, s = self._orientation.cos_sin() if hasattr(self._orientation, "cos_sin") else Quaternion(*self._orientation).cos_sin()
             self.pose = np.array([self.position[0], self.position[2], c, s], dtype=np.float64)
             self._verts, self._frames_w = ops.pose_block(self.geometry, self.pose)
-        hy = self.geometry.depth / 2.0
-        xs, zs = self._verts[:, 0], self._verts[:, 1]
-        self.bounding_box = AABB(xs.min(), self.position[1] - hy, zs.min(), xs.max(), self.position[1] + hy, zs.max())
+
+    @property
+    def orientation(self):
+        if self._orientation is None:
+            self._orientation = Quaternion.from_cos_sin(float(self.pose[2]), float(self.pose[3]))
+        return self._orientation
+
+    @property
+    def bounding_box(self):
+        """mesh.aabb() of the posed block -- computed when first asked for: a state's ~60 candidate blocks never are."""
+        if self._bounding_box is None:
+            hy = self.geometry.depth / 2.0
+            xs, zs = self._verts[:, 0], self._verts[:, 1]
+            self._bounding_box = AABB(xs.min(), self.position[1] - hy, zs.min(), xs.max(), self.position[1] + hy, zs.max())
+        return self._bounding_box
 
     @property
     def verts_2d(self):

@@ -169,9 +169,7 @@ class AssemblyGym:
             posed = ops.create_blocks(targets, [a.target_face for a in acts], [sh.geometry for sh in shapes],
                                       [a.face for a in acts], [a.offset_x for a in acts], [a.offset_y for a in acts])
             for i, sh, (pose, verts, frames) in zip(todo, shapes, posed):
-                self._block_cache[keys[i]] = Block(sh, position=[pose[0], 0.0, pose[1]],
-                                                   orientation=Quaternion.from_cos_sin(pose[2], pose[3]),
-                                                   _posed=(pose, verts, frames))
+                self._block_cache[keys[i]] = Block(sh, position=[pose[0], 0.0, pose[1]], _posed=(pose, verts, frames))
         return [self._block_cache[k] for k in keys]
 
     def step(self, action: Action):
