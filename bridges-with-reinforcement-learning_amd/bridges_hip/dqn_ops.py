@@ -276,6 +276,40 @@ class Conv3x3ReLUFunction(torch.autograd.Function):
         return dx, dw, db
 
 
+class BiasAddFunction(torch.autograd.Function):
+    """y = x + bias[None, :, None, None] for the output of a bias-free library convolution, with the bias gradient by
+    bridges_bias_grad (deterministic, no multi-workgroup reduction): what makes a training step that still holds library
+    convolutions (the U-Net's transposed and 1x1 layers) safe to replay from a HIP graph."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = abi.require_gpu()
+        dy = dy.contiguous()
+        n, c = dy.shape[0], dy.shape[1]
+        hw = dy[0, 0].numel()
+        db = torch.empty(c, dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(min(n, 32) * c, dtype=torch.float32, device=dy.device)
+        abi.check(L.bridges_bias_grad(_ptr(dy), _ptr(db), _ptr(scratch), scratch.numel(), n, c, hw, _stream()), "bridges_bias_grad")
+        return dy, db
+
+
+def conv_bias_train(module, x):
+    """module(x) for a Conv2d / ConvTranspose2d of a training pass on the GPU: the library's convolution without its bias, the
+    bias through BiasAddFunction."""
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and module.bias is not None):
+        return module(x)
+    if isinstance(module, torch.nn.ConvTranspose2d):
+        y = torch.nn.functional.conv_transpose2d(x, module.weight, None, module.stride, module.padding, module.output_padding,
+                                                 module.groups, module.dilation)
+    else:
+        y = torch.nn.functional.conv2d(x, module.weight, None, module.stride, module.padding, module.dilation, module.groups)
+    return BiasAddFunction.apply(y, module.bias)
+
+
 def conv3x3_relu_train(conv, x):
     """relu(conv(x)) for a training pass: the hand-written Function where it applies, else the library."""
     if (torch.is_grad_enabled() and conv3x3_supported(x, conv.out_channels) and tuple(conv.kernel_size) == (3, 3)

@@ -1109,3 +1109,15 @@ int bridges_maxpool2_relu_backward(const float* a, const float* dy, float* g, in
     LAUNCH_CHECK("k_maxpool2_relu_bwd");
     return BRIDGES_OK;
 }
+
+int bridges_bias_grad(const float* g, float* db, float* scratch, int64_t scratch_floats, int64_t n, int32_t C, int32_t hw, void* stream) {
+    if (!g || !db || !scratch || n < 1 || C < 1 || hw < 1) return fail_arg("bridges_bias_grad");
+    int S = (int)(n < 32 ? n : 32);
+    if (scratch_floats < (int64_t)S * C) return fail_arg("bridges_bias_grad: scratch needs min(n, 32) * C floats");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bias_grad_part, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, scratch, (int)n, C, hw, S);
+    LAUNCH_CHECK("k_bias_grad_part");
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (const float*)scratch, db, db, 0, C, S);
+    LAUNCH_CHECK("k_c3_reduce");
+    return BRIDGES_OK;
+}

@@ -336,6 +336,28 @@ __global__ __launch_bounds__(256) void k_c3_reduce(const float* __restrict__ par
     }
 }
 
+// Bias gradient of a convolution whose weights stay with the library (the U-Net's transposed and 1x1 convolutions):
+// part[s][c] = sum of g[n, c, :] over the images n = s, s + S, ...; k_c3_reduce adds the S partial sums in a fixed order.
+// torch's own sum over (N, H, W) is a multi-workgroup reduction with a semaphore -- the kind that returned garbage inside a
+// replayed HIP graph (vec_dqn._check_graph_losses) -- and not reproducible from run to run; this one is both.
+__global__ __launch_bounds__(256) void k_bias_grad_part(const float* __restrict__ g, float* __restrict__ part, int N, int C, int hw,
+                                                        int S) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, s = blockIdx.y, t = threadIdx.x;
+    float acc = 0.f;
+    for (int n = s; n < N; n += S) {
+        const float* p = g + ((size_t)n * C + c) * hw;
+        for (int i = t; i < hw; i += 256) acc += p[i];
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) part[(size_t)s * C + c] = red[0];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // y [n*C, H/2, W/2] = MaxPool2d(2)(a [n*C, H, W]); one thread per output pixel pair row (2 outputs: 4 input columns x 2 rows).
 __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ a, float* __restrict__ y, int64_t items, int H, int W) {

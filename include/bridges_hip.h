@@ -532,6 +532,9 @@ int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_
 int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
                           int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream);
 int bridges_maxpool2(const float* a, float* y, int64_t nc, int32_t H, int32_t W, void* stream);
+/* db [C] = sum over n and the hw pixels of g [n, C, hw] in a fixed order (deterministic, single-workgroup stages): the bias
+ * gradient of a convolution whose weights stay with the library.  scratch: min(n, 32) * C floats. */
+int bridges_bias_grad(const float* g, float* db, float* scratch, int64_t scratch_floats, int64_t n, int32_t C, int32_t hw, void* stream);
 int bridges_maxpool2_relu_backward(const float* a, const float* dy, float* g, int64_t nc, int32_t H, int32_t W, void* stream);
 
 #ifdef __cplusplus

@@ -185,3 +185,17 @@ def test_unet_policy_optimiser_steps_follow_the_library_path():
     np.testing.assert_allclose(losses[0], losses[1], rtol=2e-4)              # after one / two Adam updates (losses of O(100))
     for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
         assert rel(pa.detach(), pb.detach()) < 5e-4
+
+
+@pytest.mark.parametrize("n,c,hw", [(32, 1, 4096), (32, 16, 4096), (5, 32, 1024), (64, 7, 36)])
+def test_bias_grad_is_the_channel_sum_and_deterministic(n, c, hw):
+    from bridges_hip import dqn_ops
+    x = rnd(n, c, hw, 1, seed=60).requires_grad_(True)
+    b = rnd(c, seed=61).requires_grad_(True)
+    y = dqn_ops.BiasAddFunction.apply(x, b)
+    assert torch.equal(y.detach(), x.detach() + b.detach().view(1, -1, 1, 1))
+    dy = rnd(n, c, hw, 1, seed=62)
+    dx, db = torch.autograd.grad(y, [x, b], dy)
+    assert torch.equal(dx, dy) and rel(db, dy.sum(dim=(0, 2, 3))) < 2e-6
+    _, db2 = torch.autograd.grad(dqn_ops.BiasAddFunction.apply(x, b), [x, b], dy)
+    assert torch.equal(db, db2)
