@@ -440,13 +440,14 @@ class VecDQN:
         (tests/test_gpu_vec_dqn.py), and on for ConvNet: its ConvBlocks run forward and backward on the hand-written
         kernels (deterministic partial-sum reductions, csrc/conv_train_kernels.hip), what is left of the library in its step
         are single-workgroup reductions over the 32 batch rows, the eager step is bound by the host (1.2 ms of Python and
-        launches for 0.57 ms of GPU work), and the replays run under the on-device restore guard (_guard_restore).  Off for
-        the U-Net policy: its transposed and 1x1 convolutions still go through the library, whose bias-gradient reductions
-        over 131 k elements are of the multi-workgroup kind that once misbehaved inside a replay.  BRIDGES_TRAIN_GRAPH=0/1
-        overrides.  The first calls always run eagerly (they initialise the optimiser state and the library workspaces a
+        launches for 0.57 ms of GPU work), and the replays run under the on-device restore guard (_guard_restore).  On for
+        the U-Net policy as well: its 3x3 convolutions are the hand-written ones, its transposed and 1x1 convolutions stay with
+        the library but without their bias, whose gradient -- a sum over 131 k elements that torch reduces with the
+        multi-workgroup kernel that once misbehaved inside a replay -- comes from bridges_bias_grad (dqn_ops.conv_bias_train).
+        BRIDGES_TRAIN_GRAPH=0/1 overrides.  The first calls always run eagerly (they initialise the optimiser state and the library workspaces a
         capture needs)."""
-        from robotoddler.models.cv import ConvNet, SuccessorMLP
-        default = "1" if isinstance(self.policy_net, (SuccessorMLP, ConvNet)) else "0"
+        from robotoddler.models.cv import ConvNet, Policy, SuccessorMLP
+        default = "1" if isinstance(self.policy_net, (SuccessorMLP, ConvNet, Policy)) else "0"
         if os.environ.get("BRIDGES_TRAIN_GRAPH", default) != "1":
             return None
         st = self._graph_state

@@ -239,7 +239,9 @@ def test_batched_targets_equal_per_batch_targets():
 
 @pytest.mark.parametrize("model,loss,E,n_steps,locksteps", [("SuccessorMLP", "mse_q_values+mse_block_features", 64, 3, 6),
                                                             ("SuccessorMLP", "mse_block_features", 4096, 25, 14),
-                                                            ("ConvNet", "mse_q_values", 64, 3, 6)])
+                                                            ("ConvNet", "mse_q_values", 64, 3, 6),
+                                                            ("UNet", "mse_q_values+mse_block_features", 64, 3, 6),
+                                                            ("UNet", "mse_q_values+mse_block_features", 256, 8, 8)])
 def test_graph_captured_train_step_equals_eager(model, loss, E, n_steps, locksteps, monkeypatch):
     """The HIP-graph train step (third call onwards) performs the same optimiser steps and logs the same losses as
     eager PyTorch; the 4096-env case is the BASELINE.json configs[2] shape (25 steps of batch 32 per lock-step), the
