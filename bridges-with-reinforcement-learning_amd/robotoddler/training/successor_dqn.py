@@ -145,15 +145,84 @@ class _FusedTrainer:
         self.loss1 = torch.zeros(1, dtype=torch.float32, device=dev)
 
     @staticmethod
-    def applies(policy_net, optimizer, loss_parts, scheduler, transitions, batch):
+    def applies(policy_net, optimizer, loss_parts, scheduler, transitions, batch=None, device=None):
         if scheduler is not None or not isinstance(policy_net, SuccessorMLP) or getattr(policy_net, "_flat_params", None) is None:
             return False
         if not set(loss_parts) <= {'mse_q_values', 'mse_block_features'} or type(optimizer) is not torch.optim.Adam:
             return False
-        if not transitions or not batch.block_features.is_cuda or batch.block_features.dtype != torch.float32:
+        if not transitions:
+            return False
+        if batch is not None:
+            if not batch.block_features.is_cuda or batch.block_features.dtype != torch.float32:
+                return False
+        elif torch.device(device).type != 'cuda' or any(t.block_features.dtype != torch.float32 for t in transitions):
             return False
         keys = {getattr(t.reward_features, "_task_key", None) for t in transitions}
         return len(keys) == 1 and None not in keys and all(getattr(t.obstacle_features, "_task_key", None) in keys for t in transitions)
+
+    @classmethod
+    def of(cls, policy_net, optimizer, batch_size, loss_parts):
+        """The net's trainer for this optimiser / batch size / loss, built on first use; None if the optimiser is not a plain
+        Adam over the flattened parameters."""
+        tr = getattr(policy_net, "_fused_trainer", None)
+        if tr is None or tr.key != (id(optimizer), batch_size, tuple(loss_parts)):
+            try:
+                sync_fused_optimizer(policy_net)
+                tr = policy_net._fused_trainer = cls(policy_net, optimizer, batch_size, loss_parts)
+            except ValueError:
+                return None
+        return tr
+
+    def run_all(self, drawn, target_net, gamma, device):
+        """All optimiser steps of one train_policy_net call: ``drawn`` = the sampled transitions of every step.  The target net
+        does not change inside the call, so the TD targets of all steps come from ONE target forward and ONE segmented argmax
+        over all next-action rows, and the steps are launch sequences that read their batch by a device-side counter
+        (FusedSuccessorStep.launch): per step the host queues 11 launches and nothing else.  The rows of a next state are
+        gathered from one copy per transition; the task's reward / obstacle rasters are the same image for every row."""
+        n, st = len(drawn), self.step
+        B, px = st.batch, st.px
+        flat = [t for b in drawn for t in b]
+        cat = lambda field: torch.cat([getattr(t, field) for t in flat]).to(device=device)
+        block, action, binary = cat('block_features'), cat('action_features'), cat('binary_features')
+        lin = cat('lin_reward').reshape(n, B).float()
+        counts = [t.next_actions_features.shape[0] for t in flat]
+        num_actions = [max(1, len(t.next_available_actions)) for t in flat]
+        assert counts == num_actions, "a next state's action rows and its action list differ in length"
+        seg_np = np.zeros(len(flat) + 1, dtype=np.int32)
+        np.cumsum(num_actions, out=seg_np[1:])
+        owner = np.repeat(np.arange(len(flat), dtype=np.int64), num_actions)
+        seg, done, owner = ops.upload(device, seg_np, np.asarray([t.done for t in flat], dtype=np.bool_), owner)
+        rows = int(seg_np[-1])
+        reward, obstacle = flat[0].reward_features.to(device), flat[0].obstacle_features.to(device)
+        with torch.no_grad():
+            one_row = lambda x: x.shape[0] == 1 or x.stride(0) == 0              # rollout_episode stores expand()ed views
+            if all(one_row(t.next_block_features) and one_row(t.next_binary_features) for t in flat):
+                nb = torch.cat([t.next_block_features[:1] for t in flat]).to(device).index_select(0, owner)
+                nbin = torch.cat([t.next_binary_features[:1] for t in flat]).to(device).index_select(0, owner)
+            else:
+                nb, nbin = cat('next_block_features'), cat('next_binary_features')
+            next_q, next_sf, _ = target_net(nb, nbin, cat('next_actions_features'), reward.expand(rows, -1, -1, -1),
+                                            obstacle.expand(rows, -1, -1, -1))
+            zeros = torch.zeros(len(flat), dtype=torch.float32, device=device)
+            nq = next_q.contiguous().float()
+            q_sel, _, _ = dqn_ops.td_target(seg, nq, zeros, done, 1.0)
+            sf_target = None
+            if self.use_sf:
+                _, sf_target, _ = dqn_ops.td_target(seg, nq, zeros, done, gamma, next_sf=next_sf[:, 0], action_raster=action.squeeze(1))
+                sf_target = sf_target.reshape(n * B, px).contiguous()
+            st.check_hyperparameters()
+            q_target = extra = None
+            if self.use_q:
+                m = lin.mean(dim=1, keepdim=True)
+                q_target = (m + gamma * q_sel.view(n, B)).reshape(-1).contiguous()
+                extra = ((lin - m) ** 2).mean(dim=1)
+            losses = torch.zeros(n, dtype=torch.float32, device=device)
+            self.counter.zero_()
+            args = (block.reshape(n * B, px).contiguous(), action.reshape(n * B, px).contiguous(), binary.contiguous(),
+                    reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous(), q_target, sf_target, losses)
+            for _ in range(n):
+                st.launch(self.counter, *args)
+        return losses + extra if extra is not None else losses
 
     def run(self, batch, q_sel, sf_target, gamma):
         B = batch.block_features.shape[0]
@@ -192,17 +261,27 @@ def train_policy_net(policy_net, target_net, optimizer, replay_buffer, gamma, lo
     target_net.eval()
     mse = torch.nn.MSELoss()
     losses = []
-    for _ in range(n_steps):
-        transitions, batch = replay_buffer.sample(batch_size=batch_size, stack_tensors=True, device=device)
+    # the draws of all steps first: they depend on the buffer and the random generators only, which the steps do not touch
+    # (a buffer without draw(): one sample() per step, as the reference)
+    draw = getattr(replay_buffer, "draw", None)
+    if draw is not None:
+        from robotoddler.utils.replay_memory import _stack
+        drawn = [draw(batch_size) for _ in range(n_steps)]
+        if batch_size is not None and _FusedTrainer.applies(policy_net, optimizer, loss_fct, scheduler, [t for b in drawn for t in b], device=device):
+            tr = _FusedTrainer.of(policy_net, optimizer, batch_size, loss_fct)
+            if tr is not None:
+                out = []
+                for k in range(0, n_steps, 64):           # (bounds the target pass: 64 steps x 32 transitions x their next actions)
+                    out.append(tr.run_all(drawn[k:k + 64], target_net, gamma, device))
+                return torch.cat(out).tolist()            # ONE host read for all steps
+        steps = ((transitions, _stack(transitions, device)) for transitions in drawn)
+    else:
+        steps = (replay_buffer.sample(batch_size=batch_size, stack_tensors=True, device=device) for _ in range(n_steps))
+    for transitions, batch in steps:
         fused = _FusedTrainer.applies(policy_net, optimizer, loss_fct, scheduler, transitions, batch)
         if fused:
-            tr = getattr(policy_net, "_fused_trainer", None)
-            if tr is None or tr.key != (id(optimizer), batch.block_features.shape[0], tuple(loss_fct)):
-                try:
-                    sync_fused_optimizer(policy_net)
-                    tr = policy_net._fused_trainer = _FusedTrainer(policy_net, optimizer, batch.block_features.shape[0], loss_fct)
-                except ValueError:
-                    fused = False
+            tr = _FusedTrainer.of(policy_net, optimizer, batch.block_features.shape[0], loss_fct)
+            fused = tr is not None
         if not fused and getattr(policy_net, "_fused_trainer", None) is not None:
             sync_fused_optimizer(policy_net)                  # optimizer.step() takes over: it needs the true step count,
             policy_net._fused_trainer = None                  # and a later fused batch adopts the optimiser's state afresh

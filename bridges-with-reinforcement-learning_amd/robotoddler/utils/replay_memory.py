@@ -67,8 +67,12 @@ class ReplayBuffer:
         items, maxlen, _ = _load_plain(path)
         self.memory = items if maxlen is None else deque(items, maxlen=maxlen)
 
+    def draw(self, batch_size=None):
+        """The transitions of one sample() call, unstacked (the same use of the random generator)."""
+        return self.memory if batch_size is None else random.sample(self.memory, batch_size)
+
     def sample(self, batch_size=None, stack_tensors=False, device=None):
-        batch = self.memory if batch_size is None else random.sample(self.memory, batch_size)
+        batch = self.draw(batch_size)
         if stack_tensors:
             return batch, _stack(batch, device)
         return batch, batch[0].__class__(*zip(*batch))
@@ -98,15 +102,17 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         self.memory = items if maxlen is None else deque(items, maxlen=maxlen)
         self.priorities = list(pr) if maxlen is None else deque(pr, maxlen=maxlen)
 
-    def sample(self, batch_size=None, stack_tensors=False, device=None):
+    def draw(self, batch_size=None):
         if batch_size is None:
-            batch = self.memory
-        else:
-            pr = [p.cpu().item() if isinstance(p, torch.Tensor) else p for p in self.priorities]
-            total = sum(pr)
-            probs = [1 / len(pr)] * len(pr) if total < 1e-10 else [p / total for p in pr]
-            idx = np.random.choice(len(self.memory), batch_size, p=probs)
-            batch = [self.memory[i] for i in idx]
+            return self.memory
+        pr = [p.cpu().item() if isinstance(p, torch.Tensor) else p for p in self.priorities]
+        total = sum(pr)
+        probs = [1 / len(pr)] * len(pr) if total < 1e-10 else [p / total for p in pr]
+        idx = np.random.choice(len(self.memory), batch_size, p=probs)
+        return [self.memory[i] for i in idx]
+
+    def sample(self, batch_size=None, stack_tensors=False, device=None):
+        batch = self.draw(batch_size)
         if stack_tensors:
             return batch, _stack(batch, device)
         return batch, batch[0].__class__(*zip(*batch))

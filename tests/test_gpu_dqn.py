@@ -540,6 +540,9 @@ def test_train_policy_net_on_the_hand_written_step_follows_the_autograd_form(los
         n1 = t.next_block_features.shape[0]
         d = {f: dev_t(getattr(t, f)) for f in t._fields}
         d.update(next_reward_features=reward.expand(n1, -1, -1, -1), next_obstacle_features=obstacle.expand(n1, -1, -1, -1))
+        if B == 32:             # the next state's rows as rollout_episode stores them: expand()ed views of one row (gathered by
+            d.update(next_block_features=d["next_block_features"][:1].expand(n1, -1, -1, -1),        # run_all; else: concatenated)
+                     next_binary_features=d["next_binary_features"][:1].expand(n1, -1))
         plain.append(Transition(**dict(d, reward_features=reward.clone(), obstacle_features=obstacle.clone())))
         shared.append(Transition(**dict(d, reward_features=S._tagged(reward.clone(), key), obstacle_features=S._tagged(obstacle.clone(), key))))
     torch.manual_seed(1)
