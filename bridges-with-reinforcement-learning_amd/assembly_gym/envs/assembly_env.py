@@ -190,6 +190,14 @@ def is_stable_rbe(assembly_env):
     return f(assembly_env)
 
 
+def _is_stable_rbe_variants(assembly_env, fixed_sets):
+    from assembly_gym.utils.stability import is_stable_rbe as f
+    return f.variants(assembly_env, fixed_sets)
+
+
+is_stable_rbe.variants = _is_stable_rbe_variants
+
+
 class _StateInfo(dict):
     """AssemblyEnv.state_info with the stability verdict computed on first access ('stable' / 'stability_info'), for the
     (blocks, frozen set) the environment held when the dictionary was made."""
@@ -308,7 +316,19 @@ class AssemblyEnv:
             if not memo or key not in cache:
                 if len(cache) > 64:
                     cache.clear()
-                cache[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique
+                variants = getattr(self.stability_fct, "variants", None)
+                flags = key[1]
+                if memo and variants is not None and self.blocks:
+                    # the same blocks with the last one's frozen flag the other way round ride in the same operator call:
+                    # AssemblyGym.step freezes the new block, solves, and stabilities_freezing() then asks for it free
+                    # (gym_env.py:238-243, :325-333 of the reference) -- one launch and one copy back instead of two
+                    other = flags[:-1] + (not flags[-1],)
+                    sets = [{i for i, f in enumerate(fl) if f} for fl in (flags, other)]
+                    first, second = variants(self, sets)
+                    cache[key] = (first, list(self.blocks))
+                    cache.setdefault((key[0], other) + key[2:], (second, list(self.blocks)))
+                else:
+                    cache[key] = (self.stability_fct(self), list(self.blocks))      # the blocks are kept alive: ids stay unique
             return cache[key][0]
         finally:
             if not same:

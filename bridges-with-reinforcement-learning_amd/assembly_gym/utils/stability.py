@@ -26,6 +26,16 @@ def is_stable_rbe(assembly_env):
     return stable, None
 
 
+def _is_stable_rbe_variants(assembly_env, fixed_sets):
+    """is_stable_rbe's answers for the environment's blocks under each frozen set of ``fixed_sets`` (one operator call)."""
+    res = ops.stability_variants(assembly_env.blocks, fixed_sets, assembly_env.mu, assembly_env.density,
+                                 assembly_env.floor_half_width, assembly_env.floor_depth)
+    return [(None, info) if stable is None else (stable, None) for stable, info in res]
+
+
+is_stable_rbe.variants = _is_stable_rbe_variants
+
+
 def is_stable_rbe_penalty(assembly_env, tol=1e-3):
     """(stable, {'max_tension': ...}) as stability.py:75-88; an assembly without any contact returns (no free block, None)
     like the reference (:77-81).  PARITY UNPINNED -- the reference holds no output of this variant -- and not the same

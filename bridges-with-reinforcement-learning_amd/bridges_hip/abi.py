@@ -288,3 +288,10 @@ def require_gpu():
         raise BridgesHipError("no MI355X / HIP device visible: the assembly_gym hot path runs only on the "
                               "HIP kernels of libbridges_hip.so (no CPU fallback)")
     return L
+
+
+def current_stream():
+    """torch's current stream of the current device as the C ABI's ``void* stream`` (the raw getter: a tenth of the cost of
+    building a torch.cuda.Stream object per operator call)."""
+    import torch
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -10,8 +10,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = abi.current_stream
 
 
 def td_target(seg_offset, next_q, lin_reward, done, gamma, next_sf=None, action_raster=None):

@@ -17,8 +17,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = abi.current_stream
 
 
 class ShapeRegistry:
@@ -51,6 +50,9 @@ class ShapeRegistry:
 REGISTRY = ShapeRegistry()
 
 
+_TORCH_DTYPE = {np.dtype(n): getattr(torch, n) for n in ("float32", "float64", "int32", "int64", "uint8", "int8", "int16", "bool")}
+
+
 class _Stager:
     """Small host arrays -> device tensors through ONE pinned staging buffer and ONE asynchronous copy per call.
 
@@ -66,34 +68,32 @@ class _Stager:
         self.slots, self.turn = [], 0
 
     def upload(self, dev, *arrays):
-        arrays = [np.ascontiguousarray(a) for a in arrays]
+        arrays = [a if a.flags.c_contiguous else np.ascontiguousarray(a) for a in arrays]
         offs, total = [], 0
         for a in arrays:
             offs.append(total)
             total += -(-max(a.nbytes, 1) // 16) * 16
         if len(self.slots) < self.SLOTS:
-            self.slots.append([torch.empty(max(total, self.MIN_BYTES), dtype=torch.uint8).pin_memory(), None])
+            pinned = torch.empty(max(total, self.MIN_BYTES), dtype=torch.uint8).pin_memory()
+            self.slots.append([pinned, torch.cuda.Event(), pinned.numpy()])     # buffer, "copy done" event, numpy view
             slot = self.slots[-1]
         else:
             slot = self.slots[self.turn]
             self.turn = (self.turn + 1) % self.SLOTS
-            if slot[1] is not None:
-                slot[1].synchronize()                       # (passed long ago unless 16 uploads are in flight)
+            slot[1].synchronize()                           # (passed long ago unless 16 uploads are in flight)
             if slot[0].numel() < total:
                 slot[0] = torch.empty(total, dtype=torch.uint8).pin_memory()
-        host = slot[0].numpy()
+                slot[2] = slot[0].numpy()
+        host = slot[2]
         for a, off in zip(arrays, offs):
             host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
         d = torch.empty(total, dtype=torch.uint8, device=dev)
         d.copy_(slot[0][:total], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        slot[1] = ev
-        out = []
-        for a, off in zip(arrays, offs):
-            t = d[off:off + a.nbytes].view(getattr(torch, a.dtype.name))
-            out.append(t.reshape(a.shape))
-        return out
+        slot[1].record()
+        if len(arrays) == 1:
+            a = arrays[0]
+            return [d[:a.nbytes].view(_TORCH_DTYPE[a.dtype]).reshape(a.shape)]
+        return [d[off:off + a.nbytes].view(_TORCH_DTYPE[a.dtype]).reshape(a.shape) for a, off in zip(arrays, offs)]
 
 
 _STAGER = _Stager()
@@ -465,6 +465,43 @@ def stability(blocks, fixed, mu, density, floor_half_width, floor_depth, tension
     if forces is not None:
         out["forces"] = fo[:int(inf[1])]
     return bool(st[0]), out
+
+
+def stability_variants(blocks, fixed_sets, mu, density, floor_half_width, floor_depth):
+    """is_stable_rbe of the SAME blocks under several frozen sets, in one operator call and one copy back: a list of
+    (stable, info) as ``stability`` returns them.  (AssemblyGym.step asks for the new block frozen and, right after, for it
+    free: gym_env.py:238-243 with :325-333 of the reference.)"""
+    L = abi.require_gpu()
+    dev = device()
+    K = abi.MAX_BLOCKS
+    n, m = len(blocks), len(fixed_sets)
+    if n > K:
+        raise abi.BridgesHipError(f"{n} blocks > BRIDGES_MAX_BLOCKS ({K})")
+    if n == 0:
+        return [(True, dict(objective=0.0, n_interfaces=0, pivots=0)) for _ in fixed_sets]
+    pose = np.zeros((m, K, 4))
+    verts = np.zeros((m, K, 6, 2))
+    ids = np.zeros((m, K), dtype=np.int32)
+    for i, b in enumerate(blocks):
+        pose[:, i] = b.pose
+        verts[:, i, :len(b.verts_2d)] = b.verts_2d
+        ids[:, i] = REGISTRY.id_of(b.geometry)
+    masks = np.array([sum(1 << i for i in fixed if i < n) for fixed in fixed_sets], dtype=np.int32)
+    tab = REGISTRY.device_table()
+    ws_stride = abi.lp_ws_stride(K)
+    ws = torch.empty((m, ws_stride), dtype=torch.float64, device=dev)
+    stable = torch.zeros(m, dtype=torch.uint8, device=dev)
+    info = torch.zeros((m, 8), dtype=torch.float64, device=dev)
+    a_pose, a_verts, a_ids, a_n, a_mask = upload(dev, pose, verts, ids, np.full(m, n, dtype=np.int32), masks)
+    abi.check(L.bridges_stability(tab, m, K, _ptr(a_pose), _ptr(a_verts), _ptr(a_ids), _ptr(a_n), _ptr(a_mask),
+                                  float(mu), float(density), float(floor_half_width), float(floor_depth),
+                                  _ptr(stable), _ptr(info), _ptr(ws), ws_stride, _stream()), "bridges_stability")
+    inf, st = download(info, stable)
+    out = []
+    for j in range(m):
+        d = dict(objective=float(inf[j, 0]), n_interfaces=int(inf[j, 1]), pivots=int(inf[j, 2]))
+        out.append((None, dict(d, error="lp")) if inf[j, 3] != 0 else (bool(st[j]), d))
+    return out
 
 
 def create_blocks(target_blocks, target_faces, geoms, faces, oxs, oys):

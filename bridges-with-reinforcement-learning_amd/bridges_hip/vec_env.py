@@ -31,8 +31,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = abi.current_stream
 
 
 def gaussian_reward_map(target_image, kernel_size=101, sigma=16):

@@ -143,6 +143,35 @@ class _FusedTrainer:
         dev = self.step.flat.device
         self.counter = torch.zeros((), dtype=torch.int64, device=dev)
         self.loss1 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._graphs, self._seen = {}, {}
+
+    def _steps(self, n, *tensors):
+        """n optimiser steps on the n batches in ``tensors`` (block, action, binary, reward, obstacle, q target, sf target,
+        losses).  The first call with a given n queues n x 11 launches; from the second on the sequence is one HIP graph over
+        static copies of the inputs (a launch costs the host ~7 us, a step is ~100 us of GPU work: queued one by one the host
+        and the GPU take about the same time, as a graph the host is free after one launch).  BRIDGES_TRAIN_GRAPH=0: never."""
+        st = self.step
+        self.counter.zero_()
+        g = self._graphs.get(n)
+        if g is None:
+            seen = self._seen[n] = self._seen.get(n, 0) + 1
+            if seen == 1 or os.environ.get("BRIDGES_TRAIN_GRAPH", "1") != "1":
+                for _ in range(n):
+                    st.launch(self.counter, *tensors)
+                return tensors[-1]
+            bufs = [torch.empty_like(t) if t is not None else None for t in tensors]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(n):
+                    st.launch(self.counter, *bufs)
+            g = self._graphs[n] = (graph, bufs)
+        graph, bufs = g
+        for dst, src in zip(bufs[:-1], tensors[:-1]):
+            if dst is not None:
+                dst.copy_(src)
+        bufs[-1].zero_()
+        graph.replay()
+        return bufs[-1].clone()
 
     @staticmethod
     def applies(policy_net, optimizer, loss_parts, scheduler, transitions, batch=None, device=None):
@@ -177,51 +206,58 @@ class _FusedTrainer:
         """All optimiser steps of one train_policy_net call: ``drawn`` = the sampled transitions of every step.  The target net
         does not change inside the call, so the TD targets of all steps come from ONE target forward and ONE segmented argmax
         over all next-action rows, and the steps are launch sequences that read their batch by a device-side counter
-        (FusedSuccessorStep.launch): per step the host queues 11 launches and nothing else.  The rows of a next state are
-        gathered from one copy per transition; the task's reward / obstacle rasters are the same image for every row."""
+        (FusedSuccessorStep.launch): per step the host queues 11 launches and nothing else.  A transition drawn several times
+        (the draws are with replacement across the steps; 20 x 32 draws from a buffer of a few hundred) is stacked and
+        evaluated once and its rows are gathered; the rows of a next state are gathered from one copy per transition; the
+        task's reward / obstacle rasters are the same image for every row."""
         n, st = len(drawn), self.step
         B, px = st.batch, st.px
-        flat = [t for b in drawn for t in b]
-        cat = lambda field: torch.cat([getattr(t, field) for t in flat]).to(device=device)
-        block, action, binary = cat('block_features'), cat('action_features'), cat('binary_features')
-        lin = cat('lin_reward').reshape(n, B).float()
-        counts = [t.next_actions_features.shape[0] for t in flat]
-        num_actions = [max(1, len(t.next_available_actions)) for t in flat]
-        assert counts == num_actions, "a next state's action rows and its action list differ in length"
-        seg_np = np.zeros(len(flat) + 1, dtype=np.int32)
+        slot, uniq, which = {}, [], []
+        for b in drawn:
+            for t in b:
+                k = slot.get(id(t))
+                if k is None:
+                    k = slot[id(t)] = len(uniq)
+                    uniq.append(t)
+                which.append(k)
+        cat = lambda field: torch.cat([getattr(t, field) for t in uniq]).to(device=device)
+        num_actions = [max(1, len(t.next_available_actions)) for t in uniq]
+        assert [t.next_actions_features.shape[0] for t in uniq] == num_actions, "a next state's action rows and its action list differ"
+        seg_np = np.zeros(len(uniq) + 1, dtype=np.int32)
         np.cumsum(num_actions, out=seg_np[1:])
-        owner = np.repeat(np.arange(len(flat), dtype=np.int64), num_actions)
-        seg, done, owner = ops.upload(device, seg_np, np.asarray([t.done for t in flat], dtype=np.bool_), owner)
+        owner = np.repeat(np.arange(len(uniq), dtype=np.int64), num_actions)
+        seg, done, owner, which = ops.upload(device, seg_np, np.asarray([t.done for t in uniq], dtype=np.bool_), owner,
+                                             np.asarray(which, dtype=np.int64))
         rows = int(seg_np[-1])
-        reward, obstacle = flat[0].reward_features.to(device), flat[0].obstacle_features.to(device)
+        reward, obstacle = uniq[0].reward_features.to(device), uniq[0].obstacle_features.to(device)
         with torch.no_grad():
+            action_u = cat('action_features')
             one_row = lambda x: x.shape[0] == 1 or x.stride(0) == 0              # rollout_episode stores expand()ed views
-            if all(one_row(t.next_block_features) and one_row(t.next_binary_features) for t in flat):
-                nb = torch.cat([t.next_block_features[:1] for t in flat]).to(device).index_select(0, owner)
-                nbin = torch.cat([t.next_binary_features[:1] for t in flat]).to(device).index_select(0, owner)
+            if all(one_row(t.next_block_features) and one_row(t.next_binary_features) for t in uniq):
+                nb = torch.cat([t.next_block_features[:1] for t in uniq]).to(device).index_select(0, owner)
+                nbin = torch.cat([t.next_binary_features[:1] for t in uniq]).to(device).index_select(0, owner)
             else:
                 nb, nbin = cat('next_block_features'), cat('next_binary_features')
             next_q, next_sf, _ = target_net(nb, nbin, cat('next_actions_features'), reward.expand(rows, -1, -1, -1),
                                             obstacle.expand(rows, -1, -1, -1))
-            zeros = torch.zeros(len(flat), dtype=torch.float32, device=device)
+            zeros = torch.zeros(len(uniq), dtype=torch.float32, device=device)
             nq = next_q.contiguous().float()
             q_sel, _, _ = dqn_ops.td_target(seg, nq, zeros, done, 1.0)
             sf_target = None
             if self.use_sf:
-                _, sf_target, _ = dqn_ops.td_target(seg, nq, zeros, done, gamma, next_sf=next_sf[:, 0], action_raster=action.squeeze(1))
-                sf_target = sf_target.reshape(n * B, px).contiguous()
+                _, sf_target, _ = dqn_ops.td_target(seg, nq, zeros, done, gamma, next_sf=next_sf[:, 0], action_raster=action_u.squeeze(1))
+                sf_target = sf_target.reshape(len(uniq), px).index_select(0, which)
             st.check_hyperparameters()
             q_target = extra = None
             if self.use_q:
+                lin = cat('lin_reward').reshape(-1).float().index_select(0, which).view(n, B)
                 m = lin.mean(dim=1, keepdim=True)
-                q_target = (m + gamma * q_sel.view(n, B)).reshape(-1).contiguous()
+                q_target = (m + gamma * q_sel.index_select(0, which).view(n, B)).reshape(-1).contiguous()
                 extra = ((lin - m) ** 2).mean(dim=1)
             losses = torch.zeros(n, dtype=torch.float32, device=device)
-            self.counter.zero_()
-            args = (block.reshape(n * B, px).contiguous(), action.reshape(n * B, px).contiguous(), binary.contiguous(),
-                    reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous(), q_target, sf_target, losses)
-            for _ in range(n):
-                st.launch(self.counter, *args)
+            losses = self._steps(n, cat('block_features').reshape(len(uniq), px).index_select(0, which),
+                                 action_u.reshape(len(uniq), px).index_select(0, which), cat('binary_features').index_select(0, which),
+                                 reward.reshape(px).contiguous(), obstacle.reshape(px).contiguous(), q_target, sf_target, losses)
         return losses + extra if extra is not None else losses
 
     def run(self, batch, q_sel, sf_target, gamma):
@@ -399,8 +435,12 @@ def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_v
             return policy_net(bf.expand(n, -1, -1, -1), binf.expand(n, -1), af, reward_features.expand(n, -1, -1, -1),
                               obstacle_features.expand(n, -1, -1, -1))
 
+    q_next = None
     while not done:
-        q_values, succ_block_features, succ_binary_features = qnet(block_features, binary_features, action_features, num_actions)
+        # (the net's outputs for this state were computed as "next state" of the previous step: the same net in eval mode on
+        # the same rows -- the reference runs the forward a second time, successor_dqn.py:383 after :420)
+        q_values, succ_block_features, succ_binary_features = q_next if q_next is not None else qnet(
+            block_features, binary_features, action_features, num_actions)
         sel = policy(q_values, step_index, action_features, succ_block_features, succ_binary_features)
         sel = int(sel)
         action = available_actions[sel]
@@ -421,8 +461,10 @@ def rollout_episode(env, policy, policy_net, x_discr_ground, setup_fct, offset_v
             next_action_features = torch.zeros([1, 1, *img_size], device=device)
         # q(s, a) and max_a' q(s', a') travel to the host together (one read instead of two)
         pair = [q_values[sel].reshape(1).float()]
+        q_next = None
         if not done:
-            pair.append(qnet(next_block_features, next_binary_features, next_action_features, num_actions)[0].max().reshape(1).float())
+            q_next = qnet(next_block_features, next_binary_features, next_action_features, num_actions)
+            pair.append(q_next[0].max().reshape(1).float())
         pair = torch.cat(pair).tolist()
         q_value, next_q_value = pair[0], (pair[1] if not done else 0)
         td_error = abs(q_value - (reward + 0.95 * next_q_value))          # successor_dqn.py:425 (hard-coded 0.95)

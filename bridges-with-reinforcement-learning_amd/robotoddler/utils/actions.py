@@ -16,10 +16,11 @@ def generate_actions(gym: AssemblyGym, x_discr_ground, offset_values=None, max_a
         for face in shape.target_faces_2d:
             for offset_x in x_discr_ground:
                 yield Action(-1, 0, shape_index, face, offset_x, offset_y=0.)
+            # (arccos is at most pi: the default 2 pi + 0.1 excludes nothing and the face frames need not be built)
+            check_angle = max_angle_rad is not None and max_angle_rad < np.pi
             for target_block, block in enumerate(gym.assembly_env.blocks):
                 for target_face in block.receiving_faces_2d:
-                    normal = block.get_face_frame_2d(target_face).normal
-                    if max_angle_rad is not None and np.arccos(np.clip(normal[2], -1.0, 1.0)) > max_angle_rad:
+                    if check_angle and np.arccos(np.clip(block.get_face_frame_2d(target_face).normal[2], -1.0, 1.0)) > max_angle_rad:
                         continue
                     if max_blocks_per_face and len(gym.block_graph.get((target_block, target_face), ())) >= max_blocks_per_face:
                         continue

@@ -439,3 +439,33 @@ def test_render_blocks_2d_at_the_reference_default_and_at_non_square_sizes():
         from bridges_hip import ops
         assert np.array_equal(ops.render_blocks(obs["blocks"], (-3, 7), (0, 10), (64, 64)).cpu().numpy().astype(bool),
                               render_blocks_2d(obs["blocks"], xlim=(-3, 7), ylim=(0, 10), img_size=(64, 64)))
+
+
+def test_frozen_and_free_verdicts_of_a_step_come_from_one_operator_call(monkeypatch):
+    """AssemblyGym.step solves the state with the new block frozen and stabilities_freezing() then asks for it free
+    (gym_env.py:238-243, :325-333 of the reference): both frozen sets ride in ONE bridges_stability call
+    (ops.stability_variants, AssemblyEnv._solve_state) -- same verdicts as one call each, and as the oracle."""
+    from assembly_gym.envs.assembly_env import AssemblyEnv
+    from assembly_gym.envs.gym_env import Action, AssemblyGym, bridge_setup, sparse_reward
+    from bridges_hip import ops
+    from oracle.env import OracleGym
+    from oracle.env import bridge_setup as o_bridge_setup
+    calls = []
+    inner = ops.stability_variants
+    monkeypatch.setattr(ops, "stability_variants", lambda blocks, sets, *a: calls.append(len(sets)) or inner(blocks, sets, *a))
+    env = AssemblyGym(**bridge_setup(num_stories=2), reward_fct=sparse_reward, restrict_2d=True, max_steps=10,
+                      assembly_env=AssemblyEnv(render=False))
+    og = OracleGym(**o_bridge_setup(num_stories=2), max_steps=10)
+    for a in [(-1, 0, 0, 3, -1.3333333333333335, 0.0), (0, 1, 0, 3, 0.0, 0.0), (1, 2, 0, 0, 0.0, 0.0), (2, 1, 0, 3, 0.6, 0.0)]:
+        before = len(calls)
+        obs, *_ = env.step(Action(*a))
+        og.step(a)
+        pair = env.stabilities_freezing()
+        assert len(calls) == before + 1 and calls[-1] == 2, calls             # one call, two frozen sets
+        assert pair == og.stabilities_freezing() and obs["stable"] == pair[0]
+        ae = env.assembly_env
+        n = len(ae.blocks)
+        fixed = {i for i, b in enumerate(ae.blocks) if b.is_static}
+        single = [ops.stability(ae.blocks, f, ae.mu, ae.density, ae.floor_half_width, ae.floor_depth) for f in (fixed, fixed - {n - 1})]
+        both = inner(ae.blocks, [fixed, fixed - {n - 1}], ae.mu, ae.density, ae.floor_half_width, ae.floor_depth)
+        assert both == single and (single[0][0], single[1][0]) == pair

@@ -577,3 +577,51 @@ def test_train_policy_net_on_the_hand_written_step_follows_the_autograd_form(los
     random.seed(22)
     more = S.train_policy_net(nets["fused"][0], mk(), nets["fused"][1], rb, gamma, loss_fct=loss_fct, n_steps=1, batch_size=B, device=DEV)
     assert len(more) == 1 and np.isfinite(more[0]) and {float(st["step"]) for st in nets["fused"][1].state.values()} == {4.0}
+
+
+def test_train_policy_net_graph_of_all_steps_equals_the_queued_launches(monkeypatch):
+    """From the second call with the same number of steps on, train_policy_net replays its optimiser steps from one HIP graph
+    (_FusedTrainer._steps): the same launches on copies of the same inputs -- losses and weights bit-identical to the run that
+    queues them one by one (BRIDGES_TRAIN_GRAPH=0), over three calls of four steps."""
+    import warnings
+    from robotoddler.models.cv import SuccessorMLP
+    from robotoddler.training import successor_dqn as S
+    from robotoddler.utils.replay_memory import ReplayBuffer
+    from robotoddler.utils.utils import init_weights
+    warnings.filterwarnings("ignore", message="Using a target size")
+    B, size, gamma = 16, (64, 64), 0.9
+    trans = synthetic_transitions(4 * B, size, 9)
+    reward, obstacle = trans[0].reward_features.to(DEV), trans[0].obstacle_features.to(DEV)
+    key = S._task_key(reward, obstacle)
+    items = []
+    for t in trans:
+        n1 = t.next_block_features.shape[0]
+        d = {f: (getattr(t, f).to(DEV) if torch.is_tensor(getattr(t, f)) else getattr(t, f)) for f in t._fields}
+        d.update(next_reward_features=reward.expand(n1, -1, -1, -1), next_obstacle_features=obstacle.expand(n1, -1, -1, -1),
+                 next_block_features=d["next_block_features"][:1].expand(n1, -1, -1, -1),
+                 next_binary_features=d["next_binary_features"][:1].expand(n1, -1),
+                 reward_features=S._tagged(reward.clone(), key), obstacle_features=S._tagged(obstacle.clone(), key))
+        items.append(Transition(**d))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BRIDGES_TRAIN_GRAPH", mode)
+        torch.manual_seed(5)
+        pol = SuccessorMLP(img_size=size, hidden_dims=[128, 64, 128]).to(DEV)
+        pol.apply(init_weights)
+        tgt = SuccessorMLP(img_size=size, hidden_dims=[128, 64, 128]).to(DEV)
+        tgt.load_state_dict(pol.state_dict())
+        S.flatten_nets(pol, tgt)
+        opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+        rb = ReplayBuffer(capacity=1000)
+        rb.push(items)
+        random.seed(3)
+        losses = []
+        for _ in range(3):
+            losses += S.train_policy_net(pol, tgt, opt, rb, gamma, loss_fct="mse_q_values+mse_block_features", n_steps=4, batch_size=B,
+                                         device=DEV)
+            S.update_target_net(pol, tgt, 0.05)
+        tr = pol._fused_trainer
+        assert (4 in tr._graphs) == (mode == "1")
+        out[mode] = (losses, torch.cat([p.detach().flatten() for p in pol.parameters()]).cpu())
+    assert len(out["1"][0]) == 12 and out["1"][0] == out["0"][0]
+    assert torch.equal(out["1"][1], out["0"][1])
