@@ -155,12 +155,18 @@ def conv3x3_supported(x, c_out):
             and c_out % 16 == 0 and c_out >= 16)
 
 
+def _vec4(t):
+    """contiguous and 16-byte aligned (the conv kernels read image rows as float4)."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def conv3x3(x, weight, bias=None, mask=None, transposed=False, in_mask=None):
     """conv2d(x, weight, padding=1) by bridges_conv3x3 (f32 matrix cores): + bias and ReLU when ``bias`` is given; times
     [mask > 0] when ``mask`` is given; ``transposed``: the input gradient of a layer with ``weight`` [c_in_of_x, c_out, 3, 3];
     ``in_mask`` (shape of x): x counts only where in_mask > 0 (x = the gradient at a ReLU's output)."""
     L = abi.require_gpu()
-    x = x.contiguous()
+    x = _vec4(x)
     weight = weight.contiguous()
     n, c_in, H, W = x.shape
     c_out = weight.shape[1] if transposed else weight.shape[0]
@@ -169,10 +175,10 @@ def conv3x3(x, weight, bias=None, mask=None, transposed=False, in_mask=None):
     out = torch.empty((n, c_out, H, W), dtype=torch.float32, device=x.device)
     mode = 1 if bias is not None else (2 if mask is not None else 0)
     if mask is not None:
-        mask = mask.contiguous()
+        mask = _vec4(mask)
         assert mask.shape == out.shape
     if in_mask is not None:
-        in_mask = in_mask.contiguous()
+        in_mask = _vec4(in_mask)
         assert in_mask.shape == x.shape
     abi.check(L.bridges_conv3x3(_ptr(x), _ptr(in_mask), _ptr(weight), _ptr(bias.contiguous() if bias is not None else None), _ptr(mask),
                                 _ptr(out), n, c_in, c_out, W, mode, int(bool(transposed)), _stream()), "bridges_conv3x3")
@@ -186,9 +192,9 @@ def conv3x3_wgrad(g, x, g_mask=None):
     """(dW [c_out, c_in, 3, 3], db [c_out]) of a conv3x3 layer from the gradient g at its output (times [g_mask > 0] when
     given: the layer's ReLU) and its input x (bridges_conv3x3_wgrad: deterministic partial sums + one reduction launch)."""
     L = abi.require_gpu()
-    g, x = g.contiguous(), x.contiguous()
+    g, x = _vec4(g), _vec4(x)
     if g_mask is not None:
-        g_mask = g_mask.contiguous()
+        g_mask = _vec4(g_mask)
         assert g_mask.shape == g.shape
     n, c_out, H, W = g.shape
     c_in = x.shape[1]

@@ -1033,7 +1033,8 @@ int bridges_conv3x3(const float* x, const float* in_mask, const float* w, const 
     if (n < 0 || !x || !w || !out || c_in < 1 || c_out < 16 || (c_out & 15)) return fail_arg("bridges_conv3x3: channels (C_out must be a multiple of 16)");
     if (W != 8 && W != 16 && W != 32 && W != 64) return fail_arg("bridges_conv3x3: W must be 8, 16, 32 or 64 (square images)");
     if (mode < C3_EPI_RAW || mode > C3_EPI_MASK || (mode == C3_EPI_BIAS_RELU && !bias) || (mode == C3_EPI_MASK && !mask)) return fail_arg("bridges_conv3x3: mode");
-    if ((((uintptr_t)out) | ((uintptr_t)mask)) & 15) return fail_arg("bridges_conv3x3: out / mask must be 16-byte aligned");
+    if ((((uintptr_t)out) | ((uintptr_t)mask) | ((uintptr_t)x) | ((uintptr_t)in_mask)) & 15)
+        return fail_arg("bridges_conv3x3: x / in_mask / out / mask must be 16-byte aligned");
     if (n == 0) return BRIDGES_OK;
     const int bands = W / c3_band_rows(W);
     if (n * bands > 0x7fffffff) return fail_arg("bridges_conv3x3: too many images");
@@ -1065,6 +1066,7 @@ int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_
 int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
                           int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream) {
     if (!g || !x || !dw || !db || !scratch) return fail_arg("bridges_conv3x3_wgrad");
+    if ((((uintptr_t)g) | ((uintptr_t)g_mask) | ((uintptr_t)x)) & 15) return fail_arg("bridges_conv3x3_wgrad: g / g_mask / x must be 16-byte aligned");
     int64_t need = 0;
     int rc = bridges_conv3x3_wgrad_scratch(n, c_in, c_out, W, &need);
     if (rc != BRIDGES_OK) return rc;

@@ -72,86 +72,77 @@ __global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const f
     // this lane's pixel inside a tile: 16 consecutive pixels of a row (W >= 16) or two rows of 8
     const int lp_r = (W >= 16) ? 0 : px / W, lp_c = (W >= 16) ? px : px % W;
     const int n_pass = (c_in + STAGE - 1) / STAGE;
-    constexpr int ITEMS = STAGE * (R + 2) * WP, SLOTS = (ITEMS + 255) / 256;
+    // staging of a pass: the band's rows are full image rows, so a row is W / 4 aligned float4 loads and the two halo columns of
+    // every patch row are always zero (written once here).  (One scalar load per patch element -- 42 per thread on the 64-pixel
+    // layers, each with its own address and clamp -- took 464 registers and, with the mask beside it, spilled to scratch.)
+    constexpr int V4_ROW = W / 4, V4_ITEMS = STAGE * (R + 2) * V4_ROW, V4_SLOTS = (V4_ITEMS + 255) / 256;
     constexpr int INNER = (CIN_CHUNK < 16 ? CIN_CHUNK : 16) * 9;
     constexpr int WSLOTS = (SUB * 16 * 16 * 9 + 255) / 256;
+    for (int i = t; i < STAGE * (R + 2); i += 256) {
+        const int c = i / (R + 2), rr = i - c * (R + 2);
+        tile[c * PLANE + rr * WP] = 0.f;
+        tile[c * PLANE + rr * WP + WP - 1] = 0.f;
+    }
     for (int pass = 0; pass < n_pass; ++pass) {
         const int p_base = pass * STAGE;
         if (pass) __syncthreads();
         // ---- every global load of the pass is issued before the first LDS write (unconditional, clamped addresses: a guarded
-        //      load is not hoisted and costs a memory latency of its own): the band's input rows (+1 halo each side) of STAGE
-        //      channels -- zeros outside the image / beyond c_in -- and the weights of its sub-chunks
-        if (in_mask == nullptr) {
-            float st[SLOTS];
+        //      load is not hoisted and costs a memory latency of its own): the band's input rows (+1 halo row each side) of STAGE
+        //      channels -- zeros outside the image / beyond c_in --, the ReLU mask beside them when the input is a gradient at a
+        //      ReLU's output (in_mask: x counts only where that activation is > 0, the U-Net's layers), and the weights of the
+        //      pass's sub-chunks
+        float4 st[V4_SLOTS], mk[V4_SLOTS];
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) {
-                const int i = t + 256 * u;
-                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-                const int rr = rem / WP, cc = rem - rr * WP;
-                const int y = y0 - 1 + rr, xx = cc - 1;
-                const bool ok = i < ITEMS && y >= 0 && y < W && xx >= 0 && xx < W && p_base + c < c_in;
-                const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-                const int ch = p_base + c < c_in ? p_base + c : c_in - 1;
-                const float v = x[(((size_t)n * c_in + ch) * W + yc) * W + xc];
-                st[u] = ok ? v : 0.f;
-            }
-            float ws[WSLOTS];
+        for (int u = 0; u < V4_SLOTS; ++u) {
+            const int i = t + 256 * u;
+            const int c = i / ((R + 2) * V4_ROW), rem = i - c * ((R + 2) * V4_ROW);
+            const int rr = rem / V4_ROW, j = rem - rr * V4_ROW;
+            const int y = y0 - 1 + rr;
+            const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y);
+            const int ch = p_base + c < c_in ? p_base + c : c_in - 1;
+            const size_t idx = (((size_t)n * c_in + ch) * W + yc) * W + 4 * j;
+            st[u] = *reinterpret_cast<const float4*>(x + idx);
+            if (in_mask != nullptr) mk[u] = *reinterpret_cast<const float4*>(in_mask + idx);
+        }
+        float ws[WSLOTS];
 #pragma unroll
-            for (int u = 0; u < WSLOTS; ++u) {
-                const int i = t + 256 * u;
-                const int inner_n = flip ? 16 * 9 : INNER;
-                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
-                const int r = i2 / inner_n, j = i2 - r * inner_n;
-                const int c_base = p_base + sub * CIN_CHUNK;
-                bool ok = sub < SUB;
-                size_t a;
-                if (flip) { ok = ok && c_base + r < c_in; a = (size_t)(ok ? c_base + r : 0) * w_sin + (size_t)co0 * 9 + j; }
-                else { ok = ok && c_base + j / 9 < c_in; a = (size_t)(co0 + r) * w_sout + (size_t)(ok ? c_base : 0) * 9 + (ok ? j : 0); }
-                const float v = w[a];
-                ws[u] = ok ? v : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < SLOTS; ++u) {
-                const int i = t + 256 * u;
-                if (i < ITEMS) {
-                    const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-                    tile[c * PLANE + rem] = st[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < WSLOTS; ++u) {
-                const int i = t + 256 * u;
-                const int inner_n = flip ? 16 * 9 : INNER;
-                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
-                const int r = i2 / inner_n, j = i2 - r * inner_n;
-                if (sub < SUB) wl[sub * 16 * WROW + r * WROW + j] = ws[u];
-            }
-        } else {
-            // x = a gradient at a ReLU's output, counted only where that ReLU's activation in_mask is > 0 (the U-Net's layers)
-            for (int i = t; i < ITEMS; i += 256) {
-                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-                const int rr = rem / WP, cc = rem - rr * WP;
-                const int y = y0 - 1 + rr, xx = cc - 1;
-                float v = 0.f;
-                if (y >= 0 && y < W && xx >= 0 && xx < W && p_base + c < c_in) {
-                    const size_t idx = (((size_t)n * c_in + p_base + c) * W + y) * W + xx;
-                    v = in_mask[idx] > 0.f ? x[idx] : 0.f;
-                }
-                tile[c * PLANE + rem] = v;
-            }
+        for (int u = 0; u < WSLOTS; ++u) {
+            const int i = t + 256 * u;
             const int inner_n = flip ? 16 * 9 : INNER;
-            for (int i = t; i < SUB * 16 * inner_n; i += 256) {
-                const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
-                const int r = i2 / inner_n, j = i2 - r * inner_n;
-                const int c_base = p_base + sub * CIN_CHUNK;
-                float v = 0.f;
-                if (flip) {
-                    if (c_base + r < c_in) v = w[(size_t)(c_base + r) * w_sin + (size_t)co0 * 9 + j];
-                } else {
-                    if (c_base + j / 9 < c_in) v = w[(size_t)(co0 + r) * w_sout + (size_t)c_base * 9 + j];
+            const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
+            const int r = i2 / inner_n, j = i2 - r * inner_n;
+            const int c_base = p_base + sub * CIN_CHUNK;
+            bool ok = sub < SUB;
+            size_t a;
+            if (flip) { ok = ok && c_base + r < c_in; a = (size_t)(ok ? c_base + r : 0) * w_sin + (size_t)co0 * 9 + j; }
+            else { ok = ok && c_base + j / 9 < c_in; a = (size_t)(co0 + r) * w_sout + (size_t)(ok ? c_base : 0) * 9 + (ok ? j : 0); }
+            const float v = w[a];
+            ws[u] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < V4_SLOTS; ++u) {
+            const int i = t + 256 * u;
+            if (i < V4_ITEMS) {
+                const int c = i / ((R + 2) * V4_ROW), rem = i - c * ((R + 2) * V4_ROW);
+                const int rr = rem / V4_ROW, j = rem - rr * V4_ROW;
+                const int y = y0 - 1 + rr;
+                const bool ok = y >= 0 && y < W && p_base + c < c_in;
+                float4 v = st[u];
+                if (in_mask != nullptr) {
+                    v.x = mk[u].x > 0.f ? v.x : 0.f; v.y = mk[u].y > 0.f ? v.y : 0.f;
+                    v.z = mk[u].z > 0.f ? v.z : 0.f; v.w = mk[u].w > 0.f ? v.w : 0.f;
                 }
-                wl[sub * 16 * WROW + r * WROW + j] = v;
+                float* d = tile + c * PLANE + rr * WP + 1 + 4 * j;
+                d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < WSLOTS; ++u) {
+            const int i = t + 256 * u;
+            const int inner_n = flip ? 16 * 9 : INNER;
+            const int sub = i / (16 * inner_n), i2 = i - sub * (16 * inner_n);
+            const int r = i2 / inner_n, j = i2 - r * inner_n;
+            if (sub < SUB) wl[sub * 16 * WROW + r * WROW + j] = ws[u];
         }
         __syncthreads();
 #pragma unroll
@@ -217,7 +208,7 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
     constexpr int KS = R * W / 4;                                   // k-steps (4 pixels each) per unit
     constexpr int RED = 4 * 36 * 64;                                // cross-wave reduction scratch (floats)
     constexpr int LDS = (16 * GP + 16 * XP) > RED ? (16 * GP + 16 * XP) : RED;
-    __shared__ float lds[LDS];
+    __shared__ __attribute__((aligned(16))) float lds[LDS];
     __shared__ float bsum[4][16];
     float* gt = lds;                                                // [16 co][R * W] (+ pad)
     float* xt = lds + 16 * GP;                                      // [16 ci][(R + 2) * WP] (+ pad)
@@ -231,43 +222,63 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (c3_f32x4){0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;
+    // the halo columns of the input patch are zero for every unit (a band's rows are full image rows)
+    for (int i = t; i < 16 * (R + 2); i += 256) {
+        const int c = i / (R + 2), rr = i - c * (R + 2);
+        xt[c * XP + rr * WP] = 0.f;
+        xt[c * XP + rr * WP + WP - 1] = 0.f;
+    }
     for (int u = u_lo; u < u_hi; ++u) {
         const int n = u / bands, y0 = (u % bands) * R;
         if (u != u_lo) __syncthreads();
         {
-            // every global load of the unit before the first LDS write (unconditional, clamped addresses)
-            constexpr int GS = (16 * R * W + 255) / 256, XS = (16 * (R + 2) * WP + 255) / 256;
-            float gv[GS], xv[XS];
+            // every global load of the unit before the first LDS write (unconditional, clamped addresses), rows as float4
+            constexpr int G4 = 16 * R * W / 4, X4_ROW = W / 4, X4 = 16 * (R + 2) * X4_ROW;
+            constexpr int GS = (G4 + 255) / 256, XS = (X4 + 255) / 256;
+            float4 gv[GS], gm[GS], xv[XS];
 #pragma unroll
             for (int k = 0; k < GS; ++k) {
                 const int i = t + 256 * k;
-                const int c = i / (R * W), p = i - c * (R * W);
-                const size_t idx = (((size_t)n * c_out + co0 + (c < 16 ? c : 15)) * W + y0) * W + p;      // a band's rows are contiguous
-                float v = g[idx];
-                if (g_mask) v = g_mask[idx] > 0.f ? v : 0.f;         // g = the gradient at a ReLU's output: times [activation > 0]
-                gv[k] = v;
+                const int c = i / (R * W / 4), p4 = i - c * (R * W / 4);
+                const size_t idx = (((size_t)n * c_out + co0 + (c < 16 ? c : 15)) * W + y0) * W + 4 * p4;   // a band's rows are contiguous
+                gv[k] = *reinterpret_cast<const float4*>(g + idx);
+                if (g_mask != nullptr) gm[k] = *reinterpret_cast<const float4*>(g_mask + idx);   // g = the gradient at a ReLU's output
             }
 #pragma unroll
             for (int k = 0; k < XS; ++k) {
                 const int i = t + 256 * k;
-                const int c = i / ((R + 2) * WP), rem = i - c * ((R + 2) * WP);
-                const int rr = rem / WP, cc = rem - rr * WP;
-                const int y = y0 - 1 + rr, xx = cc - 1;
-                const bool ok = c < 16 && y >= 0 && y < W && xx >= 0 && xx < W && ci0 + c < c_in;
-                const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y), xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-                const int ch = ci0 + c < c_in ? ci0 + c : c_in - 1;
-                const float v = x[(((size_t)n * c_in + ch) * W + yc) * W + xc];
-                xv[k] = ok ? v : 0.f;
+                const int c = i / ((R + 2) * X4_ROW), rem = i - c * ((R + 2) * X4_ROW);
+                const int rr = rem / X4_ROW, j = rem - rr * X4_ROW;
+                const int y = y0 - 1 + rr;
+                const int yc = y < 0 ? 0 : (y >= W ? W - 1 : y);
+                const int cc = c < 16 ? c : 15;
+                const int ch = ci0 + cc < c_in ? ci0 + cc : c_in - 1;
+                xv[k] = *reinterpret_cast<const float4*>(x + (((size_t)n * c_in + ch) * W + yc) * W + 4 * j);
             }
 #pragma unroll
             for (int k = 0; k < GS; ++k) {
                 const int i = t + 256 * k;
-                if (i < 16 * R * W) { const int c = i / (R * W); gt[c * GP + (i - c * (R * W))] = gv[k]; }
+                if (i < G4) {
+                    const int c = i / (R * W / 4), p4 = i - c * (R * W / 4);
+                    float4 v = gv[k];
+                    if (g_mask != nullptr) {
+                        v.x = gm[k].x > 0.f ? v.x : 0.f; v.y = gm[k].y > 0.f ? v.y : 0.f;
+                        v.z = gm[k].z > 0.f ? v.z : 0.f; v.w = gm[k].w > 0.f ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(gt + c * GP + 4 * p4) = v;
+                }
             }
 #pragma unroll
             for (int k = 0; k < XS; ++k) {
                 const int i = t + 256 * k;
-                if (i < 16 * (R + 2) * WP) { const int c = i / ((R + 2) * WP); xt[c * XP + (i - c * ((R + 2) * WP))] = xv[k]; }
+                if (i < X4) {
+                    const int c = i / ((R + 2) * X4_ROW), rem = i - c * ((R + 2) * X4_ROW);
+                    const int rr = rem / X4_ROW, j = rem - rr * X4_ROW;
+                    const int y = y0 - 1 + rr;
+                    const bool ok = y >= 0 && y < W && ci0 + c < c_in;
+                    float* d = xt + c * XP + rr * WP + 1 + 4 * j;
+                    d[0] = ok ? xv[k].x : 0.f; d[1] = ok ? xv[k].y : 0.f; d[2] = ok ? xv[k].z : 0.f; d[3] = ok ? xv[k].w : 0.f;
+                }
             }
         }
         __syncthreads();

@@ -524,6 +524,7 @@ int bridges_upconv2x2(const float* x, const float* w, const float* bias, float* 
  * bridges_conv3x3_wgrad: dw [c_out, c_in, 3, 3] and db [c_out] from g [n, c_out, W, W] (gradient at the layer's output, ReLU
  *   mask applied) and the layer's input x [n, c_in, W, W]; partial sums over pixel ranges are added in a fixed order
  *   (deterministic); scratch: bridges_conv3x3_wgrad_scratch floats.
+ * Image tensors (x, in_mask, mask, out, g, g_mask) must be 16-byte aligned: rows are read and written as float4.
  * bridges_maxpool2 / bridges_maxpool2_relu_backward: MaxPool2d(2) of a [nc, H, W] and, from dy [nc, H/2, W/2], the gradient at
  *   the pre-pool activation a = relu(.): the first maximum of a window in scan order takes dy (as torch), times [a > 0]. */
 int bridges_conv3x3(const float* x, const float* in_mask, const float* w, const float* bias, const float* mask, float* out, int64_t n,
