@@ -10,9 +10,18 @@ and -- for the inference passes (acting, targets: no autograd) of the conv nets 
 ``+ bias -> ReLU [-> MaxPool2d(2)]`` in ONE pass over the activations (bridges_bias_relu, bridges_bias_relu_pool2) instead
 of torch's three, bit-identical to the module's own forward.
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
+
+# The library convolutions left on this path are the inference passes of the 32- / 64- / 128-channel layers (acting, targets:
+# thousands of rows).  For those MIOpen's immediate-mode choice on gfx950 is often its NHWC implicit-GEMM forward solver wrapped
+# in two layout transposes -- measured against its own Winograd kernels on the same layers (tools/train_throughput.py, U-Net
+# policy at 4096 envs): acting 14.7 -> 11.8 ms, targets 12.3 -> 9.2 ms per lock-step with that one solver off.  A default only:
+# an explicit setting of the variable wins.  (It must be in the environment before the process's first convolution.)
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
 
 
 def _fused_inference(x):
