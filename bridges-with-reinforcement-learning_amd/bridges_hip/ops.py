@@ -50,7 +50,13 @@ class ShapeRegistry:
 REGISTRY = ShapeRegistry()
 
 
-_TORCH_DTYPE = {np.dtype(n): getattr(torch, n) for n in ("float32", "float64", "int32", "int64", "uint8", "int8", "int16", "bool")}
+class _TorchDtypes(dict):
+    def __missing__(self, dt):                              # any other numpy dtype torch has a name for
+        self[dt] = getattr(torch, np.dtype(dt).name)
+        return self[dt]
+
+
+_TORCH_DTYPE = _TorchDtypes({np.dtype(n): getattr(torch, n) for n in ("float32", "float64", "int32", "int64", "uint8", "int8", "int16", "bool")})
 
 
 class _Stager:
