@@ -1,6 +1,8 @@
 """Host wrappers of the fused DQN ops (K7): TD / successor-feature target construction and Polyak soft update."""
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import abi
@@ -302,11 +304,88 @@ class BiasAddFunction(torch.autograd.Function):
         return dy, db
 
 
+class UpConv2x2Function(torch.autograd.Function):
+    """ConvTranspose2d(kernel 2, stride 2) + bias of the U-Net decoder, forward by bridges_upconv2x2 (the inference kernel),
+    backward by bridges_upconv2x2_backward: input gradient, weight and bias gradient as three launches (deterministic partial
+    sums) where the library ran two convolution kernels, an implicit-GEMM weight gradient between layout transposes and a fill."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _vec4(x)
+        ctx.save_for_backward(x, weight)
+        return upconv2x2(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = abi.require_gpu()
+        x, weight = ctx.saved_tensors
+        dy = _vec4(dy)
+        w = weight.contiguous()
+        n, c_in, H, W = x.shape
+        c_out = w.shape[1]
+        need = C.c_int64(0)
+        abi.check(L.bridges_upconv2x2_backward_scratch(n, c_in, c_out, H, W, C.byref(need)), "bridges_upconv2x2_backward_scratch")
+        scratch = torch.empty(need.value, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+        abi.check(L.bridges_upconv2x2_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), scratch.numel(), n, c_in,
+                                               c_out, H, W, _stream()), "bridges_upconv2x2_backward")
+        return dx, dw, db
+
+
+def upconv2x2_train_applies(x, up):
+    return upconv2x2_applies(x, up) and (x.shape[2] * x.shape[3]) % 64 == 0
+
+
+class Conv1x1O1Function(torch.autograd.Function):
+    """Conv2d(c_in, 1, kernel_size=1) (the U-Net's outconv for one class): forward one pass over x, backward one pass writing dx
+    and the partial sums of dw / db, then their fixed-order reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L = abi.require_gpu()
+        x = _vec4(x)
+        n, c_in, H, W = x.shape
+        w = weight.reshape(-1).contiguous()
+        y = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)
+        abi.check(L.bridges_conv1x1_o1_forward(_ptr(x), _ptr(w), _ptr(bias.contiguous()), _ptr(y), n, c_in, H * W, _stream()), "bridges_conv1x1_o1_forward")
+        ctx.save_for_backward(x, w)
+        ctx.w_shape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = abi.require_gpu()
+        x, w = ctx.saved_tensors
+        dy = _vec4(dy)
+        n, c_in, H, W = x.shape
+        S = min(256, max(1, -(-(n * H * W // 4) // 256)))
+        scratch = torch.empty(S * (c_in + 1), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dw = torch.empty(c_in, dtype=torch.float32, device=x.device)
+        db = torch.empty(1, dtype=torch.float32, device=x.device)
+        abi.check(L.bridges_conv1x1_o1_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), scratch.numel(), n, c_in,
+                                                H * W, _stream()), "bridges_conv1x1_o1_backward")
+        return dx, dw.view(ctx.w_shape), db
+
+
+def conv1x1_o1_applies(x, conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.out_channels == 1 and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.bias is not None and conv.in_channels <= 32 and x.dim() == 4
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.dtype == torch.float32 and x.is_cuda)
+
+
 def conv_bias_train(module, x):
-    """module(x) for a Conv2d / ConvTranspose2d of a training pass on the GPU: the library's convolution without its bias, the
-    bias through BiasAddFunction."""
+    """module(x) for the U-Net's transposed / 1x1 convolutions in a training pass on the GPU: the hand-written pair where it
+    applies (UpConv2x2Function, Conv1x1O1Function); else the library's convolution without its bias and the bias through
+    BiasAddFunction."""
     if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and module.bias is not None):
         return module(x)
+    if isinstance(module, torch.nn.ConvTranspose2d) and upconv2x2_train_applies(x, module):
+        return UpConv2x2Function.apply(x, module.weight, module.bias)
+    if conv1x1_o1_applies(x, module):
+        return Conv1x1O1Function.apply(x, module.weight, module.bias)
     if isinstance(module, torch.nn.ConvTranspose2d):
         y = torch.nn.functional.conv_transpose2d(x, module.weight, None, module.stride, module.padding, module.output_padding,
                                                  module.groups, module.dilation)
@@ -340,3 +419,64 @@ class FlatParameters:
             view.copy_(t.data)
             t.data = view
         self.module = module
+
+
+class MultiTensorAdam:
+    """``optimizer.step()`` of a plain torch.optim.Adam (one parameter group; amsgrad, weight decay, maximize off) over all its
+    float32 GPU parameters as ONE launch of 1024-element chunks (bridges_adam_multi) -- torch's fused multi-tensor launch cuts
+    the 34-60 tensors of a conv Q-network into 64 k-element chunks, ~40 workgroups, 40-63 us per step.  The optimiser's own state
+    tensors are the moments and receive the step count, so ``optimizer.step()`` / ``state_dict()`` carry on from here at any
+    time.  ``step()`` reads the gradients' addresses when it is called: inside a graph capture they are the capture's.
+    Raises ValueError when the optimiser is not of that kind or has not taken its first step yet (no state to adopt)."""
+    CHUNK = 1024
+    _SLOT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("step", "<u8"), ("n", "<i8")])
+
+    def __init__(self, optimizer):
+        if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+            raise ValueError("not a plain torch.optim.Adam with one parameter group")
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("weight_decay") or g.get("differentiable"):
+            raise ValueError("amsgrad / maximize / weight decay / differentiable are not covered")
+        self.opt, self.params = optimizer, [p for p in g["params"] if p.requires_grad]
+        steps = set()
+        for p in self.params:
+            st = optimizer.state.get(p)
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and st and torch.is_tensor(st.get("step")) and st["step"].is_cuda
+                    and st["step"].dtype == torch.float32 and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                raise ValueError("parameters must be contiguous float32 GPU tensors with an initialised fused-Adam state")
+            steps.add(float(st["step"]))
+        if len(steps) != 1:
+            raise ValueError("the parameters' step counts differ")
+        dev = self.params[0].device
+        self.step_count = torch.full((), steps.pop(), dtype=torch.float32, device=dev)      # updates done so far
+        slot_of, off = [], []
+        for i, p in enumerate(self.params):
+            n_chunks = -(-p.numel() // self.CHUNK)
+            slot_of += [i] * n_chunks
+            off += list(range(n_chunks))
+        self.n_chunks = len(slot_of)
+        self.chunk_slot = torch.tensor(slot_of, dtype=torch.int32).to(dev)
+        self.chunk_off = torch.tensor(off, dtype=torch.int32).to(dev)
+        self.host = torch.empty(len(self.params) * self._SLOT.itemsize, dtype=torch.uint8).pin_memory()
+        self.table = torch.empty(self.host.numel(), dtype=torch.uint8, device=dev)
+        self.hyper = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+
+    def check_hyperparameters(self):
+        g = self.opt.param_groups[0]
+        now = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        if now != self.hyper:
+            raise abi.BridgesHipError(f"the optimiser's hyper-parameters changed ({self.hyper} -> {now}): build a new MultiTensorAdam")
+
+    def step(self):
+        L = abi.require_gpu()
+        rows = self.host.numpy().view(self._SLOT)
+        for i, p in enumerate(self.params):
+            if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                raise abi.BridgesHipError("MultiTensorAdam.step: every parameter needs a contiguous float32 gradient")
+            st = self.opt.state[p]
+            rows[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel())
+        self.table.copy_(self.host, non_blocking=True)
+        lr, b1, b2, eps = self.hyper
+        abi.check(L.bridges_adam_multi(_ptr(self.table), len(self.params), _ptr(self.chunk_slot), _ptr(self.chunk_off), self.n_chunks,
+                                       _ptr(self.step_count), lr, b1, b2, eps, _stream()), "bridges_adam_multi")
+        self.step_count.add_(1.0)

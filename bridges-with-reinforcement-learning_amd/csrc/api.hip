@@ -955,6 +955,17 @@ int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* ex
     return BRIDGES_OK;
 }
 
+int bridges_adam_multi(const bridges_adam_slot* slots, int32_t n_slots, const int32_t* chunk_slot, const int32_t* chunk_off,
+                       int32_t n_chunks, const float* step, double lr, double beta1, double beta2, double eps, void* stream) {
+    if (n_slots < 0 || n_chunks < 0 || !step || (n_chunks > 0 && (!slots || !chunk_slot || !chunk_off || n_slots < 1))) return fail_arg("bridges_adam_multi");
+    if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail_arg("bridges_adam_multi: hyper-parameters");
+    if (n_chunks == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, slots, chunk_slot, chunk_off, step, lr, beta1,
+                       beta2, eps);
+    LAUNCH_CHECK("k_adam_multi");
+    return BRIDGES_OK;
+}
+
 // ---- conv3x3 + bias + ReLU [+ pool] for the 64-wide, 16-output-channel layers (conv_kernels.hip) ------------------
 int bridges_conv3x3_relu_o16_ex(const float* x, const float* x2, const float* w, const float* bias, float* out, float* out2,
                                 const float* proj_w, const float* proj_b, int64_t n, int32_t c_in, int32_t c_in2, int32_t H,
@@ -1123,3 +1134,91 @@ int bridges_bias_grad(const float* g, float* db, float* scratch, int64_t scratch
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;
 }
+
+// ---- backward of the U-Net's transposed / 1x1 convolutions (conv_train_kernels.hip) -----------------------------------------------
+static int up2_splits(int64_t tiles, int* tps) {
+    int per = (int)((tiles + 255) / 256);
+    if (per < 1) per = 1;
+    *tps = per;
+    return (int)((tiles + per - 1) / per);
+}
+
+extern "C" {
+
+int bridges_upconv2x2_backward_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int64_t* floats) {
+    if (!floats || n < 0 || H < 1 || W < 1 || (((int64_t)H * W) & 63)) return fail_arg("bridges_upconv2x2_backward_scratch: H * W must be a multiple of 64");
+    if (!((c_in == 32 && c_out == 16) || (c_in == 64 && c_out == 32))) return fail_arg("bridges_upconv2x2_backward_scratch: (C_in, C_out) must be (32, 16) or (64, 32)");
+    int tps;
+    const int S = up2_splits(n * H * W / 64, &tps);
+    *floats = (int64_t)(S < 1 ? 1 : S) * ((int64_t)c_in * c_out * 4 + c_out);
+    return BRIDGES_OK;
+}
+
+int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
+                               int64_t scratch_floats, int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, void* stream) {
+    if (!x || !g || !w || !dw || !db || !scratch) return fail_arg("bridges_upconv2x2_backward");
+    int64_t need = 0;
+    int rc = bridges_upconv2x2_backward_scratch(n, c_in, c_out, H, W, &need);
+    if (rc != BRIDGES_OK) return rc;
+    if (scratch_floats < need) return fail_arg("bridges_upconv2x2_backward: scratch too small (bridges_upconv2x2_backward_scratch)");
+    if (((uintptr_t)g) & 7) return fail_arg("bridges_upconv2x2_backward: g must be 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles = n * H * W / 64;
+    if (tiles > 0x7fffffff) return fail_arg("bridges_upconv2x2_backward: too many images");
+    const int K = c_out * 4;
+    float* part = scratch;
+    int tps;
+    const int S = up2_splits(tiles, &tps);
+    float* part_b = scratch + (size_t)(S < 1 ? 1 : S) * c_in * K;
+    if (tiles == 0) {                                               // no image: zero gradients
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)c_in * K, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * (size_t)c_out, s) != hipSuccess)
+            return fail_arg("bridges_upconv2x2_backward: hipMemsetAsync");
+        return BRIDGES_OK;
+    }
+    if (dx) {
+        hipLaunchKernelGGL(k_up2_dx, dim3((unsigned)tiles, (unsigned)((c_in + 15) / 16)), dim3(256), (size_t)K * 80 * sizeof(float), s, g, w, dx,
+                           c_in, c_out, H, W);
+        LAUNCH_CHECK("k_up2_dx");
+    }
+    if (c_in == 64) hipLaunchKernelGGL((k_up2_wgrad<4, 8>), dim3((unsigned)S), dim3(256), 0, s, x, g, part, part_b, c_out, H, W, (int)tiles, tps);
+    else hipLaunchKernelGGL((k_up2_wgrad<2, 4>), dim3((unsigned)S), dim3(256), 0, s, x, g, part, part_b, c_out, H, W, (int)tiles, tps);
+    LAUNCH_CHECK("k_up2_wgrad");
+    const int n_w = c_in * K;
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((n_w + c_out + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
+                       n_w, c_out, S);
+    LAUNCH_CHECK("k_c3_reduce");
+    return BRIDGES_OK;
+}
+
+int bridges_conv1x1_o1_forward(const float* x, const float* w, const float* bias, float* y, int64_t n, int32_t c_in, int32_t hw, void* stream) {
+    if (!x || !w || !bias || !y || n < 0 || c_in < 1 || hw < 4 || (hw & 3)) return fail_arg("bridges_conv1x1_o1_forward: H * W must be a multiple of 4");
+    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return fail_arg("bridges_conv1x1_o1_forward: x / y must be 16-byte aligned");
+    const int64_t quads = n * hw / 4;
+    if (quads == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_pw1_fwd, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, c_in, hw, quads);
+    LAUNCH_CHECK("k_pw1_fwd");
+    return BRIDGES_OK;
+}
+
+int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
+                                int64_t scratch_floats, int64_t n, int32_t c_in, int32_t hw, void* stream) {
+    if (!x || !g || !w || !dx || !dw || !db || !scratch || n < 0 || c_in < 1 || c_in > 32 || hw < 4 || (hw & 3))
+        return fail_arg("bridges_conv1x1_o1_backward: C_in <= 32, H * W a multiple of 4");
+    if ((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)dx)) & 15) return fail_arg("bridges_conv1x1_o1_backward: x / g / dx must be 16-byte aligned");
+    const int64_t quads = n * hw / 4;
+    int64_t S = (quads + 255) / 256;
+    if (S > 256) S = 256;
+    if (S < 1) S = 1;
+    if (scratch_floats < S * (c_in + 1)) return fail_arg("bridges_conv1x1_o1_backward: scratch needs min(256, ceil(n * hw / 1024)) * (C_in + 1) floats");
+    hipStream_t s = (hipStream_t)stream;
+    float* part = scratch;
+    float* part_b = scratch + S * c_in;
+    hipLaunchKernelGGL(k_pw1_bwd, dim3((unsigned)S), dim3(256), 0, s, x, g, w, dx, part, part_b, c_in, hw, quads);
+    LAUNCH_CHECK("k_pw1_bwd");
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((c_in + 1 + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db, c_in, 1,
+                       (int)S);
+    LAUNCH_CHECK("k_c3_reduce");
+    return BRIDGES_OK;
+}
+
+}  // extern "C"

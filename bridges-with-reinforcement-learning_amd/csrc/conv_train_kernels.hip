@@ -370,6 +370,163 @@ __global__ __launch_bounds__(256) void k_bias_grad_part(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward of the U-Net's ConvTranspose2d(kernel 2, stride 2) layers (cv.py:176, 179: 64 -> 32 on 16 x 16, 32 -> 16 on 32 x 32)
+// and of its 1x1 output convolution to one channel (cv.py:182), forward of the latter.  y[n, co, 2i + a, 2j + b] = bias[co] +
+// sum_ci x[n, ci, i, j] w[ci, co, a, b] is a GEMM per input pixel with K = c_in and N = c_out * 4 -- 134 MFLOP per layer at the
+// replay batch, which the library served with a Winograd / implicit-GEMM kernel per direction, three layout transposes and a
+// zero fill (~130 us per layer and step).  Plain FMA kernels on LDS tiles of 64 input pixels:
+//   k_up2_dx     dx[n, ci, i, j] = sum_{co, a, b} g[n, co, 2i + a, 2j + b] w[ci, co, a, b]; grid (pixels / 64, c_in / 16);
+//   k_up2_wgrad  part[s][ci][co][a][b] = sum over the workgroup's pixels of x g, part_b[s][co] = sum of g; k_c3_reduce adds the
+//                workgroups' partial sums in a fixed order (deterministic);
+//   k_pw1_fwd / k_pw1_bwd  y[n, p] = b + sum_ci x[n, ci, p] w[ci];  dx = g w[ci], partial sums of dw[ci] = sum x g and db = sum g.
+// (The forward of the transposed convolution is the inference kernel k_upconv2x2, conv_kernels.hip.)
+__global__ __launch_bounds__(256) void k_up2_dx(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx, int c_in,
+                                                int c_out, int H, int W) {
+    extern __shared__ float up_lds[];
+    const int K = c_out * 4, HW = H * W;
+    float* gs = up_lds;                                             // [K][64]: g of the tile's pixels, k = (co, a, b)
+    float* wt = up_lds + K * 64;                                    // [K][16]: w[ci0 + c][k] transposed
+    const int t = threadIdx.x, p = t & 63, cig = t >> 6;
+    const int pix0 = blockIdx.x * 64, n = pix0 / HW, q0 = pix0 - n * HW, ci0 = blockIdx.y * 16;
+    for (int i = t; i < c_out * 2 * 64; i += 256) {                 // (co, a, pixel): one float2 = (b = 0, 1)
+        const int pp = i & 63, ca = i >> 6, co = ca >> 1, a = ca & 1;
+        const int q = q0 + pp, ii = q / W, jj = q - ii * W;
+        const float2 v = *reinterpret_cast<const float2*>(g + (((size_t)n * c_out + co) * 2 * H + 2 * ii + a) * 2 * W + 2 * jj);
+        gs[(co * 4 + a * 2) * 64 + pp] = v.x;
+        gs[(co * 4 + a * 2 + 1) * 64 + pp] = v.y;
+    }
+    for (int i = t; i < 16 * K; i += 256) {
+        const int c = i / K, k = i - c * K;
+        wt[k * 16 + c] = (ci0 + c < c_in) ? w[(size_t)(ci0 + c) * K + k] : 0.f;
+    }
+    __syncthreads();
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const float gv = gs[k * 64 + p];
+        const float4 wv = *reinterpret_cast<const float4*>(wt + k * 16 + cig * 4);
+        acc.x += gv * wv.x; acc.y += gv * wv.y; acc.z += gv * wv.z; acc.w += gv * wv.w;
+    }
+    const int ci = ci0 + cig * 4;
+    float* o = dx + ((size_t)n * c_in + ci) * HW + q0 + p;
+    if (ci + 0 < c_in) o[0] = acc.x;
+    if (ci + 1 < c_in) o[(size_t)HW] = acc.y;
+    if (ci + 2 < c_in) o[(size_t)2 * HW] = acc.z;
+    if (ci + 3 < c_in) o[(size_t)3 * HW] = acc.w;
+}
+
+// TI = c_in / 16 input channels x TJ = c_out * 4 / 16 columns per thread; tiles [blockIdx.x * tps, + tps) of 64 pixels.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void k_up2_wgrad(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ part,
+                                                   float* __restrict__ part_b, int c_out, int H, int W, int tiles, int tps) {
+    constexpr int CI = 16 * TI, K = 16 * TJ;
+    __shared__ float xs[CI * 65];                                   // [ci][pixel], rows padded: lanes of a read differ in ci
+    __shared__ float gs[K * 65];                                    // [k][pixel]
+    const int t = threadIdx.x, ti = t & 15, tj = t >> 4, HW = H * W;
+    float acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) acc[a][b] = 0.f;
+    float bsum = 0.f;
+    const int u_lo = blockIdx.x * tps, u_hi = (u_lo + tps < tiles) ? u_lo + tps : tiles;
+    for (int u = u_lo; u < u_hi; ++u) {
+        const int pix0 = u * 64, n = pix0 / HW, q0 = pix0 - n * HW;
+        if (u != u_lo) __syncthreads();
+        for (int i = t; i < CI * 64; i += 256) {
+            const int pp = i & 63, c = i >> 6;
+            xs[c * 65 + pp] = x[((size_t)n * CI + c) * HW + q0 + pp];
+        }
+        for (int i = t; i < c_out * 2 * 64; i += 256) {
+            const int pp = i & 63, ca = i >> 6, co = ca >> 1, a = ca & 1;
+            const int q = q0 + pp, ii = q / W, jj = q - ii * W;
+            const float2 v = *reinterpret_cast<const float2*>(g + (((size_t)n * c_out + co) * 2 * H + 2 * ii + a) * 2 * W + 2 * jj);
+            gs[(co * 4 + a * 2) * 65 + pp] = v.x;
+            gs[(co * 4 + a * 2 + 1) * 65 + pp] = v.y;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < 64; ++pp) {
+            float xv[TI], gv[TJ];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) xv[a] = xs[(ti * TI + a) * 65 + pp];
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) gv[b] = gs[(tj * TJ + b) * 65 + pp];
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) acc[a][b] += xv[a] * gv[b];
+        }
+        if (t < c_out) {                                            // bias gradient: this tile's sum of g over pixels and (a, b)
+            float sb = 0.f;
+            for (int pp = 0; pp < 64; ++pp)
+                sb += (gs[(t * 4) * 65 + pp] + gs[(t * 4 + 1) * 65 + pp]) + (gs[(t * 4 + 2) * 65 + pp] + gs[(t * 4 + 3) * 65 + pp]);
+            bsum += sb;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) part[(size_t)blockIdx.x * CI * K + (size_t)(ti * TI + a) * K + tj * TJ + b] = acc[a][b];
+    if (t < c_out) part_b[(size_t)blockIdx.x * c_out + t] = bsum;
+}
+
+// 4 pixels per thread; x [N, c_in, HW], w [c_in], y [N, HW].
+__global__ __launch_bounds__(256) void k_pw1_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ y, int c_in, int HW, int64_t quads) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= quads) return;
+    const int64_t e = 4 * i, n = e / HW, q = e - n * HW;
+    const float b = bias[0];
+    float4 acc = {b, b, b, b};
+    for (int c = 0; c < c_in; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * c_in + c) * HW + q);
+        const float wc = w[c];
+        acc.x += v.x * wc; acc.y += v.y * wc; acc.z += v.z * wc; acc.w += v.w * wc;
+    }
+    *reinterpret_cast<float4*>(y + e) = acc;
+}
+
+// dx [N, c_in, HW] = g [N, HW] * w[c]; part[blockIdx.x][c] = this workgroup's sum of x g, part_b[blockIdx.x] = its sum of g.
+// A workgroup walks quads blockIdx.x * 256 + t + k * gridDim.x * 256 (c_in <= 32).
+__global__ __launch_bounds__(256) void k_pw1_bwd(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ w,
+                                                 float* __restrict__ dx, float* __restrict__ part, float* __restrict__ part_b, int c_in, int HW,
+                                                 int64_t quads) {
+    __shared__ float red[4][33];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float aw[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) aw[c] = 0.f;
+    float ab = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < quads; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = 4 * i, n = e / HW, q = e - n * HW;
+        const float4 gv = *reinterpret_cast<const float4*>(g + e);
+        ab += (gv.x + gv.y) + (gv.z + gv.w);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            if (c < c_in) {
+                const size_t o = ((size_t)n * c_in + c) * HW + q;
+                const float4 xv = *reinterpret_cast<const float4*>(x + o);
+                const float wc = w[c];
+                float4 d = {gv.x * wc, gv.y * wc, gv.z * wc, gv.w * wc};
+                *reinterpret_cast<float4*>(dx + o) = d;
+                aw[c] += (xv.x * gv.x + xv.y * gv.y) + (xv.z * gv.z + xv.w * gv.w);
+            }
+        }
+    }
+    // fixed-order reduction: butterfly over the wave's 64 lanes, then the four waves in order
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        float v = aw[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][c] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) ab += __shfl_xor(ab, o);
+    if (lane == 0) red[wave][32] = ab;
+    __syncthreads();
+    if (t < c_in) part[(size_t)blockIdx.x * c_in + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (t == 32) part_b[blockIdx.x] = ((red[0][32] + red[1][32]) + red[2][32]) + red[3][32];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // y [n*C, H/2, W/2] = MaxPool2d(2)(a [n*C, H, W]); one thread per output pixel pair row (2 outputs: 4 input columns x 2 rows).
 __global__ __launch_bounds__(256) void k_maxpool2(const float* __restrict__ a, float* __restrict__ y, int64_t items, int H, int W) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

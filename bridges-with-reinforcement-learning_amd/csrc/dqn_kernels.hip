@@ -68,6 +68,48 @@ __global__ __launch_bounds__(256) void k_adam_flat(float* __restrict__ p, const 
 #undef ADAM_ONE
 }
 
+// The same update over MANY tensors in one launch (the conv Q-networks: 34-60 parameter tensors of 16 .. 295 k elements, each
+// with its own gradient tensor from autograd).  One workgroup per 1024-element chunk of a tensor (chunk_slot / chunk_off name
+// the tensor and the chunk's first element): 426 k parameters are ~450 workgroups.  torch's fused multi-tensor launch cuts
+// tensors into 64 k-element chunks -- ~40 workgroups for ConvNet, 40 us per step where the bytes are worth 2.
+// *step = number of updates done so far (this one is *step + 1; nothing in the launch writes *step, the caller advances it);
+// the first chunk of a tensor also writes the new count into the tensor's own step word (torch.optim.Adam's state['step']).
+__global__ __launch_bounds__(256) void k_adam_multi(const bridges_adam_slot* __restrict__ slots, const int32_t* __restrict__ chunk_slot,
+                                                    const int32_t* __restrict__ chunk_off, const float* __restrict__ step, double lr,
+                                                    double beta1_d, double beta2_d, double eps_d) {
+    const bridges_adam_slot s = slots[chunk_slot[blockIdx.x]];
+    const int64_t base = (int64_t)chunk_off[blockIdx.x] * 1024;
+    const double t = (double)*step + 1.0;
+    const float step_size = (float)(lr / (1.0 - pow(beta1_d, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, t));
+    const float w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d), beta2 = (float)beta2_d, eps = (float)eps_d;
+    if (base == 0 && threadIdx.x == 0 && s.step) *s.step = (float)t;
+#define ADAM_ONE(P, G, M, V)                                         \
+    do {                                                             \
+        M = M + (G - M) * w1;                                        \
+        V = beta2 * V + w2 * G * G;                                  \
+        P = P - step_size * M / (sqrtf(V) / bc2_sqrt + eps);         \
+    } while (0)
+    const int64_t i = base + 4 * (int64_t)threadIdx.x;
+    const bool vec = ((((uintptr_t)s.p) | ((uintptr_t)s.g) | ((uintptr_t)s.m) | ((uintptr_t)s.v)) & 15) == 0;
+    if (vec && i + 3 < s.n) {
+        float4 pp = *reinterpret_cast<float4*>(s.p + i), gg = *reinterpret_cast<const float4*>(s.g + i);
+        float4 mm = *reinterpret_cast<float4*>(s.m + i), vv = *reinterpret_cast<float4*>(s.v + i);
+        ADAM_ONE(pp.x, gg.x, mm.x, vv.x);
+        ADAM_ONE(pp.y, gg.y, mm.y, vv.y);
+        ADAM_ONE(pp.z, gg.z, mm.z, vv.z);
+        ADAM_ONE(pp.w, gg.w, mm.w, vv.w);
+        *reinterpret_cast<float4*>(s.p + i) = pp; *reinterpret_cast<float4*>(s.m + i) = mm; *reinterpret_cast<float4*>(s.v + i) = vv;
+    } else {
+        for (int64_t j = i; j < i + 4 && j < s.n; ++j) {
+            float pp = s.p[j], gg = s.g[j], mm = s.m[j], vv = s.v[j];
+            ADAM_ONE(pp, gg, mm, vv);
+            s.p[j] = pp; s.m[j] = mm; s.v[j] = vv;
+        }
+    }
+#undef ADAM_ONE
+}
+
 // train_policy_net target construction (successor_dqn.py:197-213, 222, 230).  One workgroup per transition:
 // segmented first-argmax over its next-action rows, then the q target and (optionally) the successor-feature
 // target row, 16 B per lane.

@@ -395,11 +395,21 @@ class VecDQN:
                 loss = loss + ((sf[:, 0].reshape(B, -1) - st["sf"].index_select(0, idx)) ** 2).mean(dim=1).mean()
             st["losses"].add_((st["iota"] == st["counter"]).to(torch.float32) * loss.detach())
             loss.backward()
-            self.opt.step()
+            if st["adam"] is not None:
+                st["adam"].step()                          # one launch of 1024-element chunks over all parameter tensors
+            else:
+                self.opt.step()
             st["counter"].add_(1)
 
         self.policy_net.train()
         self.opt.zero_grad(set_to_none=True)
+        st["adam"] = None
+        if not st["fused"]:
+            from bridges_hip.dqn_ops import MultiTensorAdam
+            try:
+                st["adam"] = MultiTensorAdam(self.opt)
+            except ValueError:
+                pass                                       # another optimiser, or one with options the launch does not cover
         if st["fused"]:
             from bridges_hip.mlp_ops import FusedSuccessorStep
             st["step"] = FusedSuccessorStep(self.policy_net, B, 'mse_q_values' in self.loss_parts, use_sf,
@@ -489,6 +499,8 @@ class VecDQN:
                 st["step"].prepare_inputs(n_steps, block_f.reshape(n, -1).contiguous(), action_f.reshape(n, -1).contiguous(),
                                           binary.contiguous(), st["reward"], st["obstacle"])
             else:
+                if st["adam"] is not None:
+                    st["adam"].check_hyperparameters()
                 st["block"][:n].copy_(block_f); st["binary"][:n].copy_(binary); st["action"][:n].copy_(action_f)
                 self._guard_snapshot(st)
             st["q"][:n].copy_(q_target)
@@ -540,6 +552,9 @@ class VecDQN:
         ts = [flat.flat] if flat is not None else [p.data for p in self.policy_net.parameters()]
         for s in self.opt.state.values():
             ts += [t for t in s.values() if torch.is_tensor(t) and t.is_cuda]
+        adam = (self._graph_state or {}).get("adam")
+        if adam is not None:
+            ts.append(adam.step_count)
         return ts
 
     def _guard_snapshot(self, st):

@@ -489,6 +489,16 @@ int bridges_successor_loss(int32_t batch, int32_t rows, int32_t px, int32_t nf, 
  * already incremented by the caller. */
 int bridges_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* step,
                       double lr, double beta1, double beta2, double eps, void* stream);
+/* The same update over many tensors in ONE launch (a conv Q-network's 34-60 parameter tensors with their autograd gradients):
+ * slots [n_slots] (device) name the tensors; chunk c of the launch updates elements [chunk_off[c] * 1024, + 1024) of tensor
+ * chunk_slot[c] (device int32 arrays, n_chunks entries: every tensor cut into 1024-element chunks).  *step (device float) =
+ * the number of updates done SO FAR: this update is number *step + 1; the launch does not write *step (advance it after the
+ * call), it writes the new count into every slot's own `step` word when that is not NULL (torch.optim.Adam's state['step']). */
+typedef struct bridges_adam_slot {
+    float* p; const float* g; float* m; float* v; float* step; int64_t n;
+} bridges_adam_slot;
+int bridges_adam_multi(const bridges_adam_slot* slots, int32_t n_slots, const int32_t* chunk_slot, const int32_t* chunk_off,
+                       int32_t n_chunks, const float* step, double lr, double beta1, double beta2, double eps, void* stream);
 
 /* relu(conv3x3(x, w, padding 1) + bias) [then MaxPool2d(2)] for the 64-pixel-wide layers with 16 output channels of
  * the conv Q-networks (cv.py:5-17 ConvBlock(4,16) / (16,16); cv.py:138-254 UNet e11, e12, d41, d42), inference passes:
@@ -533,6 +543,18 @@ int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_
 int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
                           int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream);
 int bridges_maxpool2(const float* a, float* y, int64_t nc, int32_t H, int32_t W, void* stream);
+/* Backward of the U-Net decoder's ConvTranspose2d(kernel_size=2, stride=2) (cv.py:176, 179; forward: bridges_upconv2x2): from
+ * the layer's input x [n, c_in, H, W], the gradient g [n, c_out, 2H, 2W] at its output and w [c_in, c_out, 2, 2] ->
+ * dx [n, c_in, H, W] (may be NULL), dw [c_in, c_out, 2, 2], db [c_out]; (c_in, c_out) = (32, 16) or (64, 32), H * W a multiple
+ * of 64; partial sums per workgroup added in a fixed order (deterministic).  scratch: bridges_upconv2x2_backward_scratch floats.
+ * bridges_conv1x1_o1_*: Conv2d(c_in, 1, kernel_size=1) (cv.py:182 outconv of UNet(1)): y [n, hw] = b + sum_c x[n, c, hw] w[c];
+ * backward: dx = g w[c], dw [c_in], db [1]; c_in <= 32, hw a multiple of 4; scratch: min(256, ceil(n * hw / 1024)) * (c_in + 1). */
+int bridges_upconv2x2_backward_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int64_t* floats);
+int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
+                               int64_t scratch_floats, int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, void* stream);
+int bridges_conv1x1_o1_forward(const float* x, const float* w, const float* bias, float* y, int64_t n, int32_t c_in, int32_t hw, void* stream);
+int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
+                                int64_t scratch_floats, int64_t n, int32_t c_in, int32_t hw, void* stream);
 /* db [C] = sum over n and the hw pixels of g [n, C, hw] in a fixed order (deterministic, single-workgroup stages): the bias
  * gradient of a convolution whose weights stay with the library.  scratch: min(n, 32) * C floats. */
 int bridges_bias_grad(const float* g, float* db, float* scratch, int64_t scratch_floats, int64_t n, int32_t C, int32_t hw, void* stream);

@@ -201,3 +201,79 @@ def test_bias_grad_is_the_channel_sum_and_deterministic(n, c, hw):
     assert float(((db.double() - exact).abs() / dy.double().abs().sum(dim=(0, 2, 3))).max()) < 1e-6
     _, db2 = torch.autograd.grad(dqn_ops.BiasAddFunction.apply(x, b), [x, b], dy)
     assert torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("model", ["ConvNet", "UNet"])
+def test_multi_tensor_adam_follows_torch_fused_adam(model):
+    """bridges_adam_multi (one launch of 1024-element chunks over every parameter tensor) against torch.optim.Adam(fused=True) on
+    the same gradients: parameters, both moments and the step counts after 1 + 3 steps; the torch optimiser carries on from the
+    state the launch left (one more torch step on both sides)."""
+    from bridges_hip.dqn_ops import MultiTensorAdam
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    args = vars(build_parser().parse_args(["--model", model]))
+    torch.manual_seed(3)
+    a, _ = make_nets(args, torch.device("cuda"))
+    b, _ = make_nets(args, torch.device("cuda"))
+    b.load_state_dict(a.state_dict())
+    oa, ob = (torch.optim.Adam(m.parameters(), lr=1e-3, fused=True) for m in (a, b))
+    with pytest.raises(ValueError):
+        MultiTensorAdam(ob)                                                   # no state yet: nothing to adopt
+    g = torch.Generator(device="cuda").manual_seed(9)
+    grads = [[torch.randn(p.shape, device="cuda", generator=g) * (0.1 if k % 2 else 1e-4) for p in a.parameters()] for k in range(5)]
+
+    def set_grads(m, k):
+        for p, gr in zip(m.parameters(), grads[k]):
+            p.grad = gr.clone()
+
+    for m, o in ((a, oa), (b, ob)):
+        set_grads(m, 0)
+        o.step()
+    mine = MultiTensorAdam(ob)
+    assert mine.n_chunks >= sum(p.numel() for p in b.parameters()) // 1024
+    for k in (1, 2, 3):
+        set_grads(a, k); oa.step()
+        set_grads(b, k); mine.step()
+    assert float(mine.step_count) == 4.0
+    set_grads(a, 4); oa.step()
+    set_grads(b, 4); ob.step()                                                # torch takes over from the launch's state
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        sa, sb = oa.state[pa], ob.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == 5.0
+        for x, y in ((pa, pb), (sa["exp_avg"], sb["exp_avg"]), (sa["exp_avg_sq"], sb["exp_avg_sq"])):
+            assert torch.allclose(x, y, rtol=2e-5, atol=1e-7), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("n,c_in,c_out,H", [(32, 64, 32, 16), (32, 32, 16, 32), (3, 64, 32, 16), (5, 32, 16, 32), (1, 32, 16, 16)])
+def test_upconv2x2_training_pair_follows_the_library(n, c_in, c_out, H):
+    from bridges_hip import dqn_ops
+    up = torch.nn.ConvTranspose2d(c_in, c_out, kernel_size=2, stride=2).cuda()
+    x = rnd(n, c_in, H, H, seed=70).requires_grad_(True)
+    assert dqn_ops.upconv2x2_train_applies(x, up)
+    dy = rnd(n, c_out, 2 * H, 2 * H, seed=71)
+    y = dqn_ops.conv_bias_train(up, x)
+    ref = up(x)
+    assert rel(y, ref) < 3e-6
+    got = torch.autograd.grad(y, [x, up.weight, up.bias], dy)
+    want = torch.autograd.grad(ref, [x, up.weight, up.bias], dy)
+    for g_, w_, name in zip(got, want, ("dx", "dw", "db")):
+        assert g_.shape == w_.shape and rel(g_, w_) < 2e-5, (name, rel(g_, w_))
+    again = torch.autograd.grad(dqn_ops.conv_bias_train(up, x), [x, up.weight, up.bias], dy)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))                  # deterministic
+
+
+@pytest.mark.parametrize("n,c_in,H", [(32, 16, 64), (3, 16, 64), (2, 7, 10), (300, 16, 64)])
+def test_conv1x1_to_one_channel_follows_the_library(n, c_in, H):
+    from bridges_hip import dqn_ops
+    conv = torch.nn.Conv2d(c_in, 1, kernel_size=1).cuda()
+    x = rnd(n, c_in, H, H, seed=72).requires_grad_(True)
+    assert dqn_ops.conv1x1_o1_applies(x, conv)
+    dy = rnd(n, 1, H, H, seed=73)
+    y = dqn_ops.conv_bias_train(conv, x)
+    ref = conv(x)
+    assert y.shape == ref.shape and rel(y, ref) < 3e-6
+    got = torch.autograd.grad(y, [x, conv.weight, conv.bias], dy)
+    want = torch.autograd.grad(ref, [x, conv.weight, conv.bias], dy)
+    for g_, w_, name in zip(got, want, ("dx", "dw", "db")):
+        assert g_.shape == w_.shape and rel(g_, w_) < 2e-5, (name, rel(g_, w_))
+    again = torch.autograd.grad(dqn_ops.conv_bias_train(conv, x), [x, conv.weight, conv.bias], dy)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
