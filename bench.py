@@ -182,8 +182,11 @@ def side_modes(args):
     """Each in a process of its own (as if started by hand): how HIP maps the streams of a SECOND set of groups onto
     hardware queues inside one process moved the latency-bound modes by +-30 %."""
     me = os.path.abspath(__file__)
-    base = [sys.executable, me, "--no-cpu-baseline", "--no-other-modes", "--envs", str(args.envs), "--steps", str(args.steps),
-            "--warmup", str(args.warmup), "--seeds", str(args.seeds).split(",")[0]]
+    # a side mode is one seed, so it gets at least 100 timed lock-steps behind 20 of warm-up whatever --steps / --warmup the
+    # headline was given (20 lock-steps are 10-30 ms: one slow launch moved such a sample by 20 %); its own counts are reported
+    side_steps, side_warmup = max(args.steps, 100), max(args.warmup, 20)
+    base = [sys.executable, me, "--no-cpu-baseline", "--no-other-modes", "--envs", str(args.envs), "--steps", str(side_steps),
+            "--warmup", str(side_warmup), "--seeds", str(args.seeds).split(",")[0]]
     task = ["--tower_height", str(args.tower_height), "--max_steps", str(args.max_steps), "--shapes", args.shapes]
     if args.bridge_length:
         task += ["--bridge_length", str(args.bridge_length)]
@@ -195,8 +198,8 @@ def side_modes(args):
             if sub is None:
                 out[name] = {"error": err}
                 return
-            out[name] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
-                         "groups": sub["config"].get("groups"), "workload": sub["config"]["workload"]}
+            out[name] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"],
+                         "warmup": sub["warmup"], "groups": sub["config"].get("groups"), "workload": sub["config"]["workload"]}
             for k in ("roofline", "candidate_stability"):
                 if k in sub:
                     out[name][k] = sub[k]

@@ -29,9 +29,15 @@ typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
 #define C3_EPI_BIAS_RELU 1
 #define C3_EPI_MASK 2
 
-// band rows of a workgroup: 8 everywhere -- at the CLI's batch of 32 that makes >= 256 workgroups for every layer of ConvNet
-// (one per CU; 16-row bands left half the chip idle on the 32- and 16-pixel layers)
-__host__ __device__ constexpr int c3_band_rows(int W) { return 8; }
+// band rows of a workgroup: 4 on the 16- to 64-pixel layers, the whole image on the 8-pixel ones -- at the CLI's batch of 32 that
+// makes >= 512 workgroups for every layer but the last block's, and with the register cap of two waves per SIMD (C3_MIN_WAVES)
+// two workgroups share a CU, one staging its patch while the other multiplies.  tools/c3_variants.sh (profiles/r04_c3_variants.txt),
+// one optimiser step of the U-Net policy: 8 rows / 1 wave 1269 us, 8 / 2 1494 (spills), 4 / 1 1276, 4 / 2 1200.  (16-row bands
+// had left half the chip idle on the 32- and 16-pixel layers.)
+#ifndef C3_BAND_ROWS_WIDE
+#define C3_BAND_ROWS_WIDE 4
+#endif
+__host__ __device__ constexpr int c3_band_rows(int W) { return W >= 16 ? C3_BAND_ROWS_WIDE : 8; }
 // band of the weight-gradient kernel: two operand tiles must fit into 64 KB of static LDS
 __host__ __device__ constexpr int c3_wgrad_rows(int W) { return W >= 64 ? 4 : (W == 32 ? 8 : W); }
 // smallest size >= raw with size % 64 == rem (LDS plane strides that put the 4 k-lanes of an operand read on distinct banks)
@@ -47,8 +53,11 @@ __host__ __device__ constexpr int c3_pad(int raw, int rem) { return ((raw - rem 
 // what it costs (64 -> 128 channels on 8 x 8 images: 8 passes of 16 channels took 39 us, the arithmetic < 2).
 __host__ __device__ constexpr int c3_stage(int W, int CIN_CHUNK) { return CIN_CHUNK < 16 ? CIN_CHUNK : (W <= 16 ? 32 : 16); }
 
+#ifndef C3_MIN_WAVES
+#define C3_MIN_WAVES 2
+#endif
 template <int W, int CIN_CHUNK, int EPI>
-__global__ __launch_bounds__(256) void k_c3(const float* __restrict__ x, const float* __restrict__ in_mask, const float* __restrict__ w,
+__global__ __launch_bounds__(256, C3_MIN_WAVES) void k_c3(const float* __restrict__ x, const float* __restrict__ in_mask, const float* __restrict__ w,
                                             const float* __restrict__ bias, const float* __restrict__ mask_src, float* __restrict__ out,
                                             int c_in, int c_out, int w_sin, int w_sout, int flip) {
     constexpr int R = c3_band_rows(W), WP = W + 2, PLANE = c3_pad((R + 2) * WP, 16);

@@ -9,6 +9,7 @@ from robotoddler.training.successor_dqn import build_parser, make_nets
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="UNet")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--plain", action="store_true", help="just run the steps (for an outer profiler: rocprofv3 --pmc)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -33,6 +34,12 @@ def step():
 for _ in range(12):
     step()
 torch.cuda.synchronize()
+if a.plain:
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    print(f"{a.model}: {a.steps} steps, last loss {float(loss.detach()):.5f}")
+    sys.exit(0)
 from torch.profiler import ProfilerActivity, profile
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(a.steps):
@@ -40,6 +47,6 @@ with profile(activities=[ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 rows = sorted(((e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_time_total > 0), key=lambda r: -r[2])
 total = sum(r[2] for r in rows)
-print(f"{a.model}: GPU time per optimiser step {total / a.steps:.1f} us over {sum(r[1] for r in rows) / a.steps:.0f} launches (last loss {float(loss):.5f})")
+print(f"{a.model}: GPU time per optimiser step {total / a.steps:.1f} us over {sum(r[1] for r in rows) / a.steps:.0f} launches (last loss {float(loss.detach()):.5f})")
 for key, count, t in rows:
     print(f"{key[:110]:110s} {count / a.steps:6.1f}/step {t / a.steps:8.1f} us/step {t / count:7.1f} us each")
