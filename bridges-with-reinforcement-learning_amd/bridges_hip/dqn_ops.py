@@ -232,6 +232,27 @@ def maxpool2_relu_backward(a, dy):
     return g
 
 
+class MaxPool2OfReLUFunction(torch.autograd.Function):
+    """max_pool2d(a, 2) of a ReLU OUTPUT a (>= 0): forward bridges_maxpool2, backward the gradient at a with the first maximum
+    of a window taking dy (as torch) and zero where a == 0 -- what the ReLU's own backward makes of it anyway, so behind a ReLU
+    this is torch's gradient exactly (the U-Net's pool1 / pool2 behind e12 / e22)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        ctx.save_for_backward(a)
+        return maxpool2(a)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, = ctx.saved_tensors
+        return maxpool2_relu_backward(a, dy)
+
+
+def maxpool2_of_relu_applies(a):
+    return a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.shape[2] % 2 == 0 and a.shape[3] % 2 == 0 and torch.is_grad_enabled()
+
+
 class ConvBlockFunction(torch.autograd.Function):
     """conv3x3 - ReLU - conv3x3 - ReLU - MaxPool2d(2) (cv.py:5-17) with a hand-written forward AND backward: 3 launches
     forward, 7 backward (pool gradient, two weight gradients with their reductions, two input gradients) instead of the

@@ -262,10 +262,12 @@ class UNet(nn.Module):
                 return dqn_ops.conv3x3_relu_o16(u, self.d42.weight, self.d42.bias, proj=(self.outconv.weight, self.outconv.bias))
             out = self.outconv(cr(self.d42, u))
         else:
-            lib = dqn_ops.conv_bias_train if x.is_cuda else (lambda m, t: m(t))      # library layers: bias by a deterministic kernel
+            lib = dqn_ops.conv_bias_train if x.is_cuda else (lambda m, t: m(t))      # transposed / 1x1 layers: hand-written pairs
+            # (pool1 / pool2 sit behind a ReLU: the hand-written pooling pair is exact there)
+            pool = lambda m, t: dqn_ops.MaxPool2OfReLUFunction.apply(t) if dqn_ops.maxpool2_of_relu_applies(t) else m(t)
             s1 = cr(self.e12, cr(self.e11, x))
-            s2 = cr(self.e22, cr(self.e21, self.pool1(s1)))
-            b = cr(self.e32, cr(self.e31, self.pool2(s2)))
+            s2 = cr(self.e22, cr(self.e21, pool(self.pool1, s1)))
+            b = cr(self.e32, cr(self.e31, pool(self.pool2, s2)))
             u = torch.cat([lib(self.upconv3, b), s2], dim=1)
             u = cr(self.d32, cr(self.d31, u))
             u = torch.cat([lib(self.upconv4, u), s1], dim=1)
