@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
 
 SHAPES = [(5, 4, 64, 16), (32, 16, 64, 16), (3, 16, 32, 32), (32, 32, 32, 32), (4, 32, 16, 64), (32, 64, 16, 64), (32, 64, 8, 128),
-          (7, 128, 8, 128), (2, 2, 64, 16), (1, 48, 16, 16)]
+          (7, 128, 8, 128), (2, 2, 64, 16), (1, 48, 16, 16), (2, 5, 32, 16), (3, 20, 16, 32), (2, 33, 8, 16)]
 
 
 def rel(a, b):
@@ -277,3 +277,27 @@ def test_conv1x1_to_one_channel_follows_the_library(n, c_in, H):
         assert g_.shape == w_.shape and rel(g_, w_) < 2e-5, (name, rel(g_, w_))
     again = torch.autograd.grad(dqn_ops.conv_bias_train(conv, x), [x, conv.weight, conv.bias], dy)
     assert all(torch.equal(a, b) for a, b in zip(got, again))
+
+
+def test_misaligned_image_views_are_cloned_by_the_wrappers_and_refused_by_the_c_abi():
+    """The conv kernels read image rows as float4: a view that starts 4 bytes into an allocation goes through a clone in
+    dqn_ops (same result), and the C entry points refuse such a pointer instead of faulting."""
+    import ctypes as C
+    from bridges_hip import abi, dqn_ops
+    n, c, W, co = 3, 16, 32, 32
+    flat = rnd(n * c * W * W + 1, seed=80)
+    x_mis = flat[1:].view(n, c, W, W)
+    assert x_mis.data_ptr() % 16 != 0 and x_mis.is_contiguous()
+    x = x_mis.clone()
+    w, b = rnd(co, c, 3, 3, seed=81) * 0.2, rnd(co, seed=82)
+    assert torch.equal(dqn_ops.conv3x3(x_mis, w, b), dqn_ops.conv3x3(x, w, b))
+    g = rnd(n, co, W, W, seed=83)
+    for a_, b_ in zip(dqn_ops.conv3x3_wgrad(g, x_mis), dqn_ops.conv3x3_wgrad(g, x)):
+        assert torch.equal(a_, b_)
+    out = torch.empty(n, co, W, W, device=DEV)
+    L = abi.lib()
+    p = lambda t_: C.c_void_p(t_.data_ptr())
+    rc = L.bridges_conv3x3(p(x_mis), None, p(w), p(b), None, p(out), n, c, co, W, 1, 0, None)
+    assert rc != 0 and "aligned" in L.bridges_last_error().decode()
+    with pytest.raises(abi.BridgesHipError, match="aligned"):
+        abi.check(rc, "bridges_conv3x3")
