@@ -1,6 +1,7 @@
-"""Does the vectorised loop learn?  Trains SuccessorMLP on tower_height=2 for a fixed number of lock-steps and prints the
-mean sparse reward, linear reward and loss per block of lock-steps (evaluation = the running epsilon-greedy rollouts).
-    python tools/learning_curve.py --locksteps 1500 --envs 1024"""
+"""Does the vectorised loop learn?  Trains a Q-network (--model SuccessorMLP | ConvNet | UNet) on tower_height=2 for a fixed
+number of lock-steps and prints the mean sparse reward, linear reward and loss per block of lock-steps (evaluation = the running
+epsilon-greedy rollouts).
+    python tools/learning_curve.py --locksteps 1500 --envs 1024 [--model ConvNet --loss mse_q_values]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bridges-with-reinforcement-learning_amd")]
@@ -21,9 +22,10 @@ ap.add_argument("--train_steps", type=int, default=10)
 ap.add_argument("--loss", default="mse_q_values+mse_block_features")
 ap.add_argument("--lr", type=float, default=1e-4)
 ap.add_argument("--block", type=int, default=100)
+ap.add_argument("--model", default="SuccessorMLP")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-args = vars(build_parser().parse_args(["--model", "SuccessorMLP", "--loss_function", a.loss]))
+args = vars(build_parser().parse_args(["--model", a.model, "--loss_function", a.loss]))
 H = 0.8
 torch.manual_seed(0)
 pol, tgt = make_nets(args, dev)
