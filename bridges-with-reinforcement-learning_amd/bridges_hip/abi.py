@@ -251,6 +251,7 @@ def lib():
         "bridges_maxpool2": [vp, vp, i64, i32, i32, vp],
         "bridges_bias_grad": [vp, vp, vp, i64, i64, i32, i32, vp],
         "bridges_adam_multi": [vp, i32, vp, vp, i32, vp, f64, f64, f64, f64, vp],
+        "bridges_reduce_jobs": [vp, i32, i32, vp],
         "bridges_upconv2x2_backward_scratch": [i64, i32, i32, i32, i32, C.POINTER(i64)],
         "bridges_upconv2x2_backward": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp],
         "bridges_conv1x1_o1_forward": [vp, vp, vp, vp, i64, i32, i32, vp],
@@ -275,7 +276,7 @@ EXPORTED_SYMBOLS = (
     "bridges_place", "bridges_create_block", "bridges_pose_block", "bridges_face_frames", "bridges_contains_points", "bridges_raster", "bridges_raster_sized", "bridges_render_blocks", "bridges_action_features", "bridges_bits_or", "bridges_bits_to_f32", "bridges_bits_linear", "bridges_bits_dot", "bridges_bits_accumulate", "bridges_head_sigmoid_dot", "bridges_linear_backward_log", "bridges_mlp_mid_rows", "bridges_mlp_mid_supported", "bridges_mlp_mid_forward", "bridges_mlp_mid_backward", "bridges_eps_greedy_select", "bridges_valid_rows", "bridges_env_groups", "bridges_record_state", "bridges_record_result", "bridges_replay_unpack", "bridges_sigmoid_dot", "bridges_stability", "bridges_stability_penalty",
     "bridges_shapes_upload", "bridges_shapes_free", "bridges_soft_update", "bridges_td_target", "bridges_bias_relu", "bridges_bias_relu_pool2",
     "bridges_conv3x3_relu_o16", "bridges_conv3x3_relu_o16_ex", "bridges_conv3x3", "bridges_conv3x3_wgrad_scratch", "bridges_conv3x3_wgrad",
-    "bridges_maxpool2", "bridges_maxpool2_relu_backward", "bridges_bias_grad", "bridges_adam_multi", "bridges_upconv2x2_backward_scratch", "bridges_upconv2x2_backward", "bridges_conv1x1_o1_forward", "bridges_conv1x1_o1_backward", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_mlp_input_batches", "bridges_successor_loss", "bridges_adam_step", "bridges_linear_backward_adam",
+    "bridges_maxpool2", "bridges_maxpool2_relu_backward", "bridges_bias_grad", "bridges_adam_multi", "bridges_reduce_jobs", "bridges_upconv2x2_backward_scratch", "bridges_upconv2x2_backward", "bridges_conv1x1_o1_forward", "bridges_conv1x1_o1_backward", "bridges_upconv2x2", "bridges_linear_forward", "bridges_linear_backward", "bridges_mlp_input", "bridges_mlp_input_batches", "bridges_successor_loss", "bridges_adam_step", "bridges_linear_backward_adam",
 )
 
 

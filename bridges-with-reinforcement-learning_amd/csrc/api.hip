@@ -1076,7 +1076,7 @@ int bridges_conv3x3_wgrad_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_
 
 int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, float* dw, float* db, float* scratch, int64_t scratch_floats,
                           int64_t n, int32_t c_in, int32_t c_out, int32_t W, void* stream) {
-    if (!g || !x || !dw || !db || !scratch) return fail_arg("bridges_conv3x3_wgrad");
+    if (!g || !x || !scratch || (!dw) != (!db)) return fail_arg("bridges_conv3x3_wgrad");
     if ((((uintptr_t)g) | ((uintptr_t)g_mask) | ((uintptr_t)x)) & 15) return fail_arg("bridges_conv3x3_wgrad: g / g_mask / x must be 16-byte aligned");
     int64_t need = 0;
     int rc = bridges_conv3x3_wgrad_scratch(n, c_in, c_out, W, &need);
@@ -1096,6 +1096,7 @@ int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, f
     else if (W == 16) hipLaunchKernelGGL(k_c3_wgrad<16>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
     else hipLaunchKernelGGL(k_c3_wgrad<8>, grid, dim3(256), 0, s, g, g_mask, x, part, part_b, (int)n, c_in, c_out, ups);
     LAUNCH_CHECK("k_c3_wgrad");
+    if (!dw) return BRIDGES_OK;                                    // partial sums only: the caller reduces them (bridges_reduce_jobs)
     const int64_t tot = n_w + c_out;
     hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
                        (int)n_w, c_out, splits);
@@ -1222,3 +1223,11 @@ int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, 
 }
 
 }  // extern "C"
+
+extern "C" int bridges_reduce_jobs(const bridges_reduce_job* jobs_dev, int32_t n_jobs, int32_t total_blocks, void* stream) {
+    if (n_jobs < 0 || total_blocks < 0 || (n_jobs > 0 && (!jobs_dev || total_blocks < 1))) return fail_arg("bridges_reduce_jobs");
+    if (n_jobs == 0) return BRIDGES_OK;
+    hipLaunchKernelGGL(k_reduce_jobs, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+    LAUNCH_CHECK("k_reduce_jobs");
+    return BRIDGES_OK;
+}

@@ -61,6 +61,7 @@ class VecDQN:
             if 'capturable' in g:
                 g['capturable'] = True
         self._graph_state, self._eager_calls = None, 0
+        self._eager_reduce = None                            # dqn_ops.ReduceTables of the eager optimiser steps
         self.episodes_done = 0
         self.env_steps = 0
         self._counts_host = torch.zeros(2, dtype=torch.int64).pin_memory()      # (env-steps, finished episodes) of a lock-step
@@ -394,7 +395,8 @@ class VecDQN:
             if use_sf:
                 loss = loss + ((sf[:, 0].reshape(B, -1) - st["sf"].index_select(0, idx)) ** 2).mean(dim=1).mean()
             st["losses"].add_((st["iota"] == st["counter"]).to(torch.float32) * loss.detach())
-            loss.backward()
+            with dqn_ops.deferred_wgrad_reduce(st["reduce"]):          # the conv layers' weight-gradient reductions as one launch
+                loss.backward()
             if st["adam"] is not None:
                 st["adam"].step()                          # one launch of 1024-element chunks over all parameter tensors
             else:
@@ -404,6 +406,7 @@ class VecDQN:
         self.policy_net.train()
         self.opt.zero_grad(set_to_none=True)
         st["adam"] = None
+        st["reduce"] = dqn_ops.ReduceTables(dev)
         if not st["fused"]:
             from bridges_hip.dqn_ops import MultiTensorAdam
             try:
@@ -531,7 +534,10 @@ class VecDQN:
             q, sf, _ = self.policy_net(block_f[sl], binary[sl], action_f[sl], reward, obstacle)
             loss = self._loss(q, sf, q_target[sl], sf_target[sl] if use_sf else None)
             self.opt.zero_grad()
-            loss.backward()
+            if self._eager_reduce is None:
+                self._eager_reduce = dqn_ops.ReduceTables(self.device)
+            with dqn_ops.deferred_wgrad_reduce(self._eager_reduce):
+                loss.backward()
             self.opt.step()
             losses.append(loss.detach())
         if defer:

@@ -301,3 +301,41 @@ def test_misaligned_image_views_are_cloned_by_the_wrappers_and_refused_by_the_c_
     assert rc != 0 and "aligned" in L.bridges_last_error().decode()
     with pytest.raises(abi.BridgesHipError, match="aligned"):
         abi.check(rc, "bridges_conv3x3")
+
+
+@pytest.mark.parametrize("model", ["ConvNet", "UNet"])
+def test_deferred_weight_gradient_reduction_gives_the_same_bits(model):
+    """with dqn_ops.deferred_wgrad_reduce(tables): loss.backward() -- the conv3x3 layers' partial sums added by ONE launch at the
+    end of the pass instead of one per layer: every parameter's .grad bit-identical to the per-layer form; a second pass through
+    the same tables as well; a parameter whose .grad already exists keeps the immediate form (accumulation stays correct)."""
+    from bridges_hip import dqn_ops
+    from robotoddler.training.successor_dqn import build_parser, make_nets
+    args = vars(build_parser().parse_args(["--model", model]))
+    torch.manual_seed(4)
+    net, _ = make_nets(args, DEV)
+    net.train()
+    B = 8
+    img = lambda p, s: (torch.rand(B, 1, 64, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(s)) > p).float()
+    x = (img(0.9, 1), torch.zeros(B, 6, device=DEV), img(0.95, 2), torch.rand(1, 1, 64, 64, device=DEV).expand(B, -1, -1, -1), img(0.9, 3))
+
+    def loss():
+        q, sf, _ = net(*x)
+        out = (q ** 2).mean()
+        return out + (sf ** 2).mean() if sf is not None else out
+
+    net.zero_grad(set_to_none=True)
+    loss().backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    tables = dqn_ops.ReduceTables(DEV)
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        with dqn_ops.deferred_wgrad_reduce(tables) as q:
+            loss().backward()
+        assert len(q.jobs) == (8 if model == "ConvNet" else 18)
+        for p, w in zip(net.parameters(), want):
+            assert torch.equal(p.grad, w)
+    with dqn_ops.deferred_wgrad_reduce(tables) as q:                          # .grad exists: nothing is deferred, gradients add up
+        loss().backward()
+    assert len(q.jobs) == 0
+    for p, w in zip(net.parameters(), want):
+        assert torch.allclose(p.grad, 2 * w, rtol=1e-6, atol=1e-12)
