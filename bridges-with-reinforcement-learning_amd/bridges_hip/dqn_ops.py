@@ -422,6 +422,7 @@ class UpConv2x2Function(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         x = _vec4(x)
         ctx.save_for_backward(x, weight)
+        ctx.owner = (weight, bias)
         return upconv2x2(x, weight, bias)
 
     @staticmethod
@@ -438,8 +439,12 @@ class UpConv2x2Function(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
         db = torch.empty(c_out, dtype=torch.float32, device=x.device)
-        abi.check(L.bridges_upconv2x2_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), scratch.numel(), n, c_in,
-                                               c_out, H, W, _stream()), "bridges_upconv2x2_backward")
+        defer = deferred_wgrad_reduce.accepts(*ctx.owner)            # placeholders for autograd, one reduction launch at the block's end
+        abi.check(L.bridges_upconv2x2_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), None if defer else _ptr(dw), None if defer else _ptr(db),
+                                               _ptr(scratch), scratch.numel(), n, c_in, c_out, H, W, _stream()), "bridges_upconv2x2_backward")
+        if defer:
+            n_w = c_in * c_out * 4
+            deferred_wgrad_reduce._active.jobs.append((ctx.owner[0], ctx.owner[1], scratch, n_w, c_out, need.value // (n_w + c_out)))
         return dx, dw, db
 
 
@@ -461,6 +466,7 @@ class Conv1x1O1Function(torch.autograd.Function):
         abi.check(L.bridges_conv1x1_o1_forward(_ptr(x), _ptr(w), _ptr(bias.contiguous()), _ptr(y), n, c_in, H * W, _stream()), "bridges_conv1x1_o1_forward")
         ctx.save_for_backward(x, w)
         ctx.w_shape = weight.shape
+        ctx.owner = (weight, bias)
         return y
 
     @staticmethod
@@ -474,8 +480,11 @@ class Conv1x1O1Function(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.empty(c_in, dtype=torch.float32, device=x.device)
         db = torch.empty(1, dtype=torch.float32, device=x.device)
-        abi.check(L.bridges_conv1x1_o1_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), scratch.numel(), n, c_in,
-                                                H * W, _stream()), "bridges_conv1x1_o1_backward")
+        defer = deferred_wgrad_reduce.accepts(*ctx.owner)
+        abi.check(L.bridges_conv1x1_o1_backward(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), None if defer else _ptr(dw), None if defer else _ptr(db),
+                                                _ptr(scratch), scratch.numel(), n, c_in, H * W, _stream()), "bridges_conv1x1_o1_backward")
+        if defer:
+            deferred_wgrad_reduce._active.jobs.append((ctx.owner[0], ctx.owner[1], scratch, c_in, 1, S))
         return dx, dw.view(ctx.w_shape), db
 
 

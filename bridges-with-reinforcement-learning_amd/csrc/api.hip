@@ -1157,7 +1157,7 @@ int bridges_upconv2x2_backward_scratch(int64_t n, int32_t c_in, int32_t c_out, i
 
 int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
                                int64_t scratch_floats, int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, void* stream) {
-    if (!x || !g || !w || !dw || !db || !scratch) return fail_arg("bridges_upconv2x2_backward");
+    if (!x || !g || !w || !scratch || (!dw) != (!db)) return fail_arg("bridges_upconv2x2_backward");
     int64_t need = 0;
     int rc = bridges_upconv2x2_backward_scratch(n, c_in, c_out, H, W, &need);
     if (rc != BRIDGES_OK) return rc;
@@ -1171,7 +1171,7 @@ int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, f
     int tps;
     const int S = up2_splits(tiles, &tps);
     float* part_b = scratch + (size_t)(S < 1 ? 1 : S) * c_in * K;
-    if (tiles == 0) {                                               // no image: zero gradients
+    if (tiles == 0 && dw) {                                         // no image: zero gradients
         if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)c_in * K, s) != hipSuccess || hipMemsetAsync(db, 0, sizeof(float) * (size_t)c_out, s) != hipSuccess)
             return fail_arg("bridges_upconv2x2_backward: hipMemsetAsync");
         return BRIDGES_OK;
@@ -1184,6 +1184,7 @@ int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, f
     if (c_in == 64) hipLaunchKernelGGL((k_up2_wgrad<4, 8>), dim3((unsigned)S), dim3(256), 0, s, x, g, part, part_b, c_out, H, W, (int)tiles, tps);
     else hipLaunchKernelGGL((k_up2_wgrad<2, 4>), dim3((unsigned)S), dim3(256), 0, s, x, g, part, part_b, c_out, H, W, (int)tiles, tps);
     LAUNCH_CHECK("k_up2_wgrad");
+    if (!dw) return BRIDGES_OK;                                    // partial sums only (bridges_reduce_jobs)
     const int n_w = c_in * K;
     hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((n_w + c_out + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
                        n_w, c_out, S);
@@ -1203,7 +1204,7 @@ int bridges_conv1x1_o1_forward(const float* x, const float* w, const float* bias
 
 int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
                                 int64_t scratch_floats, int64_t n, int32_t c_in, int32_t hw, void* stream) {
-    if (!x || !g || !w || !dx || !dw || !db || !scratch || n < 0 || c_in < 1 || c_in > 32 || hw < 4 || (hw & 3))
+    if (!x || !g || !w || !dx || !scratch || (!dw) != (!db) || n < 0 || c_in < 1 || c_in > 32 || hw < 4 || (hw & 3))
         return fail_arg("bridges_conv1x1_o1_backward: C_in <= 32, H * W a multiple of 4");
     if ((((uintptr_t)x) | ((uintptr_t)g) | ((uintptr_t)dx)) & 15) return fail_arg("bridges_conv1x1_o1_backward: x / g / dx must be 16-byte aligned");
     const int64_t quads = n * hw / 4;
@@ -1216,6 +1217,7 @@ int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, 
     float* part_b = scratch + S * c_in;
     hipLaunchKernelGGL(k_pw1_bwd, dim3((unsigned)S), dim3(256), 0, s, x, g, w, dx, part, part_b, c_in, hw, quads);
     LAUNCH_CHECK("k_pw1_bwd");
+    if (!dw) return BRIDGES_OK;                                    // partial sums only (bridges_reduce_jobs)
     hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((c_in + 1 + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db, c_in, 1,
                        (int)S);
     LAUNCH_CHECK("k_c3_reduce");

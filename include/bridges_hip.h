@@ -556,7 +556,9 @@ int bridges_maxpool2(const float* a, float* y, int64_t nc, int32_t H, int32_t W,
  * dx [n, c_in, H, W] (may be NULL), dw [c_in, c_out, 2, 2], db [c_out]; (c_in, c_out) = (32, 16) or (64, 32), H * W a multiple
  * of 64; partial sums per workgroup added in a fixed order (deterministic).  scratch: bridges_upconv2x2_backward_scratch floats.
  * bridges_conv1x1_o1_*: Conv2d(c_in, 1, kernel_size=1) (cv.py:182 outconv of UNet(1)): y [n, hw] = b + sum_c x[n, c, hw] w[c];
- * backward: dx = g w[c], dw [c_in], db [1]; c_in <= 32, hw a multiple of 4; scratch: min(256, ceil(n * hw / 1024)) * (c_in + 1). */
+ * backward: dx = g w[c], dw [c_in], db [1]; c_in <= 32, hw a multiple of 4; scratch: min(256, ceil(n * hw / 1024)) * (c_in + 1).
+ * Both backward entry points leave the partial sums in scratch ([splits][n_w] then [splits][n_b]) when dw == db == NULL, for
+ * bridges_reduce_jobs. */
 int bridges_upconv2x2_backward_scratch(int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, int64_t* floats);
 int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, float* dx, float* dw, float* db, float* scratch,
                                int64_t scratch_floats, int64_t n, int32_t c_in, int32_t c_out, int32_t H, int32_t W, void* stream);
