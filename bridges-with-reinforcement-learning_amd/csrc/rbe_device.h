@@ -39,6 +39,10 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
 #define LP_MARGIN 1e3         // a continued (warm) tableau's "infeasible" optimum below LP_MARGIN x the threshold is solved again from
                               // scratch before it is reported (observed optima: <= 3.5e-7 feasible, >= 7.8e-4 infeasible; threshold 1e-5)
+#define LP_MARGIN_LO 0.1      // ... and so is its "feasible" optimum above LP_MARGIN_LO x the threshold: the rows of a continued tableau carry
+                              // the rhs perturbations of the steps they were added in (<= 2e-7 per row, ~5e-6 over 24 rows), enough to carry
+                              // an optimum of 1.41e-5 (mixed trapezoid / hexagon bridge, mu = 2: tests/stress/stress_parity.py --task mixed
+                              // --seed 99, lock-step 88, env 797) below the threshold; the check on the original rows accepts 1e-4
 #define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
                               // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
 #ifndef LP_TAB_LDS
@@ -810,15 +814,15 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
                                     double* snap, bool* marginal) {
     const int m_act = m - 3;
     const double feas = RBE_FEAS_TOL * density, vtol = LP_VERIFY_TOL * density;
-    // an "infeasible" optimum within a factor LP_MARGIN of the threshold is the one verdict a continued tableau could owe
-    // to accumulated round-off (a "feasible" one is re-checked on the original rows): the caller re-solves it from scratch
+    // an optimum within (LP_MARGIN_LO, LP_MARGIN) x the threshold is the verdict a continued tableau could owe to accumulated
+    // round-off and to the rhs perturbations its rows were added with: the caller re-solves it from scratch
     const double near = LP_MARGIN * feas;
     *marginal = false;
     if (!warm) lp_build(T, stride, m, m_act, n, A, S.row_of, mu, density, lane, m);
     int& piv = *pivots;
     double w = lp_phase1<IN_LDS>(T, stride, m, m_act, n, S, lane, &piv, error, !warm, feas, m);
     *st_frozen = w <= feas;
-    if (w > feas && w < near) *marginal = true;
+    if (w > LP_MARGIN_LO * feas && w < near) *marginal = true;
     if (*st_frozen && m_act > 0 && lp_verify(T, stride, m, m_act, n, S, A, mu, density, lane) > vtol) {
         *st_frozen = false;                 // the verdict does not survive the check on the original rows
         *error = true;
@@ -839,7 +843,7 @@ __device__ inline void rbe_both_run(TP T, int stride, int m, int n, LpScratch& S
     lp_activate_rows<IN_LDS>(T, stride, m, m_act, n, S, lane, m);
     w = lp_phase1<IN_LDS>(T, stride, m, m, n, S, lane, &piv, error, false, feas, m);
     *st_free = w <= feas;
-    if (w > feas && w < near) *marginal = true;
+    if (w > LP_MARGIN_LO * feas && w < near) *marginal = true;
     if (*st_free && lp_verify(T, stride, m, m, n, S, A, mu, density, lane) > vtol) {
         *st_free = false;
         *error = true;
@@ -934,7 +938,7 @@ __device__ inline bool rbe_candidate_warm(double* tab_lds, int lds_cap, int max_
     lp_activate_rows<true>(tab_lds, stride, m, m - 3, n, S, lane, m);
     const double w = lp_phase1<true>(tab_lds, stride, m, m, n, S, lane, pivots, error, false, feas, m);
     bool stable = w <= feas;
-    if (w > feas && w < LP_MARGIN * feas) *error = true;       // marginal "unstable" of a continued tableau: the caller re-solves cold
+    if (w > LP_MARGIN_LO * feas && w < LP_MARGIN * feas) *error = true;   // marginal verdict of a continued tableau: the caller re-solves cold
     if (stable && lp_verify(tab_lds, stride, m, m, n, S, A, mu, density, lane) > vtol) { *error = true; stable = false; }
     return stable;
 }

@@ -12,6 +12,7 @@ then the HIP path runs the same lock-steps and the recorded arrays are compared.
         --config 3: BASELINE configs[2]  4096 envs, tower_height=4, max_steps=15, trapezoid
         --config 2: BASELINE configs[1]  1024 envs, tower_height=2, max_steps=10, trapezoid  (the simulator side)
         --config 5: BASELINE configs[4]  4096 envs, hexagon, horizontal bridge of 3, max_steps=15 (one GPU's share)
+        --config 6: 1024 envs, trapezoid + hexagon, horizontal bridge of 4, mu = 2, max_steps=12 (marginal LP optima)
 """
 import argparse
 import multiprocessing as mp
@@ -25,7 +26,11 @@ import numpy as np
 
 CONFIGS = {2: dict(envs=1024, setup="bridge", kw=dict(num_stories=2), names=["trapezoid"], max_steps=10),
            3: dict(envs=4096, setup="bridge", kw=dict(num_stories=4), names=["trapezoid"], max_steps=15),
-           5: dict(envs=4096, setup="hbridge", kw=dict(num_obstacles=3, trapezoid=False, hexagon=True), names=["hexagon"], max_steps=15)}
+           5: dict(envs=4096, setup="hbridge", kw=dict(num_obstacles=3, trapezoid=False, hexagon=True), names=["hexagon"], max_steps=15),
+           # not a BASELINE config: two shapes, mu = 2 -- the task on which a continued tableau once reported "stable" at an optimum
+           # of 1.41e-5 (threshold 1e-5; --seed 99, lock-step 88, env 797: rbe_device.h LP_MARGIN_LO)
+           6: dict(envs=1024, setup="hbridge", kw=dict(num_obstacles=4, trapezoid=True, hexagon=True), names=["trapezoid", "hexagon"],
+                   max_steps=12, mu=2.0)}
 FIELDS = ("valid_step", "no_actions", "action_index", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",
           "n_blocks", "n_reached")
 
@@ -41,7 +46,7 @@ def oracle_shard(job):
     cfg, seed, e0, e1, L, cand_every = job
     from oracle.c_env import CEnv, IMG
     from oracle.env import OracleGym
-    gym = OracleGym(**_setup(cfg), max_steps=cfg["max_steps"])
+    gym = OracleGym(**_setup(cfg), max_steps=cfg["max_steps"], mu=cfg.get("mu", 0.8))
     n = e1 - e0
     out = {k: np.zeros((L, n), dtype=np.int32) for k in FIELDS + ("n_cand", "n_valid")}
     out["reward"] = np.zeros((L, n))
@@ -98,7 +103,7 @@ def main():
     setup = _setup(cfg)
     t1 = time.time()
     vec = VecAssemblyGymGroups(E, [load_urdf(f"shapes/{n}.urdf") for n in cfg["names"]], setup["obstacles"], setup["targets"],
-                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True,
+                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True, mu=cfg.get("mu", 0.8),
                                candidate_snapshots=bool(a.candidates))
     mism, steps, lp_err, overflow = 0, 0, 0, 0
     cs_decisions = cs_mism = cs_err = 0
