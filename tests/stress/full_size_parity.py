@@ -30,14 +30,19 @@ CONFIGS = {2: dict(envs=1024, setup="bridge", kw=dict(num_stories=2), names=["tr
            # not a BASELINE config: two shapes, mu = 2 -- the task on which a continued tableau once reported "stable" at an optimum
            # of 1.41e-5 (threshold 1e-5; --seed 99, lock-step 88, env 797: rbe_device.h LP_MARGIN_LO)
            6: dict(envs=1024, setup="hbridge", kw=dict(num_obstacles=4, trapezoid=True, hexagon=True), names=["trapezoid", "hexagon"],
-                   max_steps=12, mu=2.0)}
+                   max_steps=12, mu=2.0),
+           # further stress tasks (tests/stress only): low / high friction, long episodes that fill the 16 block slots
+           7: dict(envs=1024, setup="hbridge", kw=dict(num_obstacles=5), names=["trapezoid"], max_steps=15, mu=0.5),
+           8: dict(envs=1024, setup="hbridge", kw=dict(num_obstacles=6, trapezoid=True, hexagon=True), names=["trapezoid", "hexagon"],
+                   max_steps=15, mu=1.0),
+           9: dict(envs=1024, setup="bridge", kw=dict(num_stories=6, hexagon=True), names=["trapezoid", "hexagon"], max_steps=15, mu=3.0)}
 FIELDS = ("valid_step", "no_actions", "action_index", "stable_frozen", "stable_unfrozen", "terminated", "truncated", "done",
           "n_blocks", "n_reached")
 
 
 def _setup(cfg):
     from oracle.env import bridge_setup, horizontal_bridge_setup
-    return (bridge_setup if cfg["setup"] == "bridge" else horizontal_bridge_setup)(**cfg["kw"])
+    return dict(bridge=bridge_setup, hbridge=horizontal_bridge_setup)[cfg["setup"]](**cfg["kw"])
 
 
 def oracle_shard(job):
