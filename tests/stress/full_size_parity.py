@@ -51,7 +51,7 @@ def oracle_shard(job):
     cfg, seed, e0, e1, L, cand_every = job
     from oracle.c_env import CEnv, IMG
     from oracle.env import OracleGym
-    gym = OracleGym(**_setup(cfg), max_steps=cfg["max_steps"], mu=cfg.get("mu", 0.8))
+    gym = OracleGym(**_setup(cfg), max_steps=cfg["max_steps"], mu=cfg.get("mu", 0.8), density=cfg.get("density", 1.0))
     n = e1 - e0
     out = {k: np.zeros((L, n), dtype=np.int32) for k in FIELDS + ("n_cand", "n_valid")}
     out["reward"] = np.zeros((L, n))
@@ -85,10 +85,16 @@ def main():
     ap.add_argument("--seed", type=int, default=41)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--groups", type=int, default=2, help="env groups on their own HIP streams, as bench.py runs them")
+    ap.add_argument("--density", type=float, default=0.0, help="override the block density (every force tolerance scales with it)")
+    ap.add_argument("--mu", type=float, default=0.0, help="override the friction coefficient")
     ap.add_argument("--candidates", type=int, default=0, metavar="N",
                     help="> 0: also compare is_action_stable_rbe of every valid candidate after every N-th lock-step")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
+    if a.density:
+        cfg["density"] = a.density
+    if a.mu:
+        cfg["mu"] = a.mu
     E = a.envs or cfg["envs"]
     workers = a.workers or max(1, min(len(os.sched_getaffinity(0)), 16))
     from oracle import c_env
@@ -108,7 +114,7 @@ def main():
     setup = _setup(cfg)
     t1 = time.time()
     vec = VecAssemblyGymGroups(E, [load_urdf(f"shapes/{n}.urdf") for n in cfg["names"]], setup["obstacles"], setup["targets"],
-                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True, mu=cfg.get("mu", 0.8),
+                               groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True, mu=cfg.get("mu", 0.8), density=cfg.get("density", 1.0),
                                candidate_snapshots=bool(a.candidates))
     mism, steps, lp_err, overflow = 0, 0, 0, 0
     cs_decisions = cs_mism = cs_err = 0
