@@ -469,3 +469,17 @@ def test_frozen_and_free_verdicts_of_a_step_come_from_one_operator_call(monkeypa
         single = [ops.stability(ae.blocks, f, ae.mu, ae.density, ae.floor_half_width, ae.floor_depth) for f in (fixed, fixed - {n - 1})]
         both = inner(ae.blocks, [fixed, fixed - {n - 1}], ae.mu, ae.density, ae.floor_half_width, ae.floor_depth)
         assert both == single and (single[0][0], single[1][0]) == pair
+
+
+@pytest.mark.parametrize("task,episodes", [("tower2", 30), ("mixed", 20), ("hexbridge", 20)])
+def test_random_episodes_through_the_drop_in_surface_match_the_numpy_oracle(task, episodes):
+    """tests/stress/stress_single_env.py: random-policy episodes through AssemblyGym + generate_actions / filter_actions + the feature
+    functions against oracle/env.py (numpy + HiGHS) -- candidate lists, filter masks, candidate rasters, linear rewards, every
+    step's stable flag / reward / termination, stabilities_freezing(), state rasters, distance_to_targets."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "stress", "stress_single_env.py"), "--task", task, "--episodes", str(episodes),
+                          "--seed", "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    m = re.search(r"RESULT .*: (\d+) env-steps .* (\d+) mismatches", out.stdout)
+    assert m and int(m[1]) > 2 * episodes and int(m[2]) == 0, out.stdout[-1000:]
