@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--seed", type=int, default=41)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--groups", type=int, default=2, help="env groups on their own HIP streams, as bench.py runs them")
+    ap.add_argument("--sparse", action="store_true", help="sparse row-group update of the f32 rasters (only changed rows are rewritten): "
+                    "every candidate's and every state's f32 image is compared with the expansion of its bit raster after EVERY lock-step")
     ap.add_argument("--density", type=float, default=0.0, help="override the block density (every force tolerance scales with it)")
     ap.add_argument("--mu", type=float, default=0.0, help="override the friction coefficient")
     ap.add_argument("--candidates", type=int, default=0, metavar="N",
@@ -115,8 +117,10 @@ def main():
     t1 = time.time()
     vec = VecAssemblyGymGroups(E, [load_urdf(f"shapes/{n}.urdf") for n in cfg["names"]], setup["obstacles"], setup["targets"],
                                groups=a.groups, max_steps=cfg["max_steps"], seed=a.seed, f32_rasters=True, mu=cfg.get("mu", 0.8), density=cfg.get("density", 1.0),
+                               sparse_raster_update=a.sparse,
                                candidate_snapshots=bool(a.candidates))
     mism, steps, lp_err, overflow = 0, 0, 0, 0
+    f32_every = True
     cs_decisions = cs_mism = cs_err = 0
     cat = lambda name: torch.cat([getattr(g, name) for g in vec.envs]).cpu().numpy()
     for it in range(a.locksteps):
@@ -166,13 +170,19 @@ def main():
         steps += int(v.sum())
         lp_err += int(((fl[:, 7] & 1) != 0).sum())
         overflow += int(((fl[:, 7] & 2) != 0).sum())
+        if a.sparse:                                             # the incremental f32 images never hold a stale row
+            from bridges_hip import ops
+            for g in vec.envs:
+                n = g.total_candidates()
+                f32_every &= bool(torch.equal(g.cand_raster[:n], ops.bits_to_f32(g.cand_bits[:n])))
+                f32_every &= bool(torch.equal(g.state_raster, ops.bits_to_f32(g.state_bits)))
         bad = np.flatnonzero(~ok)
         mism += bad.size
         for e in bad[:5]:
             print("MISMATCH lock-step", it, "env", e, "flags", fl[e], "sel", sel[e], "oracle", {k: o[k][e] for k in FIELDS + ("n_cand", "n_valid", "reward", "lin_reward")},
                   "gpu", dict(reward=rew[e], lin=lin[e], n_blocks=nb[e], n_cand=ncand[e], n_valid=nval[e]))
     # the f32 images of the final candidate sets are the expansion of their bit rasters (spot check of the 16 KiB-per-candidate path)
-    f32_ok = True
+    f32_ok = f32_every
     for g in vec.envs:
         tot = g.total_candidates()
         n = min(tot, 4096)
