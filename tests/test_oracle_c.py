@@ -168,9 +168,10 @@ def test_the_one_known_marginal_state_where_the_two_oracles_differ(golden_dir):
     """Documented deviation, kept visible: in 13 M stress env-steps ONE state has its phase-1 optimum at the 1e-5 threshold (an
     edge-balanced two-shape assembly at mu = 2 whose equilibrium residual is float32-mesh noise: tests/golden/
     marginal_state_mixed_seed99.json).  The C restatement -- which the HIP path follows bit for bit, continued tableaux
-    included since rbe_device.h LP_MARGIN_LO -- ends at 1.41e-5, 'unstable'; oracle/rbe.py assembles the same system in another
-    float order and HiGHS ends at 2e-7, 'stable'.  Neither is wrong at that scale; the test pins both so that a change on either
-    side shows."""
+    included since rbe_device.h LP_MARGIN_LO -- ends at 1.41e-5, 'unstable': its phase-1 simplex keeps artificials on the right-hand
+    side only, i.e. measures infeasibility one-sidedly (M x <= w); oracle/rbe.py minimises the two-sided L1 residual of the SAME
+    matrix and HiGHS ends at 2e-7, 'stable'.  The two measures agree whenever an equilibrium exists exactly; here it is missed by
+    mesh noise.  Neither is wrong at that scale; the test pins both so that a change on either side shows."""
     import json
     import os
     from oracle import rbe
