@@ -39,10 +39,12 @@ __device__ unsigned long long g_lp_prof[8];
 #define LP_PERTURB 1e-8       // rhs perturbation unit (anti-stalling)
 #define LP_MARGIN 1e3         // a continued (warm) tableau's "infeasible" optimum below LP_MARGIN x the threshold is solved again from
                               // scratch before it is reported (observed optima: <= 3.5e-7 feasible, >= 7.8e-4 infeasible; threshold 1e-5)
-#define LP_MARGIN_LO 0.1      // ... and so is its "feasible" optimum above LP_MARGIN_LO x the threshold: the rows of a continued tableau carry
-                              // the rhs perturbations of the steps they were added in (<= 2e-7 per row, ~5e-6 over 24 rows), enough to carry
-                              // an optimum of 1.41e-5 (mixed trapezoid / hexagon bridge, mu = 2: tests/stress/stress_parity.py --task mixed
-                              // --seed 99, lock-step 88, env 797) below the threshold; the check on the original rows accepts 1e-4
+#define LP_MARGIN_LO 0.1      // ... and so is its "feasible" optimum above LP_MARGIN_LO x the threshold.  Phase 1 keeps artificials on one side
+                              // of every row (the sign the right-hand side had when the row was activated), so on a system that misses an
+                              // equilibrium by mesh noise the optimum depends on that sign pattern and on the rhs perturbations the rows were
+                              // added with: a continued tableau ended below the threshold where the cold solve ends at 1.41e-5 (two-sided L1
+                              // residual of the same rows: 2e-7; mixed trapezoid / hexagon bridge, mu = 2: tests/stress/stress_parity.py
+                              // --task mixed --seed 99, lock-step 88, env 797); the check on the original rows accepts 1e-4
 #define LP_S_MAX 1e4          // budget on the total contact force sum_j x_j (oracle/rbe.py S_MAX): equilibria that exist only
                               // through forces of 1e5..1e12 x the block weights along float32 mesh noise are not equilibria
 #ifndef LP_TAB_LDS
