@@ -260,7 +260,7 @@ class ReduceTables:
             if gw is None or gb is None or not gw.is_contiguous() or not gb.is_contiguous() or gw.dtype != torch.float32:
                 raise abi.BridgesHipError("deferred_wgrad_reduce: a parameter did not receive a contiguous float32 .grad from this pass")
             rows[i] = (scratch.data_ptr(), scratch.data_ptr() + 4 * splits * n_w, gw.data_ptr(), gb.data_ptr(), n_w, n_b, splits, start)
-            start += -(-(n_w + n_b) // 16)
+            start += -(-(n_w + n_b) // (256 if splits <= 16 else 16))          # bridges_hip.h: B_j
         self.keep = [j[2] for j in jobs]
         table = _table_to_device(self.host, self.table)
         abi.check(L.bridges_reduce_jobs(_ptr(table), len(jobs), start, _stream()), "bridges_reduce_jobs")

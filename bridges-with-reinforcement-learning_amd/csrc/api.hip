@@ -1098,7 +1098,7 @@ int bridges_conv3x3_wgrad(const float* g, const float* g_mask, const float* x, f
     LAUNCH_CHECK("k_c3_wgrad");
     if (!dw) return BRIDGES_OK;                                    // partial sums only: the caller reduces them (bridges_reduce_jobs)
     const int64_t tot = n_w + c_out;
-    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)c3_reduce_blocks(tot, splits)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
                        (int)n_w, c_out, splits);
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;
@@ -1131,7 +1131,7 @@ int bridges_bias_grad(const float* g, float* db, float* scratch, int64_t scratch
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bias_grad_part, dim3((unsigned)C, (unsigned)S), dim3(256), 0, s, g, scratch, (int)n, C, hw, S);
     LAUNCH_CHECK("k_bias_grad_part");
-    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (const float*)scratch, db, db, 0, C, S);
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)c3_reduce_blocks(C, S)), dim3(256), 0, s, (const float*)scratch, (const float*)scratch, db, db, 0, C, S);
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;
 }
@@ -1186,7 +1186,7 @@ int bridges_upconv2x2_backward(const float* x, const float* g, const float* w, f
     LAUNCH_CHECK("k_up2_wgrad");
     if (!dw) return BRIDGES_OK;                                    // partial sums only (bridges_reduce_jobs)
     const int n_w = c_in * K;
-    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((n_w + c_out + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)c3_reduce_blocks(n_w + c_out, S)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db,
                        n_w, c_out, S);
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;
@@ -1218,7 +1218,7 @@ int bridges_conv1x1_o1_backward(const float* x, const float* g, const float* w, 
     hipLaunchKernelGGL(k_pw1_bwd, dim3((unsigned)S), dim3(256), 0, s, x, g, w, dx, part, part_b, c_in, hw, quads);
     LAUNCH_CHECK("k_pw1_bwd");
     if (!dw) return BRIDGES_OK;                                    // partial sums only (bridges_reduce_jobs)
-    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)((c_in + 1 + 15) / 16)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db, c_in, 1,
+    hipLaunchKernelGGL(k_c3_reduce, dim3((unsigned)c3_reduce_blocks(c_in + 1, (int)S)), dim3(256), 0, s, (const float*)part, (const float*)part_b, dw, db, c_in, 1,
                        (int)S);
     LAUNCH_CHECK("k_c3_reduce");
     return BRIDGES_OK;

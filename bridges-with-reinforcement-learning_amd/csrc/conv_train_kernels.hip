@@ -327,8 +327,25 @@ __global__ __launch_bounds__(256) void k_c3_wgrad(const float* __restrict__ g, c
 // dw[i] = sum_s part[s][i], db[c] = sum_s part_b[s][c] in a FIXED order (deterministic): a workgroup owns 16 outputs, 16 lanes
 // per output each add the splits j = lane, lane + 16, ... (four loads in flight), then a fixed butterfly over the 16 lanes.
 // (One thread per output walking 512 splits was a chain of 512 dependent-latency loads: 41 us per launch.)
+// workgroups a reduction of n = n_w + n_b outputs over `splits` partial sums takes: 16 outputs per workgroup (16 lanes per output
+// walk the splits), or -- up to 16 splits -- 256 outputs, one thread each (the deep layers: 37 k-147 k outputs, 4-16 splits: 16 x
+// fewer workgroups, the loads of a split coalesced over the outputs).  Both forms add in the same order, s = 0, 1, 2, ...
+__host__ __device__ inline int c3_reduce_blocks(int64_t n, int splits) { return (int)(splits <= 16 ? (n + 255) / 256 : (n + 15) / 16); }
+
 __device__ __forceinline__ void c3_reduce_block(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ dw,
                                                 float* __restrict__ db, int n_w, int n_b, int splits, int block) {
+    if (splits <= 16) {
+        const int i = block * 256 + threadIdx.x;
+        if (i < n_w + n_b) {
+            const bool is_w = i < n_w;
+            const float* src = is_w ? part + i : part_b + (i - n_w);
+            const size_t stride = is_w ? (size_t)n_w : (size_t)n_b;
+            float v = 0.f;
+            for (int j = 0; j < splits; ++j) v += src[(size_t)j * stride];
+            if (is_w) dw[i] = v; else db[i - n_w] = v;
+        }
+        return;
+    }
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;           // output within the group / split lane
     const int i = block * 16 + o;
     const bool is_w = i < n_w, live = i < n_w + n_b;

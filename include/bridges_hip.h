@@ -541,8 +541,9 @@ int bridges_conv3x3(const float* x, const float* in_mask, const float* w, const 
                     int32_t c_in, int32_t c_out, int32_t W, int32_t mode, int32_t transposed, void* stream);
 /* bridges_conv3x3_wgrad with dw == db == NULL leaves the partial sums in scratch ([splits][c_out * c_in * 9] then
  * [splits][c_out], splits = scratch floats / (c_out * c_in * 9 + c_out)); bridges_reduce_jobs then adds the partial sums of
- * SEVERAL layers in one launch: job j = workgroups [block_start, block_start + ceil((n_w + n_b) / 16)) of total_blocks, same
- * arithmetic and order as the single-layer form (jobs_dev: device array, ascending block_start). */
+ * SEVERAL layers in one launch: job j = workgroups [block_start, block_start + B_j) of total_blocks with B_j = ceil((n_w + n_b) /
+ * 256) when splits <= 16 and ceil((n_w + n_b) / 16) otherwise; same arithmetic and order as the single-layer form (jobs_dev:
+ * device array, ascending block_start). */
 typedef struct bridges_reduce_job {
     const float* part; const float* part_b; float* dw; float* db; int32_t n_w; int32_t n_b; int32_t splits; int32_t block_start;
 } bridges_reduce_job;
